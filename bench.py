@@ -1,0 +1,190 @@
+"""bench.py -- SE3DS hot-path throughput on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--workload gan_step|warp]
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Workloads:
+  gan_step  (default) one G+D train step (train_g_d) at 512x1024 RGB-D, bf16 compute,
+            random-init ResNet-101 G / multi-scale SN-PatchGAN D, synthetic panoramas.
+            metric = panoramas/sec.  Data-parallel over ranks (weak scaling).
+  warp      1024x2048 equirect: 2 source views unprojected, 1 target rendered per step
+            (SURVEY 8d, cfg5).  Replicas only.
+The CPU baseline leg times the oracle (oracle/, a restatement -- TF cannot run here) on a
+bounded sample on the host cores; it is a reported baseline, never the thing measured.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BF16_PEAK_TFLOPS = 2500.0  # dense MFMA bf16
+F32_PEAK_TFLOPS = 157.3
+
+
+def _dist_setup(ngpus):
+  rank = int(os.environ.get('RANK', '0'))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  local = int(os.environ.get('LOCAL_RANK', '0'))
+  torch.cuda.set_device(local)
+  if world > 1:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', local))
+  return rank, world, local
+
+
+def _barrier(world):
+  if world > 1:
+    dist.barrier()
+  torch.cuda.synchronize()
+
+
+def _max_over_ranks(x, world, dev):
+  if world == 1:
+    return x
+  t = torch.tensor([x], dtype=torch.float64, device=dev)
+  dist.all_reduce(t, op=dist.ReduceOp.MAX)
+  return float(t.item())
+
+
+# ----------------------------------------------------------------------------- warp workload
+def _warp_inputs(rng, h, w, views, dev):
+  panos = []
+  for _ in range(views):
+    rgb = rng.integers(0, 256, (1, h, w, 3)).astype(np.int32)
+    depth = rng.uniform(0, 1, (1, h, w)).astype(np.float32)
+    poison = rng.uniform(0, 1, (1, h, w))
+    depth[poison < 0.02] = 0.0
+    depth[poison > 0.99] = 1.0
+    pos = (rng.standard_normal((1, 3)) * 0.5).astype(np.float32)
+    panos.append((rgb, depth, pos))
+  target = (rng.standard_normal((1, 3)) * 0.5).astype(np.float32)
+  return panos, target
+
+
+def bench_warp(args, rank, world, dev):
+  from se3ds_amd.utils import pano_utils
+  h, w, views = args.warp_height, 2 * args.warp_height, 2
+  rng = np.random.default_rng(1234 + rank)
+  panos, target = _warp_inputs(rng, h, w, views, dev)
+  g = [(torch.from_numpy(r).to(dev), torch.from_numpy(d).to(dev), torch.from_numpy(p).to(dev))
+       for r, d, p in panos]
+  tgt = torch.from_numpy(target).to(dev)
+  P = h * w
+
+  def step():
+    xs, fs = [], []
+    for rgb, depth, pos in g:
+      x, f = pano_utils.equirectangular_to_pointcloud(rgb, depth, -1, 20.0, position=pos)
+      xs.append(x)
+      fs.append(f)
+    mem_x = torch.cat(xs, 2)  # DtoD copies (memory concat, eval_metric.py:238-239)
+    mem_f = torch.cat(fs, 1)
+    return pano_utils.project_feats_to_equirectangular(mem_f, mem_x, h, w, -1, 20.0, offset=tgt,
+                                                       with_mask=True), (mem_x, mem_f)
+
+  for _ in range(args.warmup):
+    step()
+  _barrier(world)
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  _barrier(world)
+  dt = _max_over_ranks(time.perf_counter() - t0, world, dev)
+
+  # dominant kernel chain = project+splat on a resident memory: HIP events on the launch stream
+  _, (mem_x, mem_f) = step()
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  reps = max(10, args.steps)
+  torch.cuda.synchronize()
+  ev0.record()
+  for _ in range(reps):
+    pano_utils.project_feats_to_equirectangular(mem_f, mem_x, h, w, -1, 20.0, offset=tgt,
+                                                with_mask=True)
+  ev1.record()
+  torch.cuda.synchronize()
+  proj_ms = ev0.elapsed_time(ev1) / reps
+  M = views * P
+  algo_bytes = 28 * M + 20 * P  # 28 B/point in, 16 B/px out + 4 B/px mask
+  achieved = algo_bytes / (proj_ms * 1e-3) / 1e9
+
+  out = {
+      'metric': 'panoramas/sec (2-view unproject + 1 target render, 1024x2048 equirect)',
+      'value': world * args.steps / dt, 'unit': 'panoramas/sec', 'n_gpus': world,
+      'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+      'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+      'data': 'synthetic',
+      'config': {'workload': f'warp cfg5 {h}x{w} V={views} (replicas only)'},
+      'roofline': {'bound': 'hbm', 'kernel': 'project+splat (init,zmin,resolve,finalize)',
+                   'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                   'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                   'ms_per_launch': proj_ms, 'algorithmic_bytes': algo_bytes},
+  }
+  if rank == 0 and not args.no_cpu_baseline:
+    out['cpu_baseline'] = cpu_baseline_warp(panos, target, h, w)
+  return out
+
+
+def cpu_baseline_warp(panos, target, h, w):
+  """Oracle (C restatement, 1 thread) on the same inputs, bounded to a few runs."""
+  from oracle import warp_c, warp_np
+  t0 = time.perf_counter()
+  runs = 0
+  while runs < 2 and time.perf_counter() - t0 < 30:
+    xs, fs = [], []
+    tabs = warp_np.equirect_angle_tables(h, w)
+    for rgb, depth, pos in panos:
+      x, f = warp_c.unproject_equirect(rgb, depth, tabs, -1, 20.0, position=pos)
+      xs.append(x)
+      fs.append(f)
+    warp_c.project_feats_to_equirectangular(np.concatenate(fs, 1), np.concatenate(xs, 2), h, w,
+                                            -1, 20.0, offset=target)
+    runs += 1
+  dt = (time.perf_counter() - t0) / runs
+  return {'value': 1.0 / dt, 'unit': 'panoramas/sec', 'cores': 1, 'kind': 'port',
+          'sample': f'{runs} full warp steps at {h}x{w} (C oracle restatement, not TF)'}
+
+
+# ------------------------------------------------------------------------- gan_step workload
+def bench_gan_step(args, rank, world, dev):
+  from se3ds_amd import bench_step
+  return bench_step.run(args, rank, world, dev, _barrier, _max_over_ranks)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=5)
+  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--workload', default=None, choices=['gan_step', 'warp'])
+  ap.add_argument('--warp-height', type=int, default=1024)
+  ap.add_argument('--batch', type=int, default=0, help='per-GPU batch for gan_step (0 = auto)')
+  ap.add_argument('--image-size', type=int, default=512)
+  ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  args = ap.parse_args()
+  rank, world, local = _dist_setup(args.gpus)
+  dev = torch.device('cuda', local)
+  workload = args.workload
+  if workload is None:
+    workload = 'gan_step' if os.path.exists(os.path.join(ROOT, 'se3ds_amd', 'bench_step.py')) \
+        else 'warp'
+  out = bench_warp(args, rank, world, dev) if workload == 'warp' else \
+      bench_gan_step(args, rank, world, dev)
+  if rank == 0:
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+  main()

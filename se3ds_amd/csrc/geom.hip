@@ -1,0 +1,786 @@
+// Point-cloud warp kernels for gfx950: equirect unproject, fused equirect projection +
+// z-buffer splat (zmin / resolve / finalize), bilinear gather, coordinate generators,
+// mask_pano, stream compaction.  All HBM-bound integer/float scatter-gather work: one
+// point (or pixel) per lane, coalesced row reads of the (N,4,M) coordinate planes, L2
+// atomics for the z-buffer, wave-level pre-reduction for the reference's "sink" pixel.
+//
+// Reference semantics: utils/pano_utils.py, utils/point_cloud_utils.py (see the per-entry
+// citations in include/se3ds_hip.h).  Index math lives in include/se3ds_geom_math.h and is
+// shared bit-for-bit with the CPU oracle.  Built with -ffp-contract=off.
+#include "common.h"
+#include "../../include/se3ds_geom_math.h"
+
+namespace se3ds {
+namespace {
+
+constexpr int kBlock = 256;
+
+template <typename T> struct FeatIO;
+template <> struct FeatIO<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ float cast_void(float v) { return v; }
+};
+template <> struct FeatIO<int32_t> {
+  static __device__ __forceinline__ float load(const int32_t* p) { return (float)*p; }
+  static __device__ __forceinline__ int32_t cast_void(float v) { return (int32_t)v; }
+};
+template <> struct FeatIO<uint8_t> {
+  static __device__ __forceinline__ float load(const uint8_t* p) { return (float)*p; }
+  static __device__ __forceinline__ uint8_t cast_void(float v) { return (uint8_t)v; }
+};
+
+// ------------------------------------------------------------------ unproject (equirect)
+// One pixel per lane; grid.y = batch.  pano_utils.py:219-235 with precomputed tables.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+unproject_equirect_kernel(const T* __restrict__ feats, const float* __restrict__ depth,
+                          const float* __restrict__ sin_el, const float* __restrict__ cos_el,
+                          const float* __restrict__ sin_hd, const float* __restrict__ cos_hd,
+                          const float* __restrict__ position, int height, int width, int channels,
+                          float void_class, float depth_scale, float* __restrict__ xyz1,
+                          T* __restrict__ feats_out) {
+  const int b = blockIdx.y;
+  const int64_t p = (int64_t)height * width;
+  float pos_x = 0.f, pos_y = 0.f, pos_z = 0.f;
+  if (position) {
+    pos_x = position[b * 3 + 0];
+    pos_y = position[b * 3 + 1];
+    pos_z = position[b * 3 + 2];
+  }
+  const T vc = FeatIO<T>::cast_void(void_class);
+  float* X = xyz1 + (int64_t)b * 4 * p;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p;
+       i += (int64_t)gridDim.x * kBlock) {
+    int r = (int)(i / width);
+    int col = (int)(i - (int64_t)r * width);
+    float d = depth[(int64_t)b * p + i];
+    bool valid = (d > 0.0f) && (d < 1.0f);
+    float mask = valid ? 1.0f : 0.0f;
+    float rad = (d * depth_scale) * mask;
+    float rs = rad * sin_el[r];
+    float x = rs * cos_hd[col];
+    float y = rs * sin_hd[col];
+    float z = rad * cos_el[r];
+    if (position) {
+      x = x + pos_x;
+      y = y + pos_y;
+      z = z + pos_z;
+    }
+    X[i] = x;
+    X[p + i] = y;
+    X[2 * p + i] = z;
+    X[3 * p + i] = 1.0f;
+    const T* fi = feats + ((int64_t)b * p + i) * channels;
+    T* fo = feats_out + ((int64_t)b * p + i) * channels;
+    for (int k = 0; k < channels; ++k) fo[k] = valid ? fi[k] : vc;
+  }
+}
+
+// ------------------------------------------------------------------ unproject (perspective)
+__global__ void __launch_bounds__(kBlock)
+unproject_perspective_kernel(const int32_t* __restrict__ feats, const float* __restrict__ depth,
+                             const float* __restrict__ xs, const float* __restrict__ ys,
+                             const float* __restrict__ kinv, int height, int width, int channels,
+                             float depth_scale, float* __restrict__ xyz,
+                             float* __restrict__ feats_out) {
+  const int b = blockIdx.y;
+  const int64_t p = (int64_t)height * width;
+  float k[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) k[i] = kinv[i];
+  float* X = xyz + (int64_t)b * 4 * p;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p;
+       i += (int64_t)gridDim.x * kBlock) {
+    int r = (int)(i / width);
+    int col = (int)(i - (int64_t)r * width);
+    float d = depth[(int64_t)b * p + i] * depth_scale;
+    bool valid = (d > 0.0f) && (d < depth_scale);
+    float m = valid ? 1.0f : 0.0f;
+    float v0 = (xs[col] * d) * m, v1 = (ys[r] * d) * m, v2 = d * m, v3 = 1.0f * m;
+    // tf.matmul(inv(K), xyz): 4-term dot products, accumulated left to right in fp32.
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      float acc = k[row * 4 + 0] * v0;
+      acc = acc + k[row * 4 + 1] * v1;
+      acc = acc + k[row * 4 + 2] * v2;
+      acc = acc + k[row * 4 + 3] * v3;
+      X[row * p + i] = acc;
+    }
+    const int32_t* fi = feats + ((int64_t)b * p + i) * channels;
+    float* fo = feats_out + ((int64_t)b * p + i) * channels;
+    for (int c = 0; c < channels; ++c) fo[c] = (float)(fi[c] * (valid ? 1 : 0));
+  }
+}
+
+// ------------------------------------------------------------------------------ splat
+// Workspace layout (bytes): [0,256) header: u32 sink_z (ordered), u32 sink_feat[C<=60]
+//                           then int32 idx[N*M], then float z[N*M].
+struct SplatWs {
+  uint32_t* sink_z;
+  uint32_t* sink_feat;
+  int32_t* idx;
+  float* z;
+};
+__host__ __device__ inline SplatWs carve_ws(void* ws, int n, int64_t m) {
+  SplatWs w;
+  char* p = (char*)ws;
+  w.sink_z = (uint32_t*)p;
+  w.sink_feat = (uint32_t*)(p + 16);
+  w.idx = (int32_t*)(p + 256);
+  w.z = (float*)(p + 256 + sizeof(int32_t) * (size_t)n * (size_t)m);
+  return w;
+}
+
+// K0: zmin := depth_scale (raw fp32 bits live in the depth output buffer), feat := void.
+template <bool ORDERED>
+__global__ void __launch_bounds__(kBlock)
+splat_init_kernel(float* __restrict__ zmin, float* __restrict__ feat, int64_t npx, int channels,
+                  float depth_scale, float output_void, SplatWs ws) {
+  int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * kBlock;
+  if (tid == 0) *ws.sink_z = 0xffffffffu;
+  if (tid < channels) ws.sink_feat[tid] = 0u;
+  const float fv = ORDERED ? __uint_as_float(se3ds_f32_to_ordered(output_void)) : output_void;
+  for (int64_t i = tid; i < npx; i += stride) zmin[i] = depth_scale;
+  for (int64_t i = tid; i < npx * channels; i += stride) feat[i] = fv;
+}
+
+// K1: per point -> (idx, z); atomic-min the z-buffer.  EQUIRECT fuses pano_utils.py:139-156.
+template <typename T, bool EQUIRECT>
+__global__ void __launch_bounds__(kBlock)
+splat_zmin_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
+                  const T* __restrict__ feats, int64_t m, int channels, int height, int width,
+                  float input_void, float* __restrict__ zmin, SplatWs ws) {
+  const int b = blockIdx.y;
+  const int64_t hw = (int64_t)height * width;
+  const float* X = coords + (int64_t)b * 4 * m;
+  float ox = 0.f, oy = 0.f, oz = 0.f;
+  if (EQUIRECT && offset) {
+    ox = offset[b * 3 + 0];
+    oy = offset[b * 3 + 1];
+    oz = offset[b * 3 + 2];
+  }
+  uint32_t sink = 0xffffffffu;
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < m; i0 += (int64_t)gridDim.x * kBlock) {
+    int64_t i = i0 + threadIdx.x;
+    if (i < m) {
+      float x = X[i], y = X[m + i], z = X[2 * m + i];
+      float px, py, pz;
+      if (EQUIRECT) {
+        if (offset) {
+          x = x - ox;
+          y = y - oy;
+          z = z - oz;
+        }
+        se3ds_equirect_project(x, y, z, &px, &py, &pz);
+      } else {
+        px = x;
+        py = y;
+        pz = z;
+      }
+      const T* f = feats + ((int64_t)b * m + i) * channels;
+      int fv = 1;
+      for (int k = 0; k < channels; ++k) fv &= (FeatIO<T>::load(f + k) != input_void);
+      int32_t idx = se3ds_splat_index(px, py, pz, width, height, fv);
+      ws.idx[(int64_t)b * m + i] = idx;
+      ws.z[(int64_t)b * m + i] = pz;
+      if (idx >= 0) {
+        // valid => pz > 0: raw fp32 bits are order-preserving as unsigned integers.
+        atomicMin(reinterpret_cast<unsigned int*>(zmin + (int64_t)b * hw + idx),
+                  __float_as_uint(pz));
+      } else if (pz == pz) {  // NaN never wins a min
+        uint32_t o = se3ds_f32_to_ordered(pz);
+        sink = o < sink ? o : sink;
+      }
+    }
+  }
+  // The reference redirects every invalid point to flat index 0 (point_cloud_utils.py:151-152):
+  // reduce their z per wave, one atomic per wave.
+  sink = wave_min_u32(sink);
+  if ((threadIdx.x & 63) == 0 && sink != 0xffffffffu) atomicMin(ws.sink_z, sink);
+}
+
+// K2: survivors (z < zmin + 0.1) scatter-max their features; the rest go to the sink.
+template <typename T, bool ORDERED>
+__global__ void __launch_bounds__(kBlock)
+splat_resolve_kernel(const T* __restrict__ feats, int64_t m, int channels, int height, int width,
+                     const float* __restrict__ zmin, float* __restrict__ feat, SplatWs ws) {
+  const int b = blockIdx.y;
+  const int64_t hw = (int64_t)height * width;
+  constexpr int kMaxC = 4;  // wave-reduced sink channels per pass
+  const float sink_z = se3ds_ordered_to_f32(*ws.sink_z);
+  const bool have_sink_z = (*ws.sink_z != 0xffffffffu);
+  for (int c0 = 0; c0 < channels; c0 += kMaxC) {
+    uint32_t smax[kMaxC];
+#pragma unroll
+    for (int k = 0; k < kMaxC; ++k) smax[k] = 0u;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < m; i0 += (int64_t)gridDim.x * kBlock) {
+      int64_t i = i0 + threadIdx.x;
+      if (i < m) {
+        int32_t idx = ws.idx[(int64_t)b * m + i];
+        float z = ws.z[(int64_t)b * m + i];
+        int64_t fl = idx < 0 ? 0 : (int64_t)b * hw + idx;
+        float zm = zmin[fl];
+        if (fl == 0 && have_sink_z) zm = sink_z < zm ? sink_z : zm;
+        bool keep = (idx >= 0) && (z < zm + 0.1f);
+        const T* f = feats + ((int64_t)b * m + i) * channels;
+#pragma unroll
+        for (int k = 0; k < kMaxC; ++k) {
+          if (c0 + k < channels) {
+            float v = FeatIO<T>::load(f + c0 + k);
+            if (keep) {
+              if (ORDERED) {
+                atomicMax(reinterpret_cast<unsigned int*>(feat + fl * channels + c0 + k),
+                          se3ds_f32_to_ordered(v));
+              } else if (v > 0.0f) {  // buffer starts at output_void >= 0: only v > 0 can win
+                atomicMax(reinterpret_cast<int*>(feat + fl * channels + c0 + k),
+                          __float_as_int(v));
+              }
+            } else if (v == v) {
+              uint32_t o = se3ds_f32_to_ordered(v);
+              smax[k] = o > smax[k] ? o : smax[k];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxC; ++k) {
+      uint32_t s = wave_max_u32(smax[k]);
+      if ((threadIdx.x & 63) == 0 && s != 0u && c0 + k < channels)
+        atomicMax(ws.sink_feat + c0 + k, s);
+    }
+  }
+}
+
+// K3: per pixel: fold the sink into flat pixel 0, normalise depth, decode features, mask.
+template <bool ORDERED>
+__global__ void __launch_bounds__(kBlock)
+splat_finalize_kernel(float* __restrict__ depth, float* __restrict__ feat,
+                      float* __restrict__ mask, int64_t npx, int channels, float depth_scale,
+                      float mask_void, SplatWs ws) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < npx;
+       i += (int64_t)gridDim.x * kBlock) {
+    float z = depth[i];
+    if (i == 0 && *ws.sink_z != 0xffffffffu) {
+      float sz = se3ds_ordered_to_f32(*ws.sink_z);
+      z = sz < z ? sz : z;
+    }
+    float d = z < 0.0f ? 0.0f : (z > depth_scale ? depth_scale : z);
+    d = d / depth_scale;
+    depth[i] = d;
+    bool all_ok = true;
+    for (int k = 0; k < channels; ++k) {
+      float v = feat[i * channels + k];
+      if (ORDERED) v = se3ds_ordered_to_f32(__float_as_uint(v));
+      if (i == 0 && ws.sink_feat[k] != 0u) {
+        float sv = se3ds_ordered_to_f32(ws.sink_feat[k]);
+        v = sv > v ? sv : v;
+      }
+      if (ORDERED || i == 0) feat[i * channels + k] = v;
+      all_ok = all_ok && (v != mask_void);
+    }
+    if (mask) mask[i] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+splat_debug_copy_kernel(SplatWs ws, int64_t total, int32_t* idx_out, float* z_out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kBlock) {
+    idx_out[i] = ws.idx[i];
+    z_out[i] = ws.z[i];
+  }
+}
+
+template <typename T, bool EQUIRECT>
+int launch_splat(const float* coords, const float* offset, const T* feats, int n, int64_t m,
+                 int channels, int height, int width, float depth_scale, float input_void,
+                 float output_void, float* depth, float* feat, float* mask, float mask_void,
+                 void* workspace, hipStream_t stream) {
+  SplatWs ws = carve_ws(workspace, n, m);
+  const int64_t npx = (int64_t)n * height * width;
+  const bool ordered = !(output_void >= 0.0f);
+  int g_px = grid_for(npx * (channels > 1 ? channels : 1), kBlock);
+  if (ordered)
+    hipLaunchKernelGGL(splat_init_kernel<true>, dim3(g_px), dim3(kBlock), 0, stream, depth, feat,
+                       npx, channels, depth_scale, output_void, ws);
+  else
+    hipLaunchKernelGGL(splat_init_kernel<false>, dim3(g_px), dim3(kBlock), 0, stream, depth, feat,
+                       npx, channels, depth_scale, output_void, ws);
+  if (m > 0) {
+    dim3 g_pt((unsigned)grid_for(m, kBlock), (unsigned)n);
+    hipLaunchKernelGGL((splat_zmin_kernel<T, EQUIRECT>), g_pt, dim3(kBlock), 0, stream, coords,
+                       offset, feats, m, channels, height, width, input_void, depth, ws);
+    if (ordered)
+      hipLaunchKernelGGL((splat_resolve_kernel<T, true>), g_pt, dim3(kBlock), 0, stream, feats, m,
+                         channels, height, width, depth, feat, ws);
+    else
+      hipLaunchKernelGGL((splat_resolve_kernel<T, false>), g_pt, dim3(kBlock), 0, stream, feats, m,
+                         channels, height, width, depth, feat, ws);
+  }
+  int g_fin = grid_for(npx, kBlock);
+  if (ordered)
+    hipLaunchKernelGGL(splat_finalize_kernel<true>, dim3(g_fin), dim3(kBlock), 0, stream, depth,
+                       feat, mask, npx, channels, depth_scale, mask_void, ws);
+  else
+    hipLaunchKernelGGL(splat_finalize_kernel<false>, dim3(g_fin), dim3(kBlock), 0, stream, depth,
+                       feat, mask, npx, channels, depth_scale, mask_void, ws);
+  return check_launch("splat");
+}
+
+template <bool EQUIRECT>
+int dispatch_splat(const float* coords, const float* offset, const void* feats, int feat_dtype,
+                   int n, int64_t m, int channels, int height, int width, float depth_scale,
+                   float input_void, float output_void, float* depth, float* feat, float* mask,
+                   float mask_void, void* workspace, size_t workspace_bytes, void* stream) {
+  if (n <= 0 || m < 0 || channels <= 0 || channels > 60 || height <= 0 || width <= 0)
+    return SE3DS_E_BADSHAPE;
+  if ((int64_t)n * height * width >= (int64_t)1 << 31) return SE3DS_E_BADSHAPE;
+  if (workspace_bytes < se3ds_splat_workspace_bytes(n, m, height, width, channels))
+    return SE3DS_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  switch (feat_dtype) {
+    case SE3DS_F32:
+      return launch_splat<float, EQUIRECT>(coords, offset, (const float*)feats, n, m, channels,
+                                           height, width, depth_scale, input_void, output_void,
+                                           depth, feat, mask, mask_void, workspace, s);
+    case SE3DS_I32:
+      return launch_splat<int32_t, EQUIRECT>(coords, offset, (const int32_t*)feats, n, m, channels,
+                                             height, width, depth_scale, input_void, output_void,
+                                             depth, feat, mask, mask_void, workspace, s);
+    case SE3DS_U8:
+      return launch_splat<uint8_t, EQUIRECT>(coords, offset, (const uint8_t*)feats, n, m, channels,
+                                             height, width, depth_scale, input_void, output_void,
+                                             depth, feat, mask, mask_void, workspace, s);
+    default:
+      return SE3DS_E_BADDTYPE;
+  }
+}
+
+// ------------------------------------------------------------------------- bilinear gather
+// tfa.image.interpolate_bilinear: one (query, channel) pair per lane, channel fastest so a
+// wave reads runs of contiguous channels of the four taps.
+__global__ void __launch_bounds__(kBlock)
+interp_bilinear_kernel(const float* __restrict__ grid, const float* __restrict__ query,
+                       int height, int width, int channels, int64_t q, int xy,
+                       float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int64_t total = q * channels;
+  const float* G = grid + (int64_t)b * height * width * channels;
+  const float* Q = query + (int64_t)b * q * 2;
+  float* O = out + (int64_t)b * q * channels;
+  for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * kBlock) {
+    int64_t qi = t / channels;
+    int c = (int)(t - qi * channels);
+    float q0 = Q[qi * 2 + 0], q1 = Q[qi * 2 + 1];
+    float qy = xy ? q1 : q0;
+    float qx = xy ? q0 : q1;
+    float fy = fminf(fmaxf(0.0f, floorf(qy)), (float)(height - 2));
+    float fx = fminf(fmaxf(0.0f, floorf(qx)), (float)(width - 2));
+    // NaN queries: fmaxf(0, NaN) = 0 keeps the gather in range; alpha stays NaN -> NaN out.
+    int iy = (int)fy, ix = (int)fx;
+    float ay = qy - fy, ax = qx - fx;
+    ay = (ay != ay) ? ay : fminf(fmaxf(0.0f, ay), 1.0f);
+    ax = (ax != ax) ? ax : fminf(fmaxf(0.0f, ax), 1.0f);
+    float tl = G[((int64_t)iy * width + ix) * channels + c];
+    float tr = G[((int64_t)iy * width + ix + 1) * channels + c];
+    float bl = G[((int64_t)(iy + 1) * width + ix) * channels + c];
+    float br = G[((int64_t)(iy + 1) * width + ix + 1) * channels + c];
+    float top = ax * (tr - tl) + tl;
+    float bot = ax * (br - bl) + bl;
+    O[t] = ay * (bot - top) + top;
+  }
+}
+
+// ---------------------------------------------------------------- coordinate generators
+__global__ void __launch_bounds__(kBlock)
+rotate_coords_kernel(const float* __restrict__ rays, const float* __restrict__ matrix, int64_t q,
+                     int src_h, int src_w, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  float m[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m[i] = matrix[b * 9 + i];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < q;
+       i += (int64_t)gridDim.x * kBlock) {
+    float r0 = rays[i], r1 = rays[q + i], r2 = rays[2 * q + i];
+    float x = (m[0] * r0 + m[1] * r1) + m[2] * r2;
+    float y = (m[3] * r0 + m[4] * r1) + m[5] * r2;
+    float z = (m[6] * r0 + m[7] * r1) + m[8] * r2;
+    float pitch = se3ds_acosf(-y);
+    float heading = se3ds_atan2f(x, z);
+    float hp = (heading / SE3DS_F32_TWO_PI + 0.5f) * (float)(src_w - 1);
+    float pp = pitch / SE3DS_F32_PI * (float)(src_h - 1);
+    out[((int64_t)b * q + i) * 2 + 0] = pp;
+    out[((int64_t)b * q + i) * 2 + 1] = hp;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+perspective_coords_kernel(const float* __restrict__ rays, const float* __restrict__ w2i, int64_t q,
+                          int round_nearest, float add, float* __restrict__ out) {
+  float m[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m[i] = w2i[i];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < q;
+       i += (int64_t)gridDim.x * kBlock) {
+    float r0 = rays[i], r1 = rays[q + i], r2 = rays[2 * q + i];
+    float x = (m[0] * r0 + m[1] * r1) + m[2] * r2;
+    float y = (m[3] * r0 + m[4] * r1) + m[5] * r2;
+    float z = (m[6] * r0 + m[7] * r1) + m[8] * r2;
+    float cx = z > 0.0f ? x / z : -1.0f;
+    float cy = z > 0.0f ? y / z : -1.0f;
+    if (round_nearest) {
+      cx = rintf(cx);
+      cy = rintf(cy);
+    }
+    out[i * 2 + 0] = cx + add;
+    out[i * 2 + 1] = cy + add;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+persp_from_equirect_coords_kernel(const float* __restrict__ kinv_t, const float* __restrict__ rot,
+                                  int height, int width, int eq_h, int eq_w,
+                                  float* __restrict__ out) {
+  float k[9], r[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    k[i] = kinv_t[i];
+    r[i] = rot[i];
+  }
+  const int64_t total = (int64_t)height * width;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kBlock) {
+    float px = (float)(i % width), py = (float)(i / width), pz = 1.0f;
+    // row vector times K^-T, then times R (pano_utils.py:464)
+    float a0 = (px * k[0] + py * k[3]) + pz * k[6];
+    float a1 = (px * k[1] + py * k[4]) + pz * k[7];
+    float a2 = (px * k[2] + py * k[5]) + pz * k[8];
+    float x = (a0 * r[0] + a1 * r[3]) + a2 * r[6];
+    float y = (a0 * r[1] + a1 * r[4]) + a2 * r[7];
+    float z = (a0 * r[2] + a1 * r[5]) + a2 * r[8];
+    float norm = __builtin_sqrtf((x * x + y * y) + z * z);
+    float xn = x / norm, yn = y / norm, zn = z / norm;
+    float lon = se3ds_atan2f(xn, zn);
+    float lat = se3ds_asinf(yn);
+    out[i * 2 + 0] = (lon / SE3DS_F32_TWO_PI + 0.5f) * (float)(eq_w - 1);
+    out[i * 2 + 1] = (lat / SE3DS_F32_PI + 0.5f) * (float)(eq_h - 1);
+  }
+}
+
+// ------------------------------------------------------------------------------ mask_pano
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+mask_pano_kernel(const T* __restrict__ pano, int height, int64_t row_elems, int masked_height,
+                 T value, int64_t total, T* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kBlock) {
+    int r = (int)((i / row_elems) % height);
+    bool keep = (r >= masked_height) && (r <= height - masked_height);
+    out[i] = keep ? pano[i] : value;
+  }
+}
+
+// ------------------------------------------------------------------------- compaction
+// flags -> per-block counts -> exclusive scan of block counts (one block) -> scatter.
+constexpr int kCBlock = 256;
+constexpr int kCItems = 4;  // points per thread
+constexpr int kCTile = kCBlock * kCItems;
+
+template <typename T>
+__device__ __forceinline__ bool point_valid(const T* feats, int n, int64_t m, int channels,
+                                            int64_t j, T vc) {
+  bool any = false;
+  for (int b = 0; b < n; ++b)
+    for (int k = 0; k < channels; ++k) any |= (feats[((int64_t)b * m + j) * channels + k] != vc);
+  return any;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kCBlock)
+compact_count_kernel(const T* __restrict__ feats, int n, int64_t m, int channels, float void_class,
+                     uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const T vc = FeatIO<T>::cast_void(void_class);
+  uint32_t c = 0;
+  int64_t base = (int64_t)blockIdx.x * kCTile;
+  for (int it = 0; it < kCItems; ++it) {
+    int64_t j = base + it * kCBlock + threadIdx.x;
+    if (j < m && point_valid(feats, n, m, channels, j, vc)) ++c;
+  }
+  c = (uint32_t)wave_sum((float)c);  // <= 256 per wave: exact in fp32
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt;
+}
+
+__global__ void __launch_bounds__(1024)
+compact_scan_kernel(uint32_t* __restrict__ block_counts, int64_t nblocks,
+                    int64_t* __restrict__ count_out) {
+  // single block: serial chunks + Hillis-Steele over 1024 partial sums
+  __shared__ uint64_t s[1024];
+  int64_t per = (nblocks + 1023) / 1024;
+  int64_t lo = (int64_t)threadIdx.x * per;
+  int64_t hi = lo + per < nblocks ? lo + per : nblocks;
+  uint64_t sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += block_counts[i];
+  s[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    uint64_t v = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+    __syncthreads();
+    s[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint64_t excl = s[threadIdx.x] - sum;
+  for (int64_t i = lo; i < hi; ++i) {
+    uint32_t c = block_counts[i];
+    block_counts[i] = (uint32_t)excl;
+    excl += c;
+  }
+  if (threadIdx.x == 1023) *count_out = (int64_t)s[1023];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kCBlock)
+compact_scatter_kernel(const float* __restrict__ xyz1, const T* __restrict__ feats, int n,
+                       int64_t m, int channels, float void_class,
+                       const uint32_t* __restrict__ block_offsets, float* __restrict__ xyz1_out,
+                       T* __restrict__ feats_out) {
+  __shared__ uint32_t s_wave[kCItems][kCBlock / 64];
+  const T vc = FeatIO<T>::cast_void(void_class);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t base = (int64_t)blockIdx.x * kCTile;
+  bool valid[kCItems];
+  uint32_t rank[kCItems];
+  for (int it = 0; it < kCItems; ++it) {
+    int64_t j = base + it * kCBlock + threadIdx.x;
+    valid[it] = j < m && point_valid(feats, n, m, channels, j, vc);
+    unsigned long long ball = __ballot(valid[it]);
+    rank[it] = __popcll(ball & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[it][wave] = __popcll(ball);
+  }
+  __syncthreads();
+  uint32_t run = block_offsets[blockIdx.x];
+  for (int it = 0; it < kCItems; ++it) {
+    uint32_t before = 0;
+    for (int w = 0; w < kCBlock / 64; ++w) {
+      uint32_t c = s_wave[it][w];
+      if (w < wave) before += c;
+    }
+    uint32_t total = 0;
+    for (int w = 0; w < kCBlock / 64; ++w) total += s_wave[it][w];
+    if (valid[it]) {
+      int64_t j = base + it * kCBlock + threadIdx.x;
+      int64_t dst = (int64_t)run + before + rank[it];
+      for (int b = 0; b < n; ++b) {
+        for (int r = 0; r < 4; ++r)
+          xyz1_out[((int64_t)b * 4 + r) * m + dst] = xyz1[((int64_t)b * 4 + r) * m + j];
+        for (int k = 0; k < channels; ++k)
+          feats_out[((int64_t)b * m + dst) * channels + k] =
+              feats[((int64_t)b * m + j) * channels + k];
+      }
+    }
+    run += total;
+  }
+}
+
+template <typename T>
+int launch_compact(const float* xyz1, const T* feats, int n, int64_t m, int channels,
+                   float void_class, float* xyz1_out, T* feats_out, int64_t* count_out,
+                   void* workspace, hipStream_t s) {
+  uint32_t* counts = (uint32_t*)workspace;
+  int64_t nblocks = ceil_div(m, kCTile);
+  if (nblocks == 0) {
+    (void)hipMemsetAsync(count_out, 0, sizeof(int64_t), s);
+    return check_launch("compact");
+  }
+  hipLaunchKernelGGL(compact_count_kernel<T>, dim3((unsigned)nblocks), dim3(kCBlock), 0, s, feats,
+                     n, m, channels, void_class, counts);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, counts, nblocks, count_out);
+  hipLaunchKernelGGL(compact_scatter_kernel<T>, dim3((unsigned)nblocks), dim3(kCBlock), 0, s, xyz1,
+                     feats, n, m, channels, void_class, counts, xyz1_out, feats_out);
+  return check_launch("compact");
+}
+
+}  // namespace
+}  // namespace se3ds
+
+using namespace se3ds;
+
+extern "C" {
+
+int se3ds_unproject_equirect(const void* feats, int feat_dtype, const float* depth,
+                             const float* sin_el, const float* cos_el, const float* sin_hd,
+                             const float* cos_hd, const float* position, int n, int height,
+                             int width, int channels, float void_class, float depth_scale,
+                             float* xyz1, void* feats_out, void* stream) {
+  if (n <= 0 || height <= 0 || width <= 0 || channels <= 0) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+  int64_t p = (int64_t)height * width;
+  dim3 grid((unsigned)grid_for(p, kBlock), (unsigned)n);
+  switch (feat_dtype) {
+    case SE3DS_F32:
+      hipLaunchKernelGGL(unproject_equirect_kernel<float>, grid, dim3(kBlock), 0, s,
+                         (const float*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position,
+                         height, width, channels, void_class, depth_scale, xyz1, (float*)feats_out);
+      break;
+    case SE3DS_I32:
+      hipLaunchKernelGGL(unproject_equirect_kernel<int32_t>, grid, dim3(kBlock), 0, s,
+                         (const int32_t*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position,
+                         height, width, channels, void_class, depth_scale, xyz1,
+                         (int32_t*)feats_out);
+      break;
+    case SE3DS_U8:
+      if (void_class < 0.0f) return SE3DS_E_BADDTYPE;  // pano_utils.py:193-197
+      hipLaunchKernelGGL(unproject_equirect_kernel<uint8_t>, grid, dim3(kBlock), 0, s,
+                         (const uint8_t*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position,
+                         height, width, channels, void_class, depth_scale, xyz1,
+                         (uint8_t*)feats_out);
+      break;
+    default:
+      return SE3DS_E_BADDTYPE;
+  }
+  return check_launch("unproject_equirect");
+}
+
+size_t se3ds_splat_workspace_bytes(int n, int64_t m, int height, int width, int channels) {
+  (void)height; (void)width; (void)channels;
+  return 256 + (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)(m > 0 ? m : 0) + 16;
+}
+
+int se3ds_project_equirect(const float* xyz1, const float* offset, const void* feats,
+                           int feat_dtype, int n, int64_t m, int channels, int height, int width,
+                           float depth_scale, float input_void, float output_void, float* depth,
+                           float* feat, float* mask, float mask_void, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  return dispatch_splat<true>(xyz1, offset, feats, feat_dtype, n, m, channels, height, width,
+                              depth_scale, input_void, output_void, depth, feat, mask, mask_void,
+                              workspace, workspace_bytes, stream);
+}
+
+int se3ds_project_to_feat(const float* coords, const void* feats, int feat_dtype, int n, int64_t m,
+                          int channels, int height, int width, float depth_scale,
+                          float input_void, float output_void, float* depth, float* feat,
+                          float* mask, float mask_void, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  return dispatch_splat<false>(coords, nullptr, feats, feat_dtype, n, m, channels, height, width,
+                               depth_scale, input_void, output_void, depth, feat, mask, mask_void,
+                               workspace, workspace_bytes, stream);
+}
+
+int se3ds_splat_debug_indices(const void* workspace, int n, int64_t m, int32_t* idx_out,
+                              float* z_out, void* stream) {
+  if (n <= 0 || m <= 0) return SE3DS_OK;
+  SplatWs ws = carve_ws(const_cast<void*>(workspace), n, m);
+  int64_t total = (int64_t)n * m;
+  hipLaunchKernelGGL(splat_debug_copy_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), ws, total, idx_out, z_out);
+  return check_launch("splat_debug_indices");
+}
+
+int se3ds_unproject_perspective(const int32_t* feats, const float* depth, const float* xs,
+                                const float* ys, const float* kinv, int n, int height, int width,
+                                int channels, float depth_scale, float* xyz, float* feats_out,
+                                void* stream) {
+  if (n <= 0 || height <= 0 || width <= 0 || channels <= 0) return SE3DS_E_BADSHAPE;
+  int64_t p = (int64_t)height * width;
+  dim3 grid((unsigned)grid_for(p, kBlock), (unsigned)n);
+  hipLaunchKernelGGL(unproject_perspective_kernel, grid, dim3(kBlock), 0, as_stream(stream), feats,
+                     depth, xs, ys, kinv, height, width, channels, depth_scale, xyz, feats_out);
+  return check_launch("unproject_perspective");
+}
+
+int se3ds_interp_bilinear(const float* grid, const float* query, int b, int height, int width,
+                          int channels, int64_t q, int indexing_xy, float* out, void* stream) {
+  if (b <= 0 || height < 2 || width < 2 || channels <= 0 || q < 0) return SE3DS_E_BADSHAPE;
+  if (q == 0) return SE3DS_OK;
+  dim3 g((unsigned)grid_for(q * channels, kBlock), (unsigned)b);
+  hipLaunchKernelGGL(interp_bilinear_kernel, g, dim3(kBlock), 0, as_stream(stream), grid, query,
+                     height, width, channels, q, indexing_xy, out);
+  return check_launch("interp_bilinear");
+}
+
+int se3ds_rotate_coords(const float* rays, const float* matrix, int n, int64_t q, int src_h,
+                        int src_w, float* out, void* stream) {
+  if (n <= 0 || q <= 0) return SE3DS_E_BADSHAPE;
+  dim3 g((unsigned)grid_for(q, kBlock), (unsigned)n);
+  hipLaunchKernelGGL(rotate_coords_kernel, g, dim3(kBlock), 0, as_stream(stream), rays, matrix, q,
+                     src_h, src_w, out);
+  return check_launch("rotate_coords");
+}
+
+int se3ds_perspective_coords(const float* rays, const float* w2i, int64_t q, int round_nearest,
+                             float add, float* out, void* stream) {
+  if (q <= 0) return SE3DS_E_BADSHAPE;
+  hipLaunchKernelGGL(perspective_coords_kernel, dim3(grid_for(q, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), rays, w2i, q, round_nearest, add, out);
+  return check_launch("perspective_coords");
+}
+
+int se3ds_persp_from_equirect_coords(const float* kinv_t, const float* rot, int height, int width,
+                                     int eq_h, int eq_w, float* out, void* stream) {
+  if (height <= 0 || width <= 0) return SE3DS_E_BADSHAPE;
+  hipLaunchKernelGGL(persp_from_equirect_coords_kernel,
+                     dim3(grid_for((int64_t)height * width, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), kinv_t, rot, height, width, eq_h, eq_w, out);
+  return check_launch("persp_from_equirect_coords");
+}
+
+int se3ds_mask_pano(const void* pano, int dtype, int n, int height, int width, int channels,
+                    int masked_height, float value, void* out, void* stream) {
+  if (n <= 0 || height <= 0 || width <= 0 || channels <= 0) return SE3DS_E_BADSHAPE;
+  int64_t row = (int64_t)width * channels;
+  int64_t total = (int64_t)n * height * row;
+  dim3 g(grid_for(total, kBlock));
+  hipStream_t s = as_stream(stream);
+  switch (dtype) {
+    case SE3DS_F32:
+      hipLaunchKernelGGL(mask_pano_kernel<float>, g, dim3(kBlock), 0, s, (const float*)pano, height,
+                         row, masked_height, value, total, (float*)out);
+      break;
+    case SE3DS_I32:
+      hipLaunchKernelGGL(mask_pano_kernel<int32_t>, g, dim3(kBlock), 0, s, (const int32_t*)pano,
+                         height, row, masked_height, (int32_t)value, total, (int32_t*)out);
+      break;
+    case SE3DS_U8:
+      hipLaunchKernelGGL(mask_pano_kernel<uint8_t>, g, dim3(kBlock), 0, s, (const uint8_t*)pano,
+                         height, row, masked_height, (uint8_t)value, total, (uint8_t*)out);
+      break;
+    default:
+      return SE3DS_E_BADDTYPE;
+  }
+  return check_launch("mask_pano");
+}
+
+size_t se3ds_compact_workspace_bytes(int64_t m) {
+  return sizeof(uint32_t) * (size_t)(ceil_div(m > 0 ? m : 0, kCTile) + 1) + 16;
+}
+
+int se3ds_compact_valid(const float* xyz1, const void* feats, int feat_dtype, int n, int64_t m,
+                        int channels, float void_class, float* xyz1_out, void* feats_out,
+                        int64_t* count_out, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  if (n <= 0 || m < 0 || channels <= 0) return SE3DS_E_BADSHAPE;
+  if (workspace_bytes < se3ds_compact_workspace_bytes(m)) return SE3DS_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  switch (feat_dtype) {
+    case SE3DS_F32:
+      return launch_compact<float>(xyz1, (const float*)feats, n, m, channels, void_class, xyz1_out,
+                                   (float*)feats_out, count_out, workspace, s);
+    case SE3DS_I32:
+      return launch_compact<int32_t>(xyz1, (const int32_t*)feats, n, m, channels, void_class,
+                                     xyz1_out, (int32_t*)feats_out, count_out, workspace, s);
+    case SE3DS_U8:
+      return launch_compact<uint8_t>(xyz1, (const uint8_t*)feats, n, m, channels, void_class,
+                                     xyz1_out, (uint8_t*)feats_out, count_out, workspace, s);
+    default:
+      return SE3DS_E_BADDTYPE;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""Utility functions for processing 3D point clouds -- MI355X implementation of the
+reference's utils/point_cloud_utils.py (same names, arguments and error behaviour; torch
+CUDA tensors in place of tf.Tensor).  All arithmetic runs in libse3ds_hip.so."""
+from typing import Optional, Tuple
+
+import torch
+
+from se3ds_amd import _lib
+from se3ds_amd import constants
+from se3ds_amd.utils import _host_tables
+
+
+def get_intrinsic_matrix(hfov: float) -> torch.Tensor:
+  """Returns the intrinsic for a given horizontal FOV (reference :23-29)."""
+  return torch.from_numpy(_host_tables.intrinsic_matrix_np(hfov))
+
+
+def get_filtered_coords_and_feats(feats: torch.Tensor, depth: torch.Tensor, depth_scale: float):
+  """Perspective unprojection (reference :32-87).
+
+  feats (N,H,W) or (N,H,W,C) int32, depth (N,H,W) in [0,1].
+  Returns xyz (N,4,H*W) fp32 and filtered feats (N,H*W[,C]) fp32."""
+  if feats.dim() != 3 and feats.dim() != 4:
+    raise ValueError('feats should have shape (N, H, W) or (N, H, W, C),'
+                     f' got {tuple(feats.shape)} instead.')
+  _lib.require_cuda(feats, depth)
+  is_scalar = feats.dim() == 3
+  if is_scalar:
+    feats = feats[..., None]
+  n, h, w = depth.shape
+  c = feats.shape[-1]
+  feats = feats.to(torch.int32).contiguous()
+  depth = depth.to(torch.float32).contiguous()
+  grids = _host_tables.perspective_grids(h, w, depth.device)
+  kinv = _host_tables.inv_intrinsics(constants.HFOV, depth.device)
+  xyz = torch.empty((n, 4, h * w), dtype=torch.float32, device=depth.device)
+  out = torch.empty((n, h * w, c), dtype=torch.float32, device=depth.device)
+  rc = _lib.lib().se3ds_unproject_perspective(
+      _lib.ptr(feats), _lib.ptr(depth), grids.data_ptr(), grids.data_ptr() + 4 * w,
+      _lib.ptr(kinv), n, h, w, c, float(depth_scale), _lib.ptr(xyz), _lib.ptr(out), _lib.stream())
+  _lib.check(rc, 'se3ds_unproject_perspective')
+  if is_scalar:
+    out = out[..., 0]
+  return xyz, out
+
+
+_workspaces = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+  """Grow-only scratch buffer per device (keeps allocation out of the trajectory loop)."""
+  key = str(device)
+  ws = _workspaces.get(key)
+  if ws is None or ws.numel() < nbytes:
+    ws = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=device)
+    _workspaces[key] = ws
+  return ws
+
+
+def _splat(entry: str, coords, offset, feats, height, width, depth_scale, input_void_class,
+           output_void_class, with_mask=False, mask_void=constants.INVALID_RGB_VALUE):
+  if feats.dim() != 2 and feats.dim() != 3:
+    raise ValueError('feats should have shape (N, M) or (N, M, C), got'
+                     f' {tuple(feats.shape)} instead.')
+  _lib.require_cuda(coords, feats, offset)
+  is_scalar = feats.dim() == 2
+  if is_scalar:
+    feats = feats[..., None]
+  if feats.dtype not in (torch.float32, torch.int32, torch.uint8):
+    feats = feats.to(torch.float32)
+  feats = feats.contiguous()
+  coords = coords.to(torch.float32).contiguous()
+  n, four, m = coords.shape
+  if four != 4 or feats.shape[0] != n or feats.shape[1] != m:
+    raise ValueError(f'coords {tuple(coords.shape)} and feats {tuple(feats.shape)} disagree')
+  c = feats.shape[-1]
+  dev = coords.device
+  depth = torch.empty((n, height, width), dtype=torch.float32, device=dev)
+  out = torch.empty((n, height, width, c), dtype=torch.float32, device=dev)
+  mask = torch.empty((n, height, width), dtype=torch.float32, device=dev) if with_mask else None
+  L = _lib.lib()
+  nbytes = L.se3ds_splat_workspace_bytes(n, m, height, width, c)
+  ws = _workspace(nbytes, dev)
+  if entry == 'equirect':
+    if offset is not None:
+      offset = offset.to(torch.float32).contiguous()
+    rc = L.se3ds_project_equirect(_lib.ptr(coords), _lib.ptr(offset), _lib.ptr(feats),
+                                  _lib.dtype_code(feats), n, m, c, height, width,
+                                  float(depth_scale), float(input_void_class),
+                                  float(output_void_class), _lib.ptr(depth), _lib.ptr(out),
+                                  _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(),
+                                  _lib.stream())
+    _lib.check(rc, 'se3ds_project_equirect')
+  else:
+    rc = L.se3ds_project_to_feat(_lib.ptr(coords), _lib.ptr(feats), _lib.dtype_code(feats), n, m,
+                                 c, height, width, float(depth_scale), float(input_void_class),
+                                 float(output_void_class), _lib.ptr(depth), _lib.ptr(out),
+                                 _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(),
+                                 _lib.stream())
+    _lib.check(rc, 'se3ds_project_to_feat')
+  if is_scalar:
+    out = out[..., 0]
+  if with_mask:
+    return depth, out, mask
+  return depth, out
+
+
+def project_to_feat(transformed_coords: torch.Tensor, feats: torch.Tensor, height: int,
+                    width: int, depth_scale: float, input_void_class: float,
+                    output_void_class: float = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+  """Z-buffer splat of point features (reference :90-183).
+
+  transformed_coords (N,4,M) (x, y, z, 1); feats (N,M) or (N,M,C).  Returns projected depth
+  (N,H,W) in [0,1] and projected feats (N,H,W[,C]) fp32.  Reference quirks are kept: invalid
+  and culled points scatter into flat index 0; 0.1 m tolerance; per-channel max."""
+  return _splat('generic', transformed_coords, None, feats, height, width, depth_scale,
+                input_void_class, output_void_class)
+
+
+def splat_debug_indices(n: int, m: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+  """(idx, z) of the last splat on `device` (parity tap; idx = v*W+u or -1 for the sink)."""
+  ws = _workspaces[str(device)]
+  idx = torch.empty((n, m), dtype=torch.int32, device=device)
+  z = torch.empty((n, m), dtype=torch.float32, device=device)
+  rc = _lib.lib().se3ds_splat_debug_indices(_lib.ptr(ws), n, m, _lib.ptr(idx), _lib.ptr(z),
+                                            _lib.stream())
+  _lib.check(rc, 'se3ds_splat_debug_indices')
+  return idx, z

@@ -1,0 +1,275 @@
+"""GPU parity tests of the point-cloud warp: HIP path (through the C ABI) vs the CPU oracle,
+bit-exact (indices, masks, depth, features)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import warp_c
+from oracle import warp_np
+from se3ds_amd.utils import pano_utils
+from se3ds_amd.utils import point_cloud_utils
+
+pytestmark = pytest.mark.gpu
+DEPTH_SCALE = 20.0
+F32 = np.float32
+
+
+def dev():
+  assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+  return torch.device('cuda:0')
+
+
+def t(a):
+  return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def synth_pano(rng, n, h, w):
+  rgb = rng.integers(0, 256, (n, h, w, 3)).astype(np.int32)
+  depth = rng.uniform(0, 1, (n, h, w)).astype(F32)
+  poison = rng.uniform(0, 1, (n, h, w))
+  depth[poison < 0.02] = 0.0
+  depth[poison > 0.99] = 1.0
+  return rgb, depth
+
+
+@pytest.mark.parametrize('n,h,dtype', [(2, 16, np.int32), (1, 64, np.int32), (2, 32, np.uint8),
+                                       (1, 32, np.float32)])
+def test_unproject_bit_exact(n, h, dtype):
+  rng = np.random.default_rng(10)
+  w = 2 * h
+  rgb, depth = synth_pano(rng, n, h, w)
+  feats = rgb.astype(dtype)
+  void = 0 if dtype == np.uint8 else -1
+  pos = rng.standard_normal((n, 3)).astype(F32)
+  xyz_o, f_o = warp_np.equirectangular_to_pointcloud(feats, depth, void, DEPTH_SCALE)
+  xyz_g, f_g = pano_utils.equirectangular_to_pointcloud(t(feats), t(depth), void, DEPTH_SCALE)
+  np.testing.assert_array_equal(xyz_g.cpu().numpy(), xyz_o)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+  assert f_g.cpu().numpy().dtype == dtype
+  # fused "+= position" (models.py:225-226)
+  pos4 = np.concatenate([pos, np.zeros((n, 1), F32)], 1)[:, :, None]
+  xyz_p, _ = pano_utils.equirectangular_to_pointcloud(t(feats), t(depth), void, DEPTH_SCALE,
+                                                      position=t(pos))
+  np.testing.assert_array_equal(xyz_p.cpu().numpy(), (xyz_o + pos4).astype(F32))
+  # scalar feats path
+  xs, fs = pano_utils.equirectangular_to_pointcloud(t(feats[..., 0]), t(depth), void, DEPTH_SCALE)
+  assert fs.shape == (n, h * w)
+  np.testing.assert_array_equal(fs.cpu().numpy(), f_o[..., 0])
+
+
+def test_unproject_errors():
+  d = dev()
+  with pytest.raises(ValueError):
+    pano_utils.equirectangular_to_pointcloud(torch.zeros((2, 4), device=d),
+                                             torch.zeros((1, 2, 4), device=d), 0, 20.0)
+  with pytest.raises(ValueError):
+    pano_utils.equirectangular_to_pointcloud(
+        torch.zeros((1, 2, 4, 3), dtype=torch.uint8, device=d), torch.zeros((1, 2, 4), device=d),
+        -1, 20.0)
+  with pytest.raises(AssertionError):
+    pano_utils.equirectangular_to_pointcloud(torch.zeros((1, 4, 4, 3), device=d),
+                                             torch.zeros((1, 4, 4), device=d), 0, 20.0)
+
+
+@pytest.mark.parametrize('n,h,views', [(1, 16, 1), (2, 32, 2), (1, 128, 2), (1, 256, 1)])
+def test_project_equirect_bit_exact(n, h, views):
+  rng = np.random.default_rng(11 + h)
+  w = 2 * h
+  coords, feats = [], []
+  for _ in range(views):
+    rgb, depth = synth_pano(rng, n, h, w)
+    xyz1, f = warp_np.equirectangular_to_pointcloud(rgb, depth, -1, DEPTH_SCALE)
+    pos = (rng.standard_normal((n, 3)) * 0.5).astype(F32)
+    xyz1 = xyz1 + np.concatenate([pos, np.zeros((n, 1), F32)], 1)[:, :, None]
+    coords.append(xyz1.astype(F32))
+    feats.append(f)
+  mem_xyz = np.concatenate(coords, 2)
+  mem_rgb = np.concatenate(feats, 1)
+  target = (rng.standard_normal((n, 3)) * 0.5).astype(F32)
+  m = mem_xyz.shape[2]
+
+  d_o, f_o = warp_c.project_feats_to_equirectangular(mem_rgb, mem_xyz, h, w, -1, DEPTH_SCALE,
+                                                     offset=target)
+  d_g, f_g, m_g = pano_utils.project_feats_to_equirectangular(
+      t(mem_rgb), t(mem_xyz), h, w, -1, DEPTH_SCALE, offset=t(target), with_mask=True)
+  # index-level parity: first-stage flat indices of every point
+  rel = (mem_xyz - np.concatenate([target, np.zeros((n, 1), F32)], 1)[:, :, None]).astype(F32)
+  proj = warp_c.equirect_project_coords(rel)
+  _, _, flat = warp_c.project_to_feat(proj, mem_rgb, h, w, DEPTH_SCALE, -1, return_flat=True)
+  idx_g, z_g = point_cloud_utils.splat_debug_indices(n, m, dev())
+  idx_g = idx_g.cpu().numpy().astype(np.int64)
+  flat_g = np.where(idx_g < 0, 0, idx_g + (np.arange(n)[:, None] * h * w)).reshape(-1)
+  np.testing.assert_array_equal(flat_g, flat)
+  np.testing.assert_array_equal(z_g.cpu().numpy(), proj[:, 2])
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+  np.testing.assert_array_equal(m_g.cpu().numpy()[..., None], warp_np.proj_mask(d_o, f_o, -1))
+  # the NumPy statement (libm transcendentals) agrees too
+  d_n, f_n = warp_np.project_feats_to_equirectangular(mem_rgb, rel, h, w, -1, DEPTH_SCALE)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_n)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_n)
+
+
+def test_roundtrip_property_full_size():
+  """512x1024 (BASELINE config size): unproject then project at the same position returns
+  the panorama on >= 95 % of pixels (models_test.py:62-68); we expect every valid pixel."""
+  rng = np.random.default_rng(12)
+  h, w = 512, 1024
+  rgb, depth = synth_pano(rng, 1, h, w)
+  pos = t(rng.standard_normal((1, 3)).astype(F32))
+  xyz1, f = pano_utils.equirectangular_to_pointcloud(t(rgb), t(depth), -1, DEPTH_SCALE,
+                                                     position=pos)
+  pd, prgb, pm = pano_utils.project_feats_to_equirectangular(f, xyz1, h, w, -1, DEPTH_SCALE,
+                                                             offset=pos, with_mask=True)
+  valid = (depth > 0) & (depth < 1)
+  eq = torch.all(prgb.to(torch.int32) == t(rgb), dim=-1).cpu().numpy()
+  assert eq[valid].mean() > 0.999
+  assert eq.mean() >= 0.95
+  got_d = pd.cpu().numpy()
+  assert np.mean(got_d[valid] == depth[valid]) > 0.999
+  # idempotence: re-unprojecting the projection and projecting again is a fixed point
+  xyz2, f2 = pano_utils.equirectangular_to_pointcloud(prgb.to(torch.int32), pd, -1, DEPTH_SCALE)
+  pd2, prgb2 = pano_utils.project_feats_to_equirectangular(f2, xyz2, h, w, -1, DEPTH_SCALE)
+  m = pm.cpu().numpy() > 0
+  m[0, 0, 0] = False  # the sink pixel
+  assert np.mean(pd2.cpu().numpy()[m] == got_d[m]) > 0.999
+
+
+def test_project_edge_cases():
+  d = dev()
+  h, w = 8, 16
+  # M = 0 (VLN notebook passes an all-void semantic memory)
+  pd, pf = pano_utils.project_feats_to_equirectangular(
+      torch.zeros((1, 0, 1), dtype=torch.uint8, device=d), torch.zeros((1, 4, 0), device=d), h, w,
+      0, DEPTH_SCALE)
+  assert torch.all(pd == 1.0) and torch.all(pf == 0)
+  # all points invalid (void feats) -> everything in the sink; depth[0,0,0] = min z
+  rng = np.random.default_rng(13)
+  xyz = rng.standard_normal((2, 4, 50)).astype(F32)
+  feats = np.full((2, 50, 3), -1, np.int32)
+  d_o, f_o = warp_c.project_feats_to_equirectangular(feats, xyz, h, w, -1, DEPTH_SCALE)
+  d_g, f_g = pano_utils.project_feats_to_equirectangular(t(feats), t(xyz), h, w, -1, DEPTH_SCALE)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+  # heavy collisions: all points in a few pixels, scalar uint8 semantic feats
+  xyz = (rng.standard_normal((1, 4, 5000)) * 0.01 + np.array([1, 1, 1, 0])[None, :, None]).astype(F32)
+  sem = rng.integers(0, 42, (1, 5000)).astype(np.uint8)
+  d_o, f_o = warp_c.project_feats_to_equirectangular(sem, xyz, h, w, 0, DEPTH_SCALE)
+  d_g, f_g = pano_utils.project_feats_to_equirectangular(t(sem), t(xyz), h, w, 0, DEPTH_SCALE)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+  with pytest.raises(ValueError):
+    pano_utils.project_feats_to_equirectangular(torch.zeros((1, 2, 3, 4), device=d),
+                                                torch.zeros((1, 4, 2), device=d), h, w, 0, 20.0)
+
+
+@pytest.mark.parametrize('n,size,multi', [(2, 64, False), (1, 128, True)])
+def test_perspective_unproject_and_project_to_feat(n, size, multi):
+  # utils/point_cloud_utils_test.py:26-64, against the oracle
+  rng = np.random.default_rng(14)
+  shape = (n, size, size) + ((3,) if multi else ())
+  feats = rng.integers(0, 42, shape).astype(np.int32)
+  depth = rng.uniform(0, 1.2, (n, size, size)).astype(F32)
+  x_o, f_o = warp_np.get_filtered_coords_and_feats(feats, depth, DEPTH_SCALE)
+  x_g, f_g = point_cloud_utils.get_filtered_coords_and_feats(t(feats), t(depth), DEPTH_SCALE)
+  np.testing.assert_allclose(x_g.cpu().numpy(), x_o, rtol=2e-7, atol=1e-7)  # 4-term fp32 matmul
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+  xg = x_g.cpu().numpy()
+  d_o, p_o = warp_c.project_to_feat(xg, f_o, size, size, DEPTH_SCALE, 0)
+  d_g, p_g = point_cloud_utils.project_to_feat(x_g, f_g, size, size, DEPTH_SCALE, 0)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+  np.testing.assert_array_equal(p_g.cpu().numpy(), p_o)
+  assert float(d_g.min()) >= 0 and float(d_g.max()) <= 1
+
+
+def test_project_to_feat_negative_output_void_and_negative_z():
+  rng = np.random.default_rng(15)
+  h, w = 8, 8
+  xyz = rng.standard_normal((2, 4, 400)).astype(F32)  # many z < 0 -> sink gets negative z
+  feats = (rng.standard_normal((2, 400, 2)) * 3).astype(F32)
+  d_o, f_o = warp_c.project_to_feat(xyz, feats, h, w, DEPTH_SCALE, -100.0, -5.0)
+  d_g, f_g = point_cloud_utils.project_to_feat(t(xyz), t(feats), h, w, DEPTH_SCALE, -100.0, -5.0)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+
+
+def test_plane_known_answer_on_gpu():
+  # models/models_test.py:81-137 through the product path
+  from tests.test_oracle_warp import _plane_depth
+  rng = np.random.default_rng(0)
+  size = 4
+  rgb = rng.integers(0, 255, (2, size, size * 2, 3)).astype(np.int32)
+  depth = _plane_depth(size)
+  pos = np.array([[0, 0, 0], [1, 0, 0]], F32)
+  xyz1, feats = pano_utils.equirectangular_to_pointcloud(t(rgb), t(depth), -1, DEPTH_SCALE,
+                                                         interpolation_method='bilinear',
+                                                         position=t(pos))
+  pc, mem = pano_utils.compact_valid_points(xyz1, feats, -1)
+  assert tuple(pc.shape) == (2, 4, 24)
+  pc, mem = pc.cpu().numpy(), mem.cpu().numpy()
+  for ix, (axis, value) in enumerate([(1, 1), (0, 2)]):
+    valid = np.any(mem[ix] != -1, axis=1)
+    np.testing.assert_allclose(pc[ix][axis][valid], size**2 * [value], rtol=1e-6, atol=1e-6)
+
+
+def test_compaction_matches_oracle():
+  rng = np.random.default_rng(16)
+  n, m = 2, 10007
+  xyz = rng.standard_normal((n, 4, m)).astype(F32)
+  feats = rng.integers(-1, 3, (n, m, 3)).astype(np.int32)
+  feats[:, rng.uniform(size=m) < 0.4] = -1
+  x_o, f_o = warp_np.compact_valid(xyz, feats, -1)
+  x_g, f_g = pano_utils.compact_valid_points(t(xyz), t(feats), -1)
+  np.testing.assert_array_equal(x_g.cpu().numpy(), x_o)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+
+
+def test_mask_pano_gpu():
+  rng = np.random.default_rng(17)
+  for dtype in (np.float32, np.int32, np.uint8):
+    pano = rng.integers(1, 255, (2, 64, 128, 3)).astype(dtype)
+    for val in (0, -1) if dtype != np.uint8 else (0,):
+      np.testing.assert_array_equal(pano_utils.mask_pano(t(pano), masked_region_value=val).cpu().numpy(),
+                                    warp_np.mask_pano(pano, masked_region_value=val))
+  assert pano_utils.crop_pano(t(pano)).shape == (2, 48, 128, 3)
+
+
+def test_pixel_rays_golden_product(golden_dir):
+  g = np.load(os.path.join(golden_dir, 'reference_literals.npz'))['pixel_rays_3']
+  rays = pano_utils.equirectangular_pixel_rays(3).numpy().T.reshape(3, 6, 3)
+  np.testing.assert_allclose(rays, g, rtol=1e-6, atol=1e-6)
+
+
+def test_bilinear_and_resampling_paths():
+  rng = np.random.default_rng(18)
+  grid = rng.standard_normal((2, 17, 23, 3)).astype(F32)
+  q = (rng.uniform(-2, 25, (2, 500, 2))).astype(F32)
+  for indexing in ('ij', 'xy'):
+    o = warp_np.interpolate_bilinear(grid, q, indexing)
+    g = pano_utils.interpolate_bilinear(t(grid), t(q), indexing).cpu().numpy()
+    np.testing.assert_array_equal(g, o)
+  # rotate_pano (parity unpinned by the reference; oracle follows tfa's published algorithm)
+  h, w = 32, 64
+  pano = rng.uniform(0, 1, (2, h, w, 3)).astype(F32)
+  def rot(a, b):
+    ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+    return (np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]]) @
+            np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])).astype(F32)
+  mats = np.stack([rot(0.3, -1.1), rot(-0.2, 2.0)])
+  c_o = warp_np.rotate_coords(mats, h, w, h)
+  r_o = warp_np.rotate_pano(pano, mats)
+  r_g = pano_utils.rotate_pano(t(pano), t(mats)).cpu().numpy()
+  ok = np.isfinite(c_o).all(-1).reshape(2, h, w)
+  np.testing.assert_allclose(r_g[ok], r_o[ok], rtol=0, atol=2e-5)
+  # perspective <-> equirect
+  img = rng.uniform(0, 1, (24, 24, 3)).astype(F32)
+  fov = np.array([np.pi / 2, np.pi / 2], F32)
+  p_o = warp_np.project_perspective_image(img, fov, 16, rotations=np.array([0.1, 0.4], F32))
+  p_g = pano_utils.project_perspective_image(t(img), fov, 16, rotations=np.array([0.1, 0.4], F32))
+  np.testing.assert_allclose(p_g.cpu().numpy(), p_o, rtol=0, atol=2e-5)
+  K = np.array([[12, 0, 11.5], [0, 12, 11.5], [0, 0, 1]], F32)
+  e_o = warp_np.get_perspective_from_equirectangular_image(pano[0], K, mats[0], 24, 24)
+  e_g = pano_utils.get_perspective_from_equirectangular_image(t(pano[0]), K, mats[0], 24, 24)
+  np.testing.assert_allclose(e_g.cpu().numpy(), e_o, rtol=0, atol=2e-5)
