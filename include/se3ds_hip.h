@@ -135,6 +135,183 @@ int se3ds_compact_valid(const float* xyz1, const void* feats, int feat_dtype, in
                         int channels, float void_class, float* xyz1_out, void* feats_out,
                         int64_t* count_out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ======================================================================================
+ * Convolutions (implicit GEMM on MFMA; NHWC; dtype = SE3DS_F32 or SE3DS_BF16, fp32 accumulate)
+ * Geometry arguments always describe the ASSOCIATED FORWARD CONV: input (n,h,w,cin), output
+ * (n,ho,wo,cout), kernel kh x kw, stride (1|2), explicit top/left zero padding (the bottom /
+ * right padding follows from ho/wo), wrap_w = circular padding along W (PadLayer at
+ * inference, models/layers.py:67-72; stride 1 and wo == w only).
+ * ====================================================================================== */
+
+/* fp32 master kernel HWIO viewed [K = kh*kw*cin][cout] -> compute-dtype operand copies:
+ * wt [cout][K] (forward operand) and, if non-NULL, wn [K][cout] (input-gradient operand). */
+int se3ds_weight_prep(const float* w, int64_t k, int cout, int dtype, void* wt, void* wn,
+                      void* stream);
+
+/* y = epilogue(conv(x * in_mask, W)).  Replaces tf.nn.conv2d at models/layers.py:193-198
+ * (PartialConv), :334-339 (SpectralConv), Keras Conv2D (image_models.py:513-517,542-543),
+ * and is the input-gradient of Conv2DTranspose.  in_mask (n,h,w) fp32 or NULL.  Epilogue:
+ *   t = acc * (*scale)                                  scale: device scalar or NULL
+ *   row_a != NULL, bias != NULL: t = ((t - b)*row_a + b) * row_b   (layers.py:199-202)
+ *   row_a != NULL, bias == NULL: t = t * row_a                     (layers.py:203-204)
+ *   row_a == NULL, bias != NULL: t = t + b
+ *   act: 0 none, 1 ReLU, 2 LeakyReLU(act_alpha)
+ * row_a / row_b are (n*ho*wo) fp32 vectors (mask_ratio / update_mask). */
+int se3ds_conv2d_fwd(const void* x, const void* wt, void* y, int dtype, int n, int h, int w,
+                     int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
+                     int pad_l, int wrap_w, const float* in_mask, const float* scale,
+                     const float* bias, const float* row_a, const float* row_b, int act,
+                     float act_alpha, void* stream);
+
+/* dx = epilogue(conv_transpose(dy, W)): the input-gradient of the conv above AND the forward
+ * of Keras Conv2DTranspose (models/layers.py:417-423,475-480; image_models.py:440-441), whose
+ * kernel (kh,kw,Cout_T,Cin_T) is the HWIO kernel of the associated forward conv.  wn is the
+ * [K][cout] operand copy.  dy_row_scale (n*ho*wo) optionally multiplies dy rows (partial
+ * conv: ratio*update_mask).  Epilogue: t = acc*(*scale); row_a (n*h*w): t *= row_a (the
+ * partial conv's input mask); bias (cin) added when given (ConvT bias); act as above. */
+int se3ds_conv2d_dgrad(const void* dy, const void* wn, void* dx, int dtype, int n, int h, int w,
+                       int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
+                       int pad_l, int wrap_w, const float* dy_row_scale, const float* scale,
+                       const float* bias, const float* row_a, int act, float act_alpha,
+                       void* stream);
+
+/* dW[kh,kw,cin,cout] (fp32) (+)= (*out_scale) * sum_pixels (x*in_mask)^T (dy*row_scale).
+ * The reduction over n*ho*wo is split across workgroups and reduced deterministically. */
+size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int cout, int kh,
+                                          int kw);
+int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int n, int h, int w,
+                       int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
+                       int pad_l, int wrap_w, const float* in_mask, const float* row_scale,
+                       const float* out_scale, int accumulate, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* Partial-conv mask statistics -- models/layers.py:153-163: cnt = window sum of the mask
+ * (n,h,w); ratio = kh*kw/(cnt+1e-6)*clip(cnt,0,1); um = clip(cnt,0,1); optionally
+ * ru = ratio*um and bu = (1-ratio)*um (backward helpers).  All (n,ho,wo) fp32. */
+int se3ds_mask_window(const float* mask, int n, int h, int w, int ho, int wo, int kh, int kw,
+                      int stride, int pad_t, int pad_l, int wrap_w, float* ratio, float* um,
+                      float* ru, float* bu, void* stream);
+
+/* ======================================================================================
+ * Normalisation: tensors viewed as [g][r][c]; g = 1 for SyncBatchNormalization (279 sites in
+ * the generator, e.g. models/layers.py:235-251), g = batch for tfa InstanceNormalization
+ * (image_models.py:534).  sums are [g][2][c] fp32.
+ * ====================================================================================== */
+size_t se3ds_norm_workspace_bytes(int g, int c);
+/* sums[g][0][c] = sum_r x*row_scale, sums[g][1][c] = sum_r (x*row_scale)^2 (row_scale may be NULL);
+ * also the column-sum primitive behind bias gradients. */
+int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const float* row_scale,
+                     float* sums, void* workspace, size_t workspace_bytes, void* stream);
+/* mean = S0/count, var = S1/count - mean^2 (biased); scale = gamma*rsqrt(var+eps),
+ * shift = beta - mean*scale; moving stats (c) updated in place unless NULL;
+ * use_moving != 0: inference (statistics from moving_mean / moving_var). */
+int se3ds_norm_finalize(const float* sums, float count, int g, int c, const float* gamma,
+                        const float* beta, float eps, float momentum, float* moving_mean,
+                        float* moving_var, int use_moving, float* scale, float* shift, float* mean,
+                        float* rstd, void* stream);
+/* y = act(x*scale + shift [+ res]) [+ post]  (scale/shift are [g][c]). */
+int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const float* scale,
+                     const float* shift, const void* res, const void* post, int act, float alpha,
+                     void* y, void* stream);
+/* sums[g][0][c] = sum dpre, sums[g][1][c] = sum dpre*xhat with dpre = dy*act'(y). */
+int se3ds_norm_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
+                         int c, const float* mean, const float* rstd, int act, float alpha,
+                         float* sums, void* workspace, size_t workspace_bytes, void* stream);
+/* dx = gamma*rstd*(dpre - S0/count - xhat*S1/count); dres = dpre when non-NULL. */
+int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
+                         int c, const float* mean, const float* rstd, const float* gamma,
+                         const float* sums, float count, int act, float alpha, void* dx,
+                         void* dres, void* stream);
+/* inference-mode backward: dx = dpre*scale; dres = dpre. */
+int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r, int c,
+                     const float* scale, int act, float alpha, void* dx, void* dres, void* stream);
+
+/* ======================================================================================
+ * Pointwise / pooling
+ * ====================================================================================== */
+int se3ds_act_bwd(const void* dy, const void* y, int dtype, int64_t n, int act, float alpha,
+                  void* dx, void* stream);
+int se3ds_add(const void* a, const void* b, int dtype, int64_t n, void* out, void* stream);
+/* Keras MaxPool2D(2, padding='SAME') -- image_models.py:267,289 */
+int se3ds_maxpool2x2_fwd(const void* x, int dtype, int n, int h, int w, int c, void* y,
+                         void* stream);
+int se3ds_maxpool2x2_bwd(const void* dy, const void* x, const void* y, int dtype, int n, int h,
+                         int w, int c, void* dx, void* stream);
+/* tf.nn.avg_pool(ksize=3, strides=2, 'SAME') -- image_models.py:617 */
+int se3ds_avgpool3s2_fwd(const void* x, int dtype, int n, int h, int w, int c, void* y,
+                         void* stream);
+int se3ds_avgpool3s2_bwd(const void* dy, int dtype, int n, int h, int w, int c, void* dx,
+                         void* stream);
+/* Keras UpSampling2D() nearest x2 -- image_models.py:371,378 */
+int se3ds_upsample2x_fwd(const void* x, int dtype, int n, int h, int w, int c, void* y,
+                         void* stream);
+int se3ds_upsample2x_bwd(const void* dy, int dtype, int n, int h, int w, int c, void* dx,
+                         void* stream);
+/* dst[r, dst_c0 + i] = convert(src[r, src_c0 + i]), i < ncopy: tf.concat / tf.split along
+ * channels with dtype conversion (image_models.py:157-162, se3ds_trainer.py:181-192). */
+int se3ds_copy_channels(const void* src, int src_dtype, int src_c, int src_c0, void* dst,
+                        int dst_dtype, int dst_c, int dst_c0, int ncopy, int64_t rows,
+                        void* stream);
+int se3ds_fill(void* p, int dtype, int64_t n, float value, void* stream);
+/* PadLayer as a standalone op -- models/layers.py:22-97: pad H and W by `pad`; mode 0
+ * CONSTANT(value) / 1 REFLECT / 2 SYMMETRIC; wrap_w != 0: W is padded circularly. */
+int se3ds_pad2d(const void* x, int dtype, int n, int h, int w, int c, int pad, int mode, int wrap_w,
+                float value, void* y, void* stream);
+/* heads -- image_models.py:187-190. kind 0: (tanh(x)+1)/2, kind 1: clip(x,0,1); y is fp32. */
+int se3ds_head_fwd(const void* x, int dtype, int64_t n, int kind, float* y, void* stream);
+int se3ds_head_bwd(const float* dy, const float* y, const void* x, int dtype, int64_t n, int kind,
+                   void* dx, void* stream);
+
+/* ======================================================================================
+ * Losses -- trainers/se3ds_trainer.py:39-71,148-234 (fp32)
+ * ====================================================================================== */
+/* out[n] = per-sample sum; mode 0: sum(a); 1: sum(|a-b|*m[p]); 2: count(0<a<1);
+ * 3: sum(a*(1-b)).  a,b: (n,p,c); m: (n,p). */
+int se3ds_sample_sum(const float* a, const float* b, const float* m, int n, int64_t p, int c,
+                     int mode, float* out, void* stream);
+/* grad = coef[n]*sign(a-b)*w; mode 0: w = 1[0<b<1] (depth L1); mode 1: w = m*(1-m2) (wc). */
+int se3ds_l1_grad(const float* a, const float* b, const float* m, const float* m2,
+                  const float* coef, int n, int64_t p, int c, int mode, float* grad, void* stream);
+/* out[i] = scale / max(sums[i], 1): per-sample loss normalisers (se3ds_trainer.py:151-152). */
+int se3ds_recip_clamp(const float* sums, int n, float scale, float* out, void* stream);
+/* logits (2*half) [fake | real]: sums[0] = sum(-fake), sums[1] = sum(relu(1-real)+relu(1+fake));
+ * dlog_d = cd * d(sums[1])/dlogits, dlog_g = cg * d(sums[0])/dlogits (either may be NULL). */
+int se3ds_hinge(const void* logits, int dtype, int64_t half, float cd, float cg, float* sums,
+                void* dlog_d, void* dlog_g, void* stream);
+
+/* ======================================================================================
+ * Optimiser step over flat fp32 arenas -- se3ds_trainer.py:27-32,238-257;
+ * gan_manager.py:175-183; utils/ema.py:54-64
+ * ====================================================================================== */
+/* chunks: int64 triples (tensor id, start, length<=65536) covering the arena;
+ * tensor_chunk_start: (ntensors+1) prefix into chunks.  sqnorm[t] = sum g^2 of tensor t. */
+int se3ds_multi_sqnorm(const float* grads, const int64_t* chunks, int64_t nchunks,
+                       const int64_t* tensor_chunk_start, int ntensors, float* partial,
+                       float* sqnorm, void* stream);
+/* tf.clip_by_norm per tensor, in place: g = (g*clip)/max(||g||, clip); mean_norm_out (device
+ * scalar, may be NULL) = mean over tensors of the clipped norms (NaN -> 0). */
+int se3ds_multi_clip_by_norm(float* grads, const int64_t* chunks, int64_t nchunks,
+                             const float* sqnorm, int ntensors, float clip_norm,
+                             float* mean_norm_out, void* stream);
+/* Keras Adam (ResourceApplyAdam), `step` = iteration count t >= 1. */
+int se3ds_multi_adam_keras(float* params, const float* grads, float* m, float* v, int64_t n,
+                           float lr, float beta1, float beta2, float eps, int64_t step,
+                           void* stream);
+/* ema -= (ema - vars) * one_minus_decay */
+int se3ds_multi_ema(float* ema, const float* vars, int64_t n, float one_minus_decay, void* stream);
+
+/* Spectral normalisation, batched over layers -- models/layers.py:312-331.  `table` is a
+ * device array of se3ds_spectral_table_fields() int64 per layer:
+ *   W, u, v (K), uhat (cout), sig (2: sigma, 1/(sigma+1e-10)), part (part_rows*cout),
+ *   vpart (vpart_len), K, cout, grad
+ * power_iter: v_hat, u_hat, sigma from (W,u); u := u_hat when training != 0.
+ * bwd_fixup: grad := grad/(sigma+eps) - <grad,W>/(sigma+eps)^2 * v_hat^T u_hat. */
+int se3ds_spectral_table_fields(void);
+int se3ds_spectral_part_rows(void);
+int se3ds_spectral_vpart_len(void);
+int se3ds_spectral_power_iter(const int64_t* table, int nlayers, int training, void* stream);
+int se3ds_spectral_bwd_fixup(const int64_t* table, int nlayers, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 constexpr int kWave = 64;
 
-inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Grid size for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8.
 inline int grid_for(int64_t work_items, int block) {
@@ -65,6 +65,54 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     v = t > v ? t : v;
   }
   return v;
+}
+
+// ---- typed 16-byte vector access (fp32 x4 / bf16 x8) and activation helpers
+template <typename T> struct VT;
+template <> struct VT<float> {
+  static constexpr int V = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+  static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+};
+template <> struct VT<uint16_t> {
+  static constexpr int V = 8;
+  static __device__ __forceinline__ void load(const uint16_t* p, float (&o)[8]) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = __uint_as_float(q[e] << 16);
+      o[2 * e + 1] = __uint_as_float(q[e] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(uint16_t* p, const float (&o)[8]) {
+    uint32_t q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      q[e] = (uint32_t)f32_to_bf16(o[2 * e]) | ((uint32_t)f32_to_bf16(o[2 * e + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(q[0], q[1], q[2], q[3]);
+  }
+  static __device__ __forceinline__ float ld1(const uint16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st1(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float act_apply(float v, int act, float alpha) {
+  if (act == 1) return v > 0.f ? v : 0.f;
+  if (act == 2) return v > 0.f ? v : v * alpha;
+  return v;
+}
+// derivative of the activation expressed through its OUTPUT y (alpha > 0 keeps the sign)
+__device__ __forceinline__ float act_grad_from_out(float y, int act, float alpha) {
+  if (act == 1) return y > 0.f ? 1.f : 0.f;
+  if (act == 2) return y > 0.f ? 1.f : alpha;
+  return 1.f;
 }
 
 }  // namespace se3ds

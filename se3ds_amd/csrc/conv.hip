@@ -1,0 +1,773 @@
+// Implicit-GEMM convolution family for gfx950 (CDNA4), NHWC, bf16 or fp32 operands with
+// fp32 MFMA accumulation.  Three kernels cover every contraction on the SE3DS path:
+//
+//   igemm<FWD>    y[n,oy,ox,co]  = sum_{ky,kx,ci} x[n, oy*s-pt+ky, ox*s-pl+kx, ci] * W[ky,kx,ci,co]
+//                 conv forward (layers.py:193-198,334-339) and ConvT input-gradient
+//   igemm<DGRAD>  dx[n,iy,ix,ci] = sum_{ky,kx,co} dy[n,(iy+pt-ky)/s,(ix+pl-kx)/s,co] * W[ky,kx,ci,co]
+//                 conv input-gradient and Conv2DTranspose forward (layers.py:417-423,475-480;
+//                 the Keras ConvT kernel (kh,kw,Cout_T,Cin_T) IS the HWIO kernel of the
+//                 associated forward conv).  Strided: output pixels are grouped by parity
+//                 class so that every tile only visits the taps that hit it (no zero work).
+//   wgrad         dW[ky,kx,ci,co] = sum_{n,oy,ox} x[..] * dy[n,oy,ox,co]   (fp32, split over L)
+//
+// Tiling (wave64): 128x128 output tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA 32x32
+// tiles (64 accumulator VGPRs).  K step = one 64-byte row chunk (32 bf16 / 16 fp32).  Operand
+// tiles are staged global -> registers -> LDS (double buffered; the next tile's global loads
+// are in flight under the current tile's MFMAs), rows of 64 B with an XOR swizzle of the
+// 16-byte chunk index so ds_read_b128 fragment reads are bank-conflict free.  Zero / circular
+// padding (PadLayer, layers.py:62-97) and the partial-conv input mask are folded into the
+// gather; the partial-conv renormalisation, spectral 1/sigma scale, bias and activation are
+// the epilogue.  The weight operand is the MFMA "A" side so each lane ends up holding 4
+// consecutive output channels of one pixel (8/16-byte stores).
+#include "common.h"
+
+namespace se3ds {
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int BM = 128;     // pixels per tile
+constexpr int BN = 128;     // output channels per tile
+constexpr int kThreads = 256;
+constexpr int ROWB = 64;    // bytes per LDS row (one K step)
+constexpr int TILE_BYTES = 128 * ROWB;  // one operand tile: 8 KiB
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+  static constexpr int EPC = 4;   // elements per 16-byte chunk
+  static constexpr int BK = 16;   // elements per K step
+  static __device__ __forceinline__ float to_f(float v) { return v; }
+  static __device__ __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct TT<uint16_t> {  // bf16 raw bits
+  static constexpr int EPC = 8;
+  static constexpr int BK = 32;
+  static __device__ __forceinline__ float to_f(uint16_t v) { return bf16_to_f32(v); }
+  static __device__ __forceinline__ uint16_t from_f(float v) { return f32_to_bf16(v); }
+};
+
+struct IgemmParams {
+  // source tensor of the gather (x for FWD, dy for DGRAD) and its dims
+  const void* src; int sH, sW, sC;
+  // weights: element (tap, n_out, c_red) at w + tap*w_tap + n_out*w_n + c_red
+  const void* w; int64_t w_tap, w_n;
+  void* out;              // output tensor, rows of oC channels
+  int N, oH, oW, oC;      // output spatial dims / channels
+  int kh, kw, stride, pad_t, pad_l, wrap_w;
+  // DGRAD parity classes (stride^2 of them); FWD uses class 0 only
+  int n_classes; int cls_tile_start[5]; int cls_py[4], cls_px[4];
+  // gather-side per-pixel multiplier (partial conv: x * mask), (N,sH,sW) fp32 or null
+  const float* src_mask;
+  // epilogue
+  const float* scale;     // device scalar (1/(sigma+eps)) or null
+  const float* bias;      // (oC) or null
+  const float* row_a;     // (N*oH*oW) ratio / mask or null
+  const float* row_b;     // (N*oH*oW) update_mask or null (only with bias)
+  int act; float act_alpha;  // 0 none, 1 relu, 2 leaky relu
+  int vec;                // reduction channels % BK == 0 -> vector gather
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+template <typename T>
+__device__ __forceinline__ void mfma_tile(f32x16_t (&acc)[2][2], const uint4 (&wf)[2][2],
+                                          const uint4 (&xf)[2][2]);
+
+template <>
+__device__ __forceinline__ void mfma_tile<uint16_t>(f32x16_t (&acc)[2][2],
+                                                    const uint4 (&wf)[2][2],
+                                                    const uint4 (&xf)[2][2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            __builtin_bit_cast(bf16x8_t, wf[i][ks]), __builtin_bit_cast(bf16x8_t, xf[j][ks]),
+            acc[i][j], 0, 0, 0);
+}
+
+template <>
+__device__ __forceinline__ void mfma_tile<float>(f32x16_t (&acc)[2][2], const uint4 (&wf)[2][2],
+                                                 const uint4 (&xf)[2][2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint32_t wa = e == 0 ? wf[i][ks].x : e == 1 ? wf[i][ks].y
+                            : e == 2 ? wf[i][ks].z : wf[i][ks].w;
+          const uint32_t xb = e == 0 ? xf[j][ks].x : e == 1 ? xf[j][ks].y
+                            : e == 2 ? xf[j][ks].z : xf[j][ks].w;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wa),
+                                                           __uint_as_float(xb), acc[i][j], 0, 0, 0);
+        }
+}
+
+// Decoded coordinates of one gather row (an output pixel of this kernel).
+struct RowInfo {
+  int n, a, b;   // FWD: (n, oy, ox)   DGRAD: (n, iy, ix)
+  bool valid;
+};
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kThreads, 2)
+igemm_kernel(const IgemmParams p) {
+  using tt = TT<T>;
+  constexpr int EPC = tt::EPC, BK = tt::BK;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+  // stage s: W tile at smem + s*2*TILE, X tile at + TILE
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;  // wave position: wm over channels, wn over pixels
+
+  // ---- which tile
+  int cls = 0;
+  if (MODE == MODE_DGRAD) {
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+      if (c < p.n_classes && (int)blockIdx.x >= p.cls_tile_start[c]) cls = c;
+  }
+  const int tile_m = blockIdx.x - p.cls_tile_start[cls];
+  const int n0 = blockIdx.y * BN;           // first output channel of the tile
+  const int s = p.stride;
+  int py = 0, px = 0, cH = p.oH, cW = p.oW;  // class sub-grid
+  int ky0 = 0, kx0 = 0, kstep = 1, nky = p.kh, nkx = p.kw;
+  if (MODE == MODE_DGRAD) {
+    py = p.cls_py[cls]; px = p.cls_px[cls];
+    cH = (p.oH - py + s - 1) / s;
+    cW = (p.oW - px + s - 1) / s;
+    ky0 = (py + p.pad_t) % s; kx0 = (px + p.pad_l) % s; kstep = s;
+    nky = ky0 < p.kh ? (p.kh - ky0 + s - 1) / s : 0;
+    nkx = kx0 < p.kw ? (p.kw - kx0 + s - 1) / s : 0;
+  }
+  const int64_t Mc = (int64_t)p.N * cH * cW;
+  const int ntaps = nky * nkx;
+  const int Cr = p.sC;  // reduction channels per tap
+
+  // ---- this thread's two staging rows (row, row+64) and chunk
+  const int chunk = tid & 3;
+  const int srow = tid >> 2;
+  RowInfo ri[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    int64_t m = (int64_t)tile_m * BM + srow + h * 64;
+    ri[h].valid = m < Mc;
+    int64_t mm = ri[h].valid ? m : 0;
+    int n = (int)(mm / ((int64_t)cH * cW));
+    int rem = (int)(mm - (int64_t)n * cH * cW);
+    int a = rem / cW, b = rem - a * cW;
+    ri[h].n = n;
+    ri[h].a = MODE == MODE_DGRAD ? py + a * s : a;
+    ri[h].b = MODE == MODE_DGRAD ? px + b * s : b;
+  }
+
+  const T* __restrict__ src = (const T*)p.src;
+  const T* __restrict__ wp = (const T*)p.w;
+
+  // source pixel of (row, tap); returns false when the tap falls in the zero padding
+  auto src_pixel = [&](const RowInfo& r, int ky, int kx, int64_t& pix) -> bool {
+    int sy, sx;
+    if (MODE == MODE_FWD) {
+      sy = r.a * s - p.pad_t + ky;
+      sx = r.b * s - p.pad_l + kx;
+      if (p.wrap_w) { sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx); }
+    } else {
+      int ty = r.a + p.pad_t - ky, tx = r.b + p.pad_l - kx;
+      if (p.wrap_w) { tx = tx < 0 ? tx + p.sW : (tx >= p.sW ? tx - p.sW : tx); }
+      if (ty < 0 || tx < 0) return false;
+      sy = ty / s; sx = tx / s;  // exact by construction of the class tap list
+    }
+    if (sy < 0 || sy >= p.sH || sx < 0 || sx >= p.sW) return false;
+    pix = ((int64_t)r.n * p.sH + sy) * p.sW + sx;
+    return true;
+  };
+
+  const int ksteps_per_tap = p.vec ? Cr / BK : 0;
+  const int64_t Ktot = (int64_t)ntaps * Cr;
+  const int nk = p.vec ? ntaps * ksteps_per_tap : (int)((Ktot + BK - 1) / BK);
+
+  uint4 rx[2], rw[2];  // staged chunks: X rows (srow, srow+64), W rows (srow, srow+64)
+
+  auto load_step = [&](int kstep_i) {
+    if (p.vec) {
+      int tap = kstep_i / ksteps_per_tap;
+      int c0 = (kstep_i - tap * ksteps_per_tap) * BK + chunk * EPC;
+      int ky = ky0 + kstep * (tap / nkx), kx = kx0 + kstep * (tap % nkx);
+      int tap_lin = ky * p.kw + kx;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        int64_t pix;
+        if (ri[h].valid && src_pixel(ri[h], ky, kx, pix)) {
+          v = *reinterpret_cast<const uint4*>(src + pix * Cr + c0);
+          if (p.src_mask) {
+            float mk = p.src_mask[pix];
+            if (sizeof(T) == 4) {
+              v.x = __float_as_uint(__uint_as_float(v.x) * mk);
+              v.y = __float_as_uint(__uint_as_float(v.y) * mk);
+              v.z = __float_as_uint(__uint_as_float(v.z) * mk);
+              v.w = __float_as_uint(__uint_as_float(v.w) * mk);
+            } else {
+              uint32_t* q = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float lo = __uint_as_float(q[e] << 16) * mk;
+                float hi = __uint_as_float(q[e] & 0xffff0000u) * mk;
+                q[e] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+              }
+            }
+          }
+        }
+        rx[h] = v;
+        uint4 wv = make_uint4(0, 0, 0, 0);
+        int co = n0 + srow + h * 64;
+        if (co < p.oC)
+          wv = *reinterpret_cast<const uint4*>(wp + (int64_t)tap_lin * p.w_tap +
+                                               (int64_t)co * p.w_n + c0);
+        rw[h] = wv;
+      }
+    } else {
+      // generic gather: K is the linear (tap, channel) index, decoded per element
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        T xe[EPC], we[EPC];
+        int co = n0 + srow + h * 64;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          int64_t kk = (int64_t)kstep_i * BK + chunk * EPC + e;
+          T xv = tt::from_f(0.f), wv = tt::from_f(0.f);
+          if (kk < Ktot) {
+            int tap = (int)(kk / Cr);
+            int c = (int)(kk - (int64_t)tap * Cr);
+            int ky = ky0 + kstep * (tap / nkx), kx = kx0 + kstep * (tap % nkx);
+            int64_t pix;
+            if (ri[h].valid && src_pixel(ri[h], ky, kx, pix)) {
+              xv = src[pix * Cr + c];
+              if (p.src_mask) xv = tt::from_f(tt::to_f(xv) * p.src_mask[pix]);
+            }
+            if (co < p.oC)
+              wv = wp[(int64_t)(ky * p.kw + kx) * p.w_tap + (int64_t)co * p.w_n + c];
+          }
+          xe[e] = xv; we[e] = wv;
+        }
+        rx[h] = *reinterpret_cast<uint4*>(xe);
+        rw[h] = *reinterpret_cast<uint4*>(we);
+      }
+    }
+  };
+
+  auto store_step = [&](int stage) {
+    unsigned char* wt = smem + stage * 2 * TILE_BYTES;
+    unsigned char* xt = wt + TILE_BYTES;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int row = srow + h * 64;
+      int off = row * ROWB + swz(row, chunk) * 16;
+      *reinterpret_cast<uint4*>(wt + off) = rw[h];
+      *reinterpret_cast<uint4*>(xt + off) = rx[h];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    load_step(0);
+    store_step(0);
+  }
+  __syncthreads();
+  const int half = lane >> 5, l32 = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) load_step(kt + 1);  // global loads in flight under the MFMAs below
+    const unsigned char* wt = smem + stage * 2 * TILE_BYTES;
+    const unsigned char* xt = wt + TILE_BYTES;
+    uint4 wf[2][2], xf[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        int wrow = wm * 64 + i * 32 + l32;
+        int xrow = wn * 64 + i * 32 + l32;
+        int c = ks * 2 + half;
+        wf[i][ks] = *reinterpret_cast<const uint4*>(wt + wrow * ROWB + swz(wrow, c) * 16);
+        xf[i][ks] = *reinterpret_cast<const uint4*>(xt + xrow * ROWB + swz(xrow, c) * 16);
+      }
+    mfma_tile<T>(acc, wf, xf);
+    if (kt + 1 < nk) store_step(stage ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[i][j][r]: channel = n0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*half,
+  //                               pixel row = wn*64 + j*32 + l32
+  const float scale = p.scale ? *p.scale : 1.0f;
+  T* __restrict__ out = (T*)p.out;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int64_t m = (int64_t)tile_m * BM + wn * 64 + j * 32 + l32;
+    if (m >= Mc) continue;
+    int n = (int)(m / ((int64_t)cH * cW));
+    int rem = (int)(m - (int64_t)n * cH * cW);
+    int a = rem / cW, b = rem - a * cW;
+    if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
+    const int64_t opix = ((int64_t)n * p.oH + a) * p.oW + b;
+    const float ra = p.row_a ? p.row_a[opix] : 1.0f;
+    const float rb = p.row_b ? p.row_b[opix] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = n0 + wm * 64 + i * 32 + g * 8 + half * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[i][j][g * 4 + e] * scale;
+          const float bv = (p.bias && co + e < p.oC) ? p.bias[co + e] : 0.0f;
+          if (p.row_a) {
+            if (p.bias) t = ((t - bv) * ra + bv) * rb;
+            else t = t * ra;
+          } else if (p.bias) {
+            t = t + bv;
+          }
+          if (p.act == 1) t = t > 0.f ? t : 0.f;
+          else if (p.act == 2) t = t > 0.f ? t : t * p.act_alpha;
+          v[e] = t;
+        }
+        T* o = out + opix * p.oC + co;
+        if (co + 3 < p.oC && (p.oC & 3) == 0) {
+          if (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(o) = pk;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.oC) o[e] = tt::from_f(v[e]);
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------- wgrad
+// dW[(tap,ci), co] = sum_l xg[l,(tap,ci)] * dy[l, co].  Tile: 128 (ci of one tap) x 128 (co),
+// reduction over pixels l in steps of 32.  Both operands have the reduction dim as the SLOW
+// memory dim ([l][c]); bf16 fragments (8 consecutive l per lane) come from
+// ds_read_b64_tr_b16 transposing reads, fp32 fragments from plain ds_read_b32.
+struct WgradParams {
+  const void* x; int H, W, Cin;       // gathered operand (image side)
+  const void* dy; int Ho, Wo, Cout;   // output-side operand
+  int N, kh, kw, stride, pad_t, pad_l, wrap_w;
+  const float* src_mask;              // (N,H,W) or null: x * mask (partial conv)
+  const float* row_scale;             // (N*Ho*Wo) or null: dy * row_scale (partial renorm)
+  float* dw;                          // [split][kh*kw*Cin][Cout] fp32 partial sums
+  int splits; int64_t l_per_split;    // pixels per split (multiple of 32)
+  int ci_tiles;                       // ceil(Cin / 128)
+};
+
+constexpr int WG_BL = 32;               // reduction pixels per step
+constexpr int WG_ROWB_BF16 = 320;       // 128 ch * 2 B + 64 B pad (conflict-free tr reads)
+constexpr int WG_ROWB_F32 = 528;        // 128 ch * 4 B + 16 B pad
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads, 2)
+wgrad_kernel(const WgradParams p) {
+  using tt = TT<T>;
+  constexpr int ROWBYTES = sizeof(T) == 2 ? WG_ROWB_BF16 : WG_ROWB_F32;
+  constexpr int TILE = WG_BL * ROWBYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tap = blockIdx.x / p.ci_tiles;
+  const int ci0 = (blockIdx.x - tap * p.ci_tiles) * 128;
+  const int co0 = blockIdx.y * 128;
+  const int split = blockIdx.z;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int64_t L = (int64_t)p.N * p.Ho * p.Wo;
+  const int64_t l_begin = (int64_t)split * p.l_per_split;
+  int64_t l_end = l_begin + p.l_per_split;
+  if (l_end > L) l_end = L;
+  const int nsteps = l_begin < l_end ? (int)((l_end - l_begin + WG_BL - 1) / WG_BL) : 0;
+
+  const T* __restrict__ x = (const T*)p.x;
+  const T* __restrict__ dy = (const T*)p.dy;
+  constexpr int EPC = tt::EPC;
+  constexpr int CHUNKS_PER_ROW = 128 / EPC;                 // 16 (bf16) / 32 (f32)
+  constexpr int CH_PER_THREAD = WG_BL * CHUNKS_PER_ROW / kThreads;  // 2 (bf16) / 4 (f32)
+  const bool vec_x = (p.Cin % EPC) == 0, vec_y = (p.Cout % EPC) == 0;
+
+  uint4 rx[CH_PER_THREAD], ry[CH_PER_THREAD];
+
+  auto load_step = [&](int st) {
+#pragma unroll
+    for (int q = 0; q < CH_PER_THREAD; ++q) {
+      int id = tid + q * kThreads;
+      int r = id / CHUNKS_PER_ROW, c = (id - r * CHUNKS_PER_ROW) * EPC;
+      int64_t l = l_begin + (int64_t)st * WG_BL + r;
+      T xe[EPC], ye[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { xe[e] = tt::from_f(0.f); ye[e] = tt::from_f(0.f); }
+      if (l < l_end) {
+        int n = (int)(l / ((int64_t)p.Ho * p.Wo));
+        int rem = (int)(l - (int64_t)n * p.Ho * p.Wo);
+        int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        int sy = oy * p.stride - p.pad_t + ky, sx = ox * p.stride - p.pad_l + kx;
+        if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
+        if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
+          int64_t pix = ((int64_t)n * p.H + sy) * p.W + sx;
+          const float mk = p.src_mask ? p.src_mask[pix] : 1.0f;
+          const T* xs = x + pix * p.Cin + ci0 + c;
+          if (vec_x && ci0 + c + EPC <= p.Cin) {
+            *reinterpret_cast<uint4*>(xe) = *reinterpret_cast<const uint4*>(xs);
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+              if (ci0 + c + e < p.Cin) xe[e] = xs[e];
+          }
+          if (p.src_mask) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) xe[e] = tt::from_f(tt::to_f(xe[e]) * mk);
+          }
+        }
+        const T* ys = dy + l * p.Cout + co0 + c;
+        if (vec_y && co0 + c + EPC <= p.Cout) {
+          *reinterpret_cast<uint4*>(ye) = *reinterpret_cast<const uint4*>(ys);
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e)
+            if (co0 + c + e < p.Cout) ye[e] = ys[e];
+        }
+        if (p.row_scale) {
+          const float rs = p.row_scale[l];
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) ye[e] = tt::from_f(tt::to_f(ye[e]) * rs);
+        }
+      }
+      rx[q] = *reinterpret_cast<uint4*>(xe);
+      ry[q] = *reinterpret_cast<uint4*>(ye);
+    }
+  };
+  auto store_step = [&](int stage) {
+    unsigned char* xt = smem + stage * 2 * TILE;
+    unsigned char* yt = xt + TILE;
+#pragma unroll
+    for (int q = 0; q < CH_PER_THREAD; ++q) {
+      int id = tid + q * kThreads;
+      int r = id / CHUNKS_PER_ROW, cb = (id - r * CHUNKS_PER_ROW) * 16;
+      *reinterpret_cast<uint4*>(xt + r * ROWBYTES + cb) = rx[q];
+      *reinterpret_cast<uint4*>(yt + r * ROWBYTES + cb) = ry[q];
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nsteps > 0) { load_step(0); store_step(0); }
+  __syncthreads();
+  const int half = lane >> 5, l32 = lane & 31;
+  for (int st = 0; st < nsteps; ++st) {
+    const int stage = st & 1;
+    if (st + 1 < nsteps) load_step(st + 1);
+    const unsigned char* xt = smem + stage * 2 * TILE;
+    const unsigned char* yt = xt + TILE;
+    if (sizeof(T) == 2) {
+      // A fragment (32 channels x 16 l): lane (g16 = (lane>>4)&1, i = lane&15, half):
+      // two transposing reads give l = lb .. lb+3 and lb+4 .. lb+7 for channel cbase+16*g16+i,
+      // with lb = ks*16 + half*8.  Address lane (4j+q) -> row lb+j, channels 4q..4q+3.
+      const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+      const int jrow = i16 >> 2, qcol = i16 & 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 xf[2], yf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int lb = ks * 16 + half * 8;
+          const int xc = (wm * 64 + t * 32 + g16 * 16 + qcol * 4) * 2;
+          const int yc = (wn * 64 + t * 32 + g16 * 16 + qcol * 4) * 2;
+          s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(xt + (lb + jrow) * ROWBYTES + xc));
+          s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(xt + (lb + 4 + jrow) * ROWBYTES + xc));
+          s16x4_t y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(yt + (lb + jrow) * ROWBYTES + yc));
+          s16x4_t y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(yt + (lb + 4 + jrow) * ROWBYTES + yc));
+          uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
+          uint2 b0 = __builtin_bit_cast(uint2, y0), b1 = __builtin_bit_cast(uint2, y1);
+          xf[t] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+          yf[t] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8_t, yf[j]), __builtin_bit_cast(bf16x8_t, xf[i]),
+                acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // fp32: MFMA 32x32x2 takes A[i=l32][k=half]: one float per lane, read [l][c] directly
+#pragma unroll 4
+      for (int k2 = 0; k2 < WG_BL / 2; ++k2) {
+        const int l = k2 * 2 + half;
+        float xa[2], yb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          xa[t] = *reinterpret_cast<const float*>(xt + l * ROWBYTES + (wm * 64 + t * 32 + l32) * 4);
+          yb[t] = *reinterpret_cast<const float*>(yt + l * ROWBYTES + (wn * 64 + t * 32 + l32) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb[j], xa[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (st + 1 < nsteps) store_step(stage ^ 1);
+    __syncthreads();
+  }
+  // acc[i][j][r]: co = co0 + wn*64 + j*32 + (r&3) + 8*(r>>2) + 4*half ; ci = ci0 + wm*64 + i*32 + l32
+  const int64_t K = (int64_t)p.kh * p.kw * p.Cin;
+  float* __restrict__ dw = p.dw + (int64_t)split * K * p.Cout;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ci = ci0 + wm * 64 + i * 32 + l32;
+    if (ci >= p.Cin) continue;
+    float* row = dw + ((int64_t)tap * p.Cin + ci) * p.Cout;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + wn * 64 + j * 32 + g * 8 + half * 4;
+        if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
+          *reinterpret_cast<float4*>(row + co) = make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1],
+                                                             acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.Cout) row[co + e] = acc[i][j][g * 4 + e];
+        }
+      }
+  }
+}
+
+// sum the split partials: out[i] (+)= sum_s part[s][i]
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t n, int accumulate,
+                    const float* __restrict__ out_scale, float* __restrict__ out) {
+  const float sc = out_scale ? *out_scale : 1.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float s = 0.0f;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * n + i];
+    s *= sc;
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------ weight prep
+// fp32 master HWIO [K][Cout] -> compute-dtype copies: wt [Cout][K] (forward operand) and,
+// optionally, wn [K][Cout] (input-gradient operand).  32x32 LDS-tiled transpose.
+template <typename T>
+__global__ void __launch_bounds__(256)
+weight_prep_kernel(const float* __restrict__ w, int64_t K, int Cout, T* __restrict__ wt,
+                   T* __restrict__ wn) {
+  __shared__ float tile[32][33];
+  const int64_t k0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    int64_t k = k0 + r;
+    int c = c0 + tx;
+    float v = (k < K && c < Cout) ? w[k * Cout + c] : 0.0f;
+    tile[r][tx] = v;
+    if (wn && k < K && c < Cout) wn[k * Cout + c] = TT<T>::from_f(v);
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int c = c0 + r;
+    int64_t k = k0 + tx;
+    if (c < Cout && k < K) wt[(int64_t)c * K + k] = TT<T>::from_f(tile[tx][r]);
+  }
+}
+
+int fill_classes(IgemmParams& p, int mode) {
+  int total = 0;
+  if (mode == MODE_FWD) {
+    p.n_classes = 1;
+    p.cls_py[0] = p.cls_px[0] = 0;
+    p.cls_tile_start[0] = 0;
+    int64_t m = (int64_t)p.N * p.oH * p.oW;
+    total = (int)ceil_div(m, BM);
+    p.cls_tile_start[1] = total;
+    return total;
+  }
+  const int s = p.stride;
+  p.n_classes = s * s;
+  int c = 0;
+  for (int py = 0; py < s; ++py)
+    for (int px = 0; px < s; ++px, ++c) {
+      p.cls_py[c] = py; p.cls_px[c] = px;
+      p.cls_tile_start[c] = total;
+      int cH = (p.oH - py + s - 1) / s, cW = (p.oW - px + s - 1) / s;
+      if (cH < 0) cH = 0;
+      if (cW < 0) cW = 0;
+      total += (int)ceil_div((int64_t)p.N * cH * cW, BM);
+    }
+  p.cls_tile_start[c] = total;
+  return total;
+}
+
+}  // namespace
+}  // namespace se3ds
+
+using namespace se3ds;
+
+extern "C" {
+
+static int conv_common(int mode, const void* src, const void* w, void* out, int dtype, int n,
+                       int h, int wdt, int cin, int ho, int wo, int cout, int kh, int kw,
+                       int stride, int pad_t, int pad_l, int wrap_w, const float* src_mask,
+                       const float* scale, const float* bias, const float* row_a,
+                       const float* row_b, int act, float act_alpha, void* stream) {
+  if (n <= 0 || h <= 0 || wdt <= 0 || cin <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || kh <= 0 ||
+      kw <= 0 || stride <= 0 || stride > 2)
+    return SE3DS_E_BADSHAPE;
+  if (wrap_w && (stride != 1 || wo != wdt)) return SE3DS_E_UNSUPPORTED;
+  if (dtype != SE3DS_F32 && dtype != SE3DS_BF16) return SE3DS_E_BADDTYPE;
+  IgemmParams p;
+  p.src = src; p.w = w; p.out = out;
+  p.N = n; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.wrap_w = wrap_w; p.src_mask = src_mask; p.scale = scale; p.bias = bias; p.row_a = row_a;
+  p.row_b = row_b; p.act = act; p.act_alpha = act_alpha;
+  const int bk = dtype == SE3DS_F32 ? 16 : 32;
+  const int64_t K = (int64_t)kh * kw * cin;
+  if (mode == MODE_FWD) {
+    p.sH = h; p.sW = wdt; p.sC = cin; p.oH = ho; p.oW = wo; p.oC = cout;
+    p.w_tap = cin; p.w_n = K;                       // wt [Cout][K]
+  } else {
+    p.sH = ho; p.sW = wo; p.sC = cout; p.oH = h; p.oW = wdt; p.oC = cin;
+    p.w_tap = (int64_t)cin * cout; p.w_n = cout;    // wn [K][Cout]
+  }
+  p.vec = (p.sC % bk) == 0;
+  int tiles = fill_classes(p, mode);
+  if (tiles <= 0) return SE3DS_OK;
+  dim3 grid((unsigned)tiles, (unsigned)ceil_div(p.oC, BN));
+  hipStream_t s = as_stream(stream);
+  if (dtype == SE3DS_F32) {
+    if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_kernel<float, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL((igemm_kernel<float, MODE_DGRAD>), grid, dim3(kThreads), 0, s, p);
+  } else {
+    if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_kernel<uint16_t, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL((igemm_kernel<uint16_t, MODE_DGRAD>), grid, dim3(kThreads), 0, s, p);
+  }
+  return check_launch(mode == MODE_FWD ? "conv2d_fwd" : "conv2d_dgrad");
+}
+
+int se3ds_conv2d_fwd(const void* x, const void* wt, void* y, int dtype, int n, int h, int w,
+                     int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
+                     int pad_l, int wrap_w, const float* in_mask, const float* scale,
+                     const float* bias, const float* row_a, const float* row_b, int act,
+                     float act_alpha, void* stream) {
+  return conv_common(MODE_FWD, x, wt, y, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride, pad_t,
+                     pad_l, wrap_w, in_mask, scale, bias, row_a, row_b, act, act_alpha, stream);
+}
+
+int se3ds_conv2d_dgrad(const void* dy, const void* wn, void* dx, int dtype, int n, int h, int w,
+                       int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
+                       int pad_l, int wrap_w, const float* dy_row_scale, const float* scale,
+                       const float* bias, const float* row_a, int act, float act_alpha,
+                       void* stream) {
+  return conv_common(MODE_DGRAD, dy, wn, dx, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride,
+                     pad_t, pad_l, wrap_w, dy_row_scale, scale, bias, row_a, nullptr, act,
+                     act_alpha, stream);
+}
+
+static int wgrad_splits(int64_t L, int64_t tiles) {
+  // enough blocks to fill 256 CUs x 2, but keep >= 256 pixels per split
+  int64_t want = (512 + tiles - 1) / tiles;
+  int64_t max_by_l = L / 256;
+  if (max_by_l < 1) max_by_l = 1;
+  if (want > max_by_l) want = max_by_l;
+  if (want < 1) want = 1;
+  if (want > 1024) want = 1024;
+  return (int)want;
+}
+
+size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int cout, int kh,
+                                          int kw) {
+  int64_t L = (int64_t)n * ho * wo;
+  int64_t tiles = (int64_t)kh * kw * ceil_div(cin, 128) * ceil_div(cout, 128);
+  int splits = wgrad_splits(L, tiles);
+  return sizeof(float) * (size_t)splits * (size_t)kh * kw * cin * cout + 16;
+}
+
+int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int n, int h, int w,
+                       int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
+                       int pad_l, int wrap_w, const float* in_mask, const float* row_scale,
+                       const float* out_scale, int accumulate, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || kh <= 0 ||
+      kw <= 0 || stride <= 0)
+    return SE3DS_E_BADSHAPE;
+  if (dtype != SE3DS_F32 && dtype != SE3DS_BF16) return SE3DS_E_BADDTYPE;
+  if (workspace_bytes < se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, cout, kh, kw))
+    return SE3DS_E_WORKSPACE;
+  WgradParams p;
+  p.x = x; p.H = h; p.W = w; p.Cin = cin; p.dy = dy; p.Ho = ho; p.Wo = wo; p.Cout = cout;
+  p.N = n; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  p.wrap_w = wrap_w; p.src_mask = in_mask; p.row_scale = row_scale;
+  p.dw = (float*)workspace;
+  p.ci_tiles = (int)ceil_div(cin, 128);
+  const int64_t L = (int64_t)n * ho * wo;
+  const int64_t tiles = (int64_t)kh * kw * p.ci_tiles * ceil_div(cout, 128);
+  p.splits = wgrad_splits(L, tiles);
+  p.l_per_split = ceil_div(ceil_div(L, p.splits), WG_BL) * WG_BL;
+  dim3 grid((unsigned)(kh * kw * p.ci_tiles), (unsigned)ceil_div(cout, 128), (unsigned)p.splits);
+  hipStream_t s = as_stream(stream);
+  if (dtype == SE3DS_F32) hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(kThreads), 0, s, p);
+  else hipLaunchKernelGGL(wgrad_kernel<uint16_t>, grid, dim3(kThreads), 0, s, p);
+  const int64_t nel = (int64_t)kh * kw * cin * cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nel, 256)), dim3(256), 0, s,
+                     (const float*)workspace, p.splits, nel, accumulate, out_scale, dw);
+  return check_launch("conv2d_wgrad");
+}
+
+int se3ds_weight_prep(const float* w, int64_t k, int cout, int dtype, void* wt, void* wn,
+                      void* stream) {
+  if (k <= 0 || cout <= 0) return SE3DS_E_BADSHAPE;
+  dim3 grid((unsigned)ceil_div(k, 32), (unsigned)ceil_div(cout, 32));
+  hipStream_t s = as_stream(stream);
+  if (dtype == SE3DS_F32)
+    hipLaunchKernelGGL(weight_prep_kernel<float>, grid, dim3(256), 0, s, w, k, cout, (float*)wt,
+                       (float*)wn);
+  else if (dtype == SE3DS_BF16)
+    hipLaunchKernelGGL(weight_prep_kernel<uint16_t>, grid, dim3(256), 0, s, w, k, cout,
+                       (uint16_t*)wt, (uint16_t*)wn);
+  else
+    return SE3DS_E_BADDTYPE;
+  return check_launch("weight_prep");
+}
+
+}  // extern "C"

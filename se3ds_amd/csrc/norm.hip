@@ -1,0 +1,443 @@
+// Normalisation kernels (HBM-bound): SyncBatchNorm / InstanceNorm statistics, apply with
+// fused residual + activation, and the matching backward reductions.  A tensor is viewed
+// as [G][R][C] (G = 1 for batch norm over N*H*W rows, G = N samples for instance norm).
+// Statistics are accumulated in fp32 from bf16/fp32 activations with 16-byte loads, reduced
+// deterministically in two stages (per-block partials -> final), so that the cross-replica
+// all-reduce of [2][C] sums (SyncBN, image_models.py:80-123 etc.) sits between two launches.
+#include "common.h"
+
+namespace se3ds {
+namespace {
+
+struct Layout2D {
+  int cx;    // threads along channel vectors (power of two <= 256)
+  int ry;    // threads along rows = 256 / cx
+  int vec;   // elements per thread along C (V or 1)
+  int ctiles;
+};
+inline Layout2D make_layout(int C, int V) {
+  Layout2D l;
+  l.vec = (C % V == 0) ? V : 1;
+  int cvec = C / l.vec;
+  int cx = 1;
+  while (cx < cvec && cx < 256) cx <<= 1;
+  l.cx = cx;
+  l.ry = 256 / cx;
+  l.ctiles = (int)ceil_div(cvec, cx);
+  return l;
+}
+
+// mode 0: sums of (x, x^2)                        [forward statistics / column sums]
+// mode 1: sums of (dpre, dpre * xhat), dpre = dy * act'(y)   [backward statistics]
+// Optional row_scale (rows of the [G*R] view) multiplies the first operand (x or dy).
+template <typename T, int VEC, int MODE>
+__global__ void __launch_bounds__(256)
+norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
+                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                    const float* __restrict__ row_scale, int64_t R, int C, int cx, int ry, int act,
+                    float alpha, int rblocks, float* __restrict__ partial) {
+  // grid: (rblocks, ctiles, G)
+  __shared__ float red[2][256 * (VEC > 1 ? VEC : 1)];
+  const int g = blockIdx.z;
+  const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
+  const int cv = blockIdx.y * cx + tx;  // channel-vector index
+  const int c0 = cv * VEC;
+  const bool cok = c0 < C;
+  float s0[VEC], s1[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  float mu[VEC], rs[VEC];
+  if (MODE == 1 && cok) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mu[e] = mean[(int64_t)g * C + c0 + e]; rs[e] = rstd[(int64_t)g * C + c0 + e]; }
+  }
+  const int64_t rows_per_block = ceil_div(R, rblocks);
+  const int64_t r_lo = (int64_t)blockIdx.x * rows_per_block;
+  int64_t r_hi = r_lo + rows_per_block;
+  if (r_hi > R) r_hi = R;
+  if (cok) {
+    for (int64_t r = r_lo + ty; r < r_hi; r += ry) {
+      const int64_t off = ((int64_t)g * R + r) * C + c0;
+      float av[VEC];
+      if constexpr (VEC > 1) VT<T>::load(a + off, reinterpret_cast<float(&)[VT<T>::V]>(av));
+      else av[0] = VT<T>::ld1(a + off);
+      const float rsc = row_scale ? row_scale[(int64_t)g * R + r] : 1.0f;
+      if (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float v = av[e] * rsc;
+          s0[e] += v;
+          s1[e] += v * v;
+        }
+      } else {
+        float yv[VEC], xv[VEC];
+        if constexpr (VEC > 1) {
+          if (act) VT<T>::load(y + off, reinterpret_cast<float(&)[VT<T>::V]>(yv));
+          VT<T>::load(x + off, reinterpret_cast<float(&)[VT<T>::V]>(xv));
+        } else {
+          if (act) yv[0] = VT<T>::ld1(y + off);
+          xv[0] = VT<T>::ld1(x + off);
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float d = av[e] * rsc * (act ? act_grad_from_out(yv[e], act, alpha) : 1.f);
+          s0[e] += d;
+          s1[e] += d * ((xv[e] - mu[e]) * rs[e]);
+        }
+      }
+    }
+  }
+  // reduce over ty
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    red[0][threadIdx.x * VEC + e] = s0[e];
+    red[1][threadIdx.x * VEC + e] = s1[e];
+  }
+  __syncthreads();
+  if (ty == 0 && cok) {
+    for (int t = 1; t < ry; ++t) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        s0[e] += red[0][(t * cx + tx) * VEC + e];
+        s1[e] += red[1][(t * cx + tx) * VEC + e];
+      }
+    }
+    float* P = partial + (((int64_t)g * rblocks + blockIdx.x) * 2) * C;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      P[c0 + e] = s0[e];
+      P[C + c0 + e] = s1[e];
+    }
+  }
+}
+
+// sums[g][k][c] = sum_b partial[g][b][k][c]
+__global__ void __launch_bounds__(256)
+norm_final_reduce_kernel(const float* __restrict__ partial, int rblocks, int C, int G,
+                         float* __restrict__ sums) {
+  const int64_t total = (int64_t)G * 2 * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    int g = (int)(i / (2 * C));
+    int kc = (int)(i - (int64_t)g * 2 * C);
+    float s = 0.f;
+    for (int b = 0; b < rblocks; ++b) s += partial[((int64_t)g * rblocks + b) * 2 * C + kc];
+    sums[i] = s;
+  }
+}
+
+// Per-(group, channel) scale/shift from sums.  Keras SyncBatchNormalization: mean = S1/cnt,
+// var = S2/cnt - mean^2 (biased), y = x*inv + (beta - mean*inv), inv = gamma*rsqrt(var+eps);
+// moving -= (moving - batch) * (1 - momentum).  use_moving: inference (moving statistics).
+__global__ void __launch_bounds__(256)
+norm_finalize_kernel(const float* __restrict__ sums, float count, int G, int C,
+                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                     float momentum, float* __restrict__ moving_mean,
+                     float* __restrict__ moving_var, int use_moving, float* __restrict__ scale,
+                     float* __restrict__ shift, float* __restrict__ mean_out,
+                     float* __restrict__ rstd_out) {
+  const int64_t total = (int64_t)G * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    int g = (int)(i / C), c = (int)(i - (int64_t)g * C);
+    float mean, var;
+    if (use_moving) {
+      mean = moving_mean[c];
+      var = moving_var[c];
+    } else {
+      mean = sums[((int64_t)g * 2) * C + c] / count;
+      var = sums[((int64_t)g * 2 + 1) * C + c] / count - mean * mean;
+      if (moving_mean) {
+        moving_mean[c] = moving_mean[c] - (moving_mean[c] - mean) * (1.0f - momentum);
+        moving_var[c] = moving_var[c] - (moving_var[c] - var) * (1.0f - momentum);
+      }
+    }
+    float rstd = rsqrtf(var + eps);
+    // correctly rounded 1/sqrt: refine rsqrtf (1 ulp) with one Newton step in fp32
+    rstd = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+    float inv = rstd * (gamma ? gamma[c] : 1.0f);
+    scale[i] = inv;
+    shift[i] = (beta ? beta[c] : 0.0f) - mean * inv;
+    mean_out[i] = mean;
+    rstd_out[i] = rstd;
+  }
+}
+
+// y = act(x * scale + shift [+ res]) [+ post]
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                  const float* __restrict__ shift, const T* __restrict__ res,
+                  const T* __restrict__ post, int64_t R, int C, int G, int act, float alpha,
+                  T* __restrict__ y) {
+  const int cvec = C / VEC;
+  const int64_t total = (int64_t)G * R * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvec);
+    const int64_t row = i / cvec;
+    const int g = (int)(row / R);
+    const int c0 = cv * VEC;
+    const int64_t off = row * C + c0;
+    float xv[VEC], rv[VEC], pv[VEC], o[VEC];
+    if constexpr (VEC > 1) {
+      VT<T>::load(x + off, reinterpret_cast<float(&)[VT<T>::V]>(xv));
+      if (res) VT<T>::load(res + off, reinterpret_cast<float(&)[VT<T>::V]>(rv));
+      if (post) VT<T>::load(post + off, reinterpret_cast<float(&)[VT<T>::V]>(pv));
+    } else {
+      xv[0] = VT<T>::ld1(x + off);
+      if (res) rv[0] = VT<T>::ld1(res + off);
+      if (post) pv[0] = VT<T>::ld1(post + off);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float v = xv[e] * scale[(int64_t)g * C + c0 + e] + shift[(int64_t)g * C + c0 + e];
+      if (res) v += rv[e];
+      v = act_apply(v, act, alpha);
+      if (post) v += pv[e];
+      o[e] = v;
+    }
+    if constexpr (VEC > 1) VT<T>::store(y + off, reinterpret_cast<float(&)[VT<T>::V]>(o));
+    else VT<T>::st1(y + off, o[0]);
+  }
+}
+
+// dpre = dy * act'(y);  dx = gamma*rstd * (dpre - S0/cnt - xhat * S1/cnt);  dres = dpre
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
+                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                      const float* __restrict__ gamma, const float* __restrict__ sums, float count,
+                      int64_t R, int C, int G, int act, float alpha, T* __restrict__ dx,
+                      T* __restrict__ dres) {
+  const int cvec = C / VEC;
+  const int64_t total = (int64_t)G * R * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvec);
+    const int64_t row = i / cvec;
+    const int g = (int)(row / R);
+    const int c0 = cv * VEC;
+    const int64_t off = row * C + c0;
+    float dv[VEC], yv[VEC], xv[VEC], o[VEC], dr[VEC];
+    if constexpr (VEC > 1) {
+      VT<T>::load(dy + off, reinterpret_cast<float(&)[VT<T>::V]>(dv));
+      if (act) VT<T>::load(y + off, reinterpret_cast<float(&)[VT<T>::V]>(yv));
+      VT<T>::load(x + off, reinterpret_cast<float(&)[VT<T>::V]>(xv));
+    } else {
+      dv[0] = VT<T>::ld1(dy + off);
+      if (act) yv[0] = VT<T>::ld1(y + off);
+      xv[0] = VT<T>::ld1(x + off);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int64_t gc = (int64_t)g * C + c0 + e;
+      float d = dv[e] * (act ? act_grad_from_out(yv[e], act, alpha) : 1.f);
+      dr[e] = d;
+      float xh = (xv[e] - mean[gc]) * rstd[gc];
+      float s0 = sums[((int64_t)g * 2) * C + c0 + e] / count;
+      float s1 = sums[((int64_t)g * 2 + 1) * C + c0 + e] / count;
+      o[e] = (gamma ? gamma[c0 + e] : 1.0f) * rstd[gc] * (d - s0 - xh * s1);
+    }
+    if constexpr (VEC > 1) {
+      VT<T>::store(dx + off, reinterpret_cast<float(&)[VT<T>::V]>(o));
+      if (dres) VT<T>::store(dres + off, reinterpret_cast<float(&)[VT<T>::V]>(dr));
+    } else {
+      VT<T>::st1(dx + off, o[0]);
+      if (dres) VT<T>::st1(dres + off, dr[0]);
+    }
+  }
+}
+
+// inference-mode backward (statistics are constants): dx = dpre * scale
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256)
+affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                  const float* __restrict__ scale, int64_t R, int C, int G, int act, float alpha,
+                  T* __restrict__ dx, T* __restrict__ dres) {
+  const int cvec = C / VEC;
+  const int64_t total = (int64_t)G * R * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % cvec);
+    const int64_t row = i / cvec;
+    const int g = (int)(row / R);
+    const int c0 = cv * VEC;
+    const int64_t off = row * C + c0;
+    float dv[VEC], yv[VEC], o[VEC], dr[VEC];
+    if constexpr (VEC > 1) {
+      VT<T>::load(dy + off, reinterpret_cast<float(&)[VT<T>::V]>(dv));
+      if (act) VT<T>::load(y + off, reinterpret_cast<float(&)[VT<T>::V]>(yv));
+    } else {
+      dv[0] = VT<T>::ld1(dy + off);
+      if (act) yv[0] = VT<T>::ld1(y + off);
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float d = dv[e] * (act ? act_grad_from_out(yv[e], act, alpha) : 1.f);
+      dr[e] = d;
+      o[e] = d * scale[(int64_t)g * C + c0 + e];
+    }
+    if constexpr (VEC > 1) {
+      VT<T>::store(dx + off, reinterpret_cast<float(&)[VT<T>::V]>(o));
+      if (dres) VT<T>::store(dres + off, reinterpret_cast<float(&)[VT<T>::V]>(dr));
+    } else {
+      VT<T>::st1(dx + off, o[0]);
+      if (dres) VT<T>::st1(dres + off, dr[0]);
+    }
+  }
+}
+
+int pick_rblocks(int64_t R, int ry, int ctiles, int G) {
+  int64_t want = 1024 / ((int64_t)ctiles * G);
+  if (want < 1) want = 1;
+  int64_t max_rb = ceil_div(R, (int64_t)ry * 4);
+  if (max_rb < 1) max_rb = 1;
+  if (want > max_rb) want = max_rb;
+  if (want > 512) want = 512;
+  return (int)want;
+}
+
+template <typename T, int MODE>
+int launch_partial(const T* a, const T* y, const T* x, const float* mean, const float* rstd,
+                   const float* row_scale, int G, int64_t R, int C, int act, float alpha,
+                   float* sums, float* ws, size_t ws_bytes, hipStream_t s) {
+  Layout2D l = make_layout(C, VT<T>::V);
+  int rb = pick_rblocks(R, l.ry, l.ctiles, G);
+  if (ws_bytes < sizeof(float) * (size_t)G * rb * 2 * C) return SE3DS_E_WORKSPACE;
+  dim3 grid((unsigned)rb, (unsigned)l.ctiles, (unsigned)G);
+  if (l.vec > 1)
+    hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE>), grid, dim3(256), 0, s, a, y, x,
+                       mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws);
+  else
+    hipLaunchKernelGGL((norm_partial_kernel<T, 1, MODE>), grid, dim3(256), 0, s, a, y, x, mean,
+                       rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws);
+  hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(grid_for((int64_t)G * 2 * C, 256)), dim3(256),
+                     0, s, ws, rb, C, G, sums);
+  return check_launch("norm_partial");
+}
+
+}  // namespace
+}  // namespace se3ds
+
+using namespace se3ds;
+
+extern "C" {
+
+size_t se3ds_norm_workspace_bytes(int g, int c) {
+  return sizeof(float) * (size_t)g * 512 * 2 * (size_t)c + 16;
+}
+
+int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const float* row_scale,
+                     float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+  if (dtype == SE3DS_F32)
+    return launch_partial<float, 0>((const float*)x, nullptr, nullptr, nullptr, nullptr, row_scale,
+                                    g, r, c, 0, 0.f, sums, (float*)workspace, workspace_bytes, s);
+  if (dtype == SE3DS_BF16)
+    return launch_partial<uint16_t, 0>((const uint16_t*)x, nullptr, nullptr, nullptr, nullptr,
+                                       row_scale, g, r, c, 0, 0.f, sums, (float*)workspace,
+                                       workspace_bytes, s);
+  return SE3DS_E_BADDTYPE;
+}
+
+int se3ds_norm_finalize(const float* sums, float count, int g, int c, const float* gamma,
+                        const float* beta, float eps, float momentum, float* moving_mean,
+                        float* moving_var, int use_moving, float* scale, float* shift, float* mean,
+                        float* rstd, void* stream) {
+  if (g <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(grid_for((int64_t)g * c, 256)), dim3(256), 0,
+                     as_stream(stream), sums, count, g, c, gamma, beta, eps, momentum, moving_mean,
+                     moving_var, use_moving, scale, shift, mean, rstd);
+  return check_launch("norm_finalize");
+}
+
+int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const float* scale,
+                     const float* shift, const void* res, const void* post, int act, float alpha,
+                     void* y, void* stream) {
+  if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+  if (dtype == SE3DS_F32) {
+    if (c % 4 == 0)
+      hipLaunchKernelGGL((norm_apply_kernel<float, 4>), dim3(grid_for((int64_t)g * r * c / 4, 256)),
+                         dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res,
+                         (const float*)post, r, c, g, act, alpha, (float*)y);
+    else
+      hipLaunchKernelGGL((norm_apply_kernel<float, 1>), dim3(grid_for((int64_t)g * r * c, 256)),
+                         dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res,
+                         (const float*)post, r, c, g, act, alpha, (float*)y);
+  } else if (dtype == SE3DS_BF16) {
+    if (c % 8 == 0)
+      hipLaunchKernelGGL((norm_apply_kernel<uint16_t, 8>),
+                         dim3(grid_for((int64_t)g * r * c / 8, 256)), dim3(256), 0, s,
+                         (const uint16_t*)x, scale, shift, (const uint16_t*)res,
+                         (const uint16_t*)post, r, c, g, act, alpha, (uint16_t*)y);
+    else
+      hipLaunchKernelGGL((norm_apply_kernel<uint16_t, 1>), dim3(grid_for((int64_t)g * r * c, 256)),
+                         dim3(256), 0, s, (const uint16_t*)x, scale, shift, (const uint16_t*)res,
+                         (const uint16_t*)post, r, c, g, act, alpha, (uint16_t*)y);
+  } else {
+    return SE3DS_E_BADDTYPE;
+  }
+  return check_launch("norm_apply");
+}
+
+int se3ds_norm_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
+                         int c, const float* mean, const float* rstd, int act, float alpha,
+                         float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+  if (dtype == SE3DS_F32)
+    return launch_partial<float, 1>((const float*)dy, (const float*)y, (const float*)x, mean, rstd,
+                                    nullptr, g, r, c, act, alpha, sums, (float*)workspace,
+                                    workspace_bytes, s);
+  if (dtype == SE3DS_BF16)
+    return launch_partial<uint16_t, 1>((const uint16_t*)dy, (const uint16_t*)y, (const uint16_t*)x,
+                                       mean, rstd, nullptr, g, r, c, act, alpha, sums,
+                                       (float*)workspace, workspace_bytes, s);
+  return SE3DS_E_BADDTYPE;
+}
+
+int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
+                         int c, const float* mean, const float* rstd, const float* gamma,
+                         const float* sums, float count, int act, float alpha, void* dx,
+                         void* dres, void* stream) {
+  if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+#define LAUNCH_BWD(T, V)                                                                         \
+  hipLaunchKernelGGL((norm_bwd_apply_kernel<T, V>), dim3(grid_for((int64_t)g * r * c / V, 256)), \
+                     dim3(256), 0, s, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, \
+                     sums, count, r, c, g, act, alpha, (T*)dx, (T*)dres)
+  if (dtype == SE3DS_F32) {
+    if (c % 4 == 0) LAUNCH_BWD(float, 4); else LAUNCH_BWD(float, 1);
+  } else if (dtype == SE3DS_BF16) {
+    if (c % 8 == 0) LAUNCH_BWD(uint16_t, 8); else LAUNCH_BWD(uint16_t, 1);
+  } else {
+    return SE3DS_E_BADDTYPE;
+  }
+#undef LAUNCH_BWD
+  return check_launch("norm_bwd_apply");
+}
+
+int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r, int c,
+                     const float* scale, int act, float alpha, void* dx, void* dres,
+                     void* stream) {
+  if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+#define LAUNCH_AFF(T, V)                                                                      \
+  hipLaunchKernelGGL((affine_bwd_kernel<T, V>), dim3(grid_for((int64_t)g * r * c / V, 256)),  \
+                     dim3(256), 0, s, (const T*)dy, (const T*)y, scale, r, c, g, act, alpha,  \
+                     (T*)dx, (T*)dres)
+  if (dtype == SE3DS_F32) {
+    if (c % 4 == 0) LAUNCH_AFF(float, 4); else LAUNCH_AFF(float, 1);
+  } else if (dtype == SE3DS_BF16) {
+    if (c % 8 == 0) LAUNCH_AFF(uint16_t, 8); else LAUNCH_AFF(uint16_t, 1);
+  } else {
+    return SE3DS_E_BADDTYPE;
+  }
+#undef LAUNCH_AFF
+  return check_launch("affine_bwd");
+}
+
+}  // extern "C"

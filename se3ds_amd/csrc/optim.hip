@@ -1,0 +1,323 @@
+// Multi-tensor optimiser kernels over flat fp32 parameter arenas (per-tensor clip-by-norm,
+// Keras-form Adam, EMA) and the layer-batched spectral-norm power iteration / backward
+// fix-up.  All HBM-bound streaming; reductions are two-stage and deterministic.
+//   clip   trainers/se3ds_trainer.py:27-32  (tf.clip_by_norm per tensor, before aggregation)
+//   adam   trainers/gan_manager.py:175-183  (Keras Adam -> ResourceApplyAdam)
+//   ema    utils/ema.py:54-64
+//   SN     models/layers.py:312-331 (power iteration), gradient through sigma = v W u^T
+#include "common.h"
+
+namespace se3ds {
+namespace {
+
+constexpr int kB = 256;
+
+// chunk table: int64 triples (tensor id, start element, length)
+__global__ void __launch_bounds__(kB)
+chunk_sqsum_kernel(const float* __restrict__ g, const int64_t* __restrict__ chunks,
+                   float* __restrict__ partial) {
+  __shared__ float sh[kB / 64];
+  const int64_t start = chunks[blockIdx.x * 3 + 1], len = chunks[blockIdx.x * 3 + 2];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < len; i += kB) {
+    float v = g[start + i];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < kB / 64; ++i) t += sh[i];
+    partial[blockIdx.x] = t;
+  }
+}
+
+// tensor_chunk_start: (T+1) prefix of chunk indices per tensor
+__global__ void __launch_bounds__(kB)
+tensor_sqsum_kernel(const float* __restrict__ partial, const int64_t* __restrict__ tensor_chunk_start,
+                    int T, float* __restrict__ sqnorm) {
+  for (int t = blockIdx.x * kB + threadIdx.x; t < T; t += gridDim.x * kB) {
+    float s = 0.f;
+    for (int64_t c = tensor_chunk_start[t]; c < tensor_chunk_start[t + 1]; ++c) s += partial[c];
+    sqnorm[t] = s;
+  }
+}
+
+// tf.clip_by_norm: (g * clip) / max(l2norm, clip), l2norm = sqrt(sum g^2) (0 if the sum is 0)
+__global__ void __launch_bounds__(kB)
+clip_kernel(float* __restrict__ g, const int64_t* __restrict__ chunks,
+            const float* __restrict__ sqnorm, float clip) {
+  const int64_t t = chunks[blockIdx.x * 3], start = chunks[blockIdx.x * 3 + 1],
+                len = chunks[blockIdx.x * 3 + 2];
+  const float sq = sqnorm[t];
+  const float norm = sq > 0.f ? sqrtf(sq) : sq;
+  const float den = fmaxf(norm, clip);
+  for (int64_t i = threadIdx.x; i < len; i += kB) g[start + i] = (g[start + i] * clip) / den;
+}
+
+// metric: mean over tensors of ||clipped g|| = norm * clip / max(norm, clip)
+__global__ void __launch_bounds__(kB)
+mean_clipped_norm_kernel(const float* __restrict__ sqnorm, int T, float clip,
+                         float* __restrict__ out) {
+  __shared__ float sh[kB / 64];
+  float s = 0.f;
+  for (int t = threadIdx.x; t < T; t += kB) {
+    float sq = sqnorm[t];
+    float norm = sq > 0.f ? sqrtf(sq) : sq;
+    s += (norm * clip) / fmaxf(norm, clip);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < kB / 64; ++i) t += sh[i];
+    t = t / (float)T;
+    out[0] = (t != t) ? 0.f : t;  // NaN -> 0 (se3ds_trainer.py:240-242)
+  }
+}
+
+// ResourceApplyAdam: m += (g - m)(1-b1); v += (g^2 - v)(1-b2); p -= (m * alpha)/(sqrt(v)+eps)
+__global__ void __launch_bounds__(kB)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+            float* __restrict__ v, int64_t n, float alpha, float b1, float b2, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)gridDim.x * kB) {
+    float gi = g[i];
+    float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - (mi * alpha) / (sqrtf(vi) + eps);
+  }
+}
+
+__global__ void __launch_bounds__(kB)
+ema_kernel(float* __restrict__ ema, const float* __restrict__ var, int64_t n, float omd) {
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)gridDim.x * kB)
+    ema[i] = ema[i] - (ema[i] - var[i]) * omd;
+}
+
+// ------------------------------------------------------------------ spectral norm (batched)
+// Layer table: 10 int64 per layer:
+//   0 W (float*)  1 u (float*)  2 v (float*, K)  3 uhat (float*, Cout)  4 sig (float*, 2)
+//   5 part (float*, SN_KB*Cout)  6 vpart (float*, SN_RB)  7 K  8 Cout  9 grad (float*)
+constexpr int SN_F = 10;
+constexpr int SN_RB = 64;   // row blocks for v = W u and for dot products
+constexpr int SN_KB = 32;   // K slabs for u' = v^T W
+constexpr float SN_EPS = 1e-10f;
+
+// v[k] = sum_c W[k][c] u[c]; one wave per row; vpart[block] = sum of v[k]^2 over its rows
+__global__ void __launch_bounds__(kB)
+sn_v_kernel(const int64_t* __restrict__ tab) {
+  const int64_t* L = tab + (int64_t)blockIdx.y * SN_F;
+  const float* W = (const float*)L[0];
+  const float* u = (const float*)L[1];
+  float* v = (float*)L[2];
+  float* vpart = (float*)L[6];
+  const int64_t K = L[7];
+  const int C = (int)L[8];
+  __shared__ float sh[kB / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float sq = 0.f;
+  for (int64_t k = (int64_t)blockIdx.x * 4 + wave; k < K; k += (int64_t)SN_RB * 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += W[k * C + c] * u[c];
+    s = wave_sum(s);
+    if (lane == 0) { v[k] = s; sq += s * s; }
+  }
+  if (lane == 0) sh[wave] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) vpart[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// partial[kb][c] = sum_{k in slab kb} (v[k] * inv_vnorm) * W[k][c]
+__global__ void __launch_bounds__(kB)
+sn_u_kernel(const int64_t* __restrict__ tab) {
+  const int64_t* L = tab + (int64_t)blockIdx.y * SN_F;
+  const float* W = (const float*)L[0];
+  const float* v = (const float*)L[2];
+  float* part = (float*)L[5];
+  const float* vpart = (const float*)L[6];
+  const int64_t K = L[7];
+  const int C = (int)L[8];
+  float vn = 0.f;
+  for (int i = 0; i < SN_RB; ++i) vn += vpart[i];
+  const float inv_vn = 1.0f / (sqrtf(vn) + SN_EPS);
+  const int64_t per = ceil_div(K, SN_KB);
+  const int64_t k_lo = (int64_t)blockIdx.x * per;
+  int64_t k_hi = k_lo + per;
+  if (k_hi > K) k_hi = K;
+  for (int c = threadIdx.x; c < C; c += kB) {
+    float s = 0.f;
+    for (int64_t k = k_lo; k < k_hi; ++k) s += (v[k] * inv_vn) * W[k * C + c];
+    part[(int64_t)blockIdx.x * C + c] = s;
+  }
+}
+
+// u' -> uhat, sigma = u' . uhat, inv = 1/(sigma+eps); v := vhat; u := uhat if training
+__global__ void __launch_bounds__(kB)
+sn_finish_kernel(const int64_t* __restrict__ tab, int training) {
+  const int64_t* L = tab + (int64_t)blockIdx.x * SN_F;
+  float* u = (float*)L[1];
+  float* v = (float*)L[2];
+  float* uhat = (float*)L[3];
+  float* sig = (float*)L[4];
+  const float* part = (const float*)L[5];
+  const float* vpart = (const float*)L[6];
+  const int64_t K = L[7];
+  const int C = (int)L[8];
+  __shared__ float sh[kB / 64];
+  __shared__ float s_bcast;
+  float sq = 0.f;
+  for (int c = threadIdx.x; c < C; c += kB) {
+    float s = 0.f;
+    for (int b = 0; b < SN_KB; ++b) s += part[(int64_t)b * C + c];
+    uhat[c] = s;  // u' for now
+    sq += s * s;
+  }
+  sq = wave_sum(sq);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) s_bcast = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  const float un = sqrtf(s_bcast);
+  const float inv_un = 1.0f / (un + SN_EPS);
+  float dot = 0.f;
+  for (int c = threadIdx.x; c < C; c += kB) {
+    float up = uhat[c];
+    float uh = up * inv_un;
+    dot += up * uh;
+    uhat[c] = uh;
+    if (training) u[c] = uh;
+  }
+  dot = wave_sum(dot);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float sigma = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    sig[0] = sigma;
+    sig[1] = 1.0f / (sigma + SN_EPS);
+  }
+  float vn = 0.f;
+  for (int i = 0; i < SN_RB; ++i) vn += vpart[i];
+  const float inv_vn = 1.0f / (sqrtf(vn) + SN_EPS);
+  for (int64_t k = threadIdx.x; k < K; k += kB) v[k] = v[k] * inv_vn;
+}
+
+// vpart[block] = partial of <G, W>
+__global__ void __launch_bounds__(kB)
+sn_dot_kernel(const int64_t* __restrict__ tab) {
+  const int64_t* L = tab + (int64_t)blockIdx.y * SN_F;
+  const float* W = (const float*)L[0];
+  float* vpart = (float*)L[6];
+  const float* G = (const float*)L[9];
+  const int64_t n = L[7] * L[8];
+  __shared__ float sh[kB / 64];
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)SN_RB * kB)
+    s += G[i] * W[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) vpart[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// G := inv*G - inv^2 * <G,W> * vhat[k] * uhat[c]
+__global__ void __launch_bounds__(kB)
+sn_fix_kernel(const int64_t* __restrict__ tab) {
+  const int64_t* L = tab + (int64_t)blockIdx.y * SN_F;
+  const float* v = (const float*)L[2];
+  const float* uhat = (const float*)L[3];
+  const float* sig = (const float*)L[4];
+  const float* vpart = (const float*)L[6];
+  float* G = (float*)L[9];
+  const int C = (int)L[8];
+  const int64_t n = L[7] * C;
+  float dot = 0.f;
+  for (int i = 0; i < SN_RB; ++i) dot += vpart[i];
+  const float inv = sig[1];
+  const float coef = inv * inv * dot;
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)SN_RB * kB) {
+    int64_t k = i / C;
+    int c = (int)(i - k * C);
+    G[i] = inv * G[i] - coef * v[k] * uhat[c];
+  }
+}
+
+}  // namespace
+}  // namespace se3ds
+
+using namespace se3ds;
+
+extern "C" {
+
+int se3ds_multi_sqnorm(const float* grads, const int64_t* chunks, int64_t nchunks,
+                       const int64_t* tensor_chunk_start, int ntensors, float* partial,
+                       float* sqnorm, void* stream) {
+  if (nchunks <= 0 || ntensors <= 0) return SE3DS_OK;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(chunk_sqsum_kernel, dim3((unsigned)nchunks), dim3(kB), 0, s, grads, chunks,
+                     partial);
+  hipLaunchKernelGGL(tensor_sqsum_kernel, dim3(grid_for(ntensors, kB)), dim3(kB), 0, s, partial,
+                     tensor_chunk_start, ntensors, sqnorm);
+  return check_launch("multi_sqnorm");
+}
+
+int se3ds_multi_clip_by_norm(float* grads, const int64_t* chunks, int64_t nchunks,
+                             const float* sqnorm, int ntensors, float clip_norm,
+                             float* mean_norm_out, void* stream) {
+  if (nchunks <= 0) return SE3DS_OK;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(clip_kernel, dim3((unsigned)nchunks), dim3(kB), 0, s, grads, chunks, sqnorm,
+                     clip_norm);
+  if (mean_norm_out)
+    hipLaunchKernelGGL(mean_clipped_norm_kernel, dim3(1), dim3(kB), 0, s, sqnorm, ntensors,
+                       clip_norm, mean_norm_out);
+  return check_launch("multi_clip_by_norm");
+}
+
+int se3ds_multi_adam_keras(float* params, const float* grads, float* m, float* v, int64_t n,
+                           float lr, float beta1, float beta2, float eps, int64_t step,
+                           void* stream) {
+  if (n <= 0) return SE3DS_OK;
+  // alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t), computed in fp32 like the Keras optimizer
+  float b1p = 1.0f, b2p = 1.0f;
+  for (int64_t i = 0; i < step; ++i) { b1p *= beta1; b2p *= beta2; }
+  float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, kB)), dim3(kB), 0, as_stream(stream), params,
+                     grads, m, v, n, alpha, beta1, beta2, eps);
+  return check_launch("multi_adam_keras");
+}
+
+int se3ds_multi_ema(float* ema, const float* vars, int64_t n, float one_minus_decay,
+                    void* stream) {
+  if (n <= 0) return SE3DS_OK;
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n, kB)), dim3(kB), 0, as_stream(stream), ema, vars,
+                     n, one_minus_decay);
+  return check_launch("multi_ema");
+}
+
+int se3ds_spectral_power_iter(const int64_t* table, int nlayers, int training, void* stream) {
+  if (nlayers <= 0) return SE3DS_OK;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(sn_v_kernel, dim3(SN_RB, (unsigned)nlayers), dim3(kB), 0, s, table);
+  hipLaunchKernelGGL(sn_u_kernel, dim3(SN_KB, (unsigned)nlayers), dim3(kB), 0, s, table);
+  hipLaunchKernelGGL(sn_finish_kernel, dim3((unsigned)nlayers), dim3(kB), 0, s, table, training);
+  return check_launch("spectral_power_iter");
+}
+
+int se3ds_spectral_bwd_fixup(const int64_t* table, int nlayers, void* stream) {
+  if (nlayers <= 0) return SE3DS_OK;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(sn_dot_kernel, dim3(SN_RB, (unsigned)nlayers), dim3(kB), 0, s, table);
+  hipLaunchKernelGGL(sn_fix_kernel, dim3(SN_RB, (unsigned)nlayers), dim3(kB), 0, s, table);
+  return check_launch("spectral_bwd_fixup");
+}
+
+int se3ds_spectral_table_fields(void) { return SN_F; }
+int se3ds_spectral_part_rows(void) { return SN_KB; }
+int se3ds_spectral_vpart_len(void) { return SN_RB; }
+
+}  // extern "C"

@@ -1,0 +1,724 @@
+"""Differentiable building blocks of the SE3DS G/D step on libse3ds_hip.so.
+
+Everything numeric happens in our HIP kernels.  torch is used for device memory
+(`torch.empty`, views), streams and `torch.distributed` only.  Reverse mode is a small tape:
+each op appends a closure; gradient accumulation for tensors with several consumers runs in
+`se3ds_add`, parameter gradients are written straight into a flat fp32 arena.
+"""
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from se3ds_amd import _lib
+from se3ds_amd import hipops  # noqa: F401  (registers the ctypes signatures)
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+BN_EPS, BN_MOMENTUM = 1e-3, 0.99   # Keras SyncBatchNormalization defaults
+IN_EPS = 1e-3                      # tfa InstanceNormalization default
+
+
+def _L():
+  return _lib.lib()
+
+
+def _chk(rc, what):
+  _lib.check(rc, what)
+
+
+# ------------------------------------------------------------------------------ parameters
+class ParamStore:
+  """Flat fp32 arenas: `theta` (trainable), `state` (non-trainable: BN moving statistics,
+  spectral `u`), plus matching gradient / Adam / EMA arenas created on demand."""
+
+  def __init__(self):
+    self._specs = []   # (name, shape, init, trainable)
+    self.theta = None
+    self.state = None
+    self.grad = None
+    self.views = {}
+    self.grad_views = {}
+    self.offsets = {}
+    self.trainable_names = []
+    self.state_names = []
+    self.version = 0   # bumped whenever theta changes (compute-dtype copies are refreshed)
+
+  def add(self, name, shape, init, trainable=True):
+    assert self.theta is None, 'store already finalized'
+    assert name not in [s[0] for s in self._specs], name
+    self._specs.append((name, tuple(int(s) for s in shape), init, trainable))
+    return name
+
+  def finalize(self, device, generator: Optional[torch.Generator] = None):
+    tr = [s for s in self._specs if s[3]]
+    st = [s for s in self._specs if not s[3]]
+    def pack(specs):
+      off, offs = 0, {}
+      for name, shape, _, _ in specs:
+        offs[name] = (off, int(np.prod(shape)) if len(shape) else 1, shape)
+        off += offs[name][1]
+        off = (off + 3) // 4 * 4   # keep every tensor 16-byte aligned
+      return off, offs
+    n_tr, off_tr = pack(tr)
+    n_st, off_st = pack(st)
+    host_tr = torch.zeros(max(n_tr, 4), dtype=torch.float32)
+    host_st = torch.zeros(max(n_st, 4), dtype=torch.float32)
+    for specs, host, offs in ((tr, host_tr, off_tr), (st, host_st, off_st)):
+      for name, shape, init, _ in specs:
+        o, n, _ = offs[name]
+        host[o:o + n] = init(shape, generator).reshape(-1)
+    self.theta = host_tr.to(device)
+    self.state = host_st.to(device)
+    self.grad = torch.zeros_like(self.theta)
+    for name, (o, n, shape) in off_tr.items():
+      self.views[name] = self.theta[o:o + n].view(shape)
+      self.grad_views[name] = self.grad[o:o + n].view(shape)
+      self.offsets[name] = ('theta', o, n)
+    for name, (o, n, shape) in off_st.items():
+      self.views[name] = self.state[o:o + n].view(shape)
+      self.offsets[name] = ('state', o, n)
+    self.trainable_names = [s[0] for s in tr]
+    self.state_names = [s[0] for s in st]
+    self._off_tr = off_tr
+    return self
+
+  def __getitem__(self, name):
+    return self.views[name]
+
+  def load_dict(self, d):
+    """Overwrite parameters from {name: array-like} (tests inject identical weights)."""
+    for k, v in d.items():
+      t = torch.as_tensor(np.asarray(v), dtype=torch.float32).to(self.theta.device)
+      self.views[k].copy_(t.reshape(self.views[k].shape))
+    self.version += 1
+
+  def to_dict(self):
+    return {k: v.detach().cpu().numpy().copy() for k, v in self.views.items()}
+
+  def chunk_tables(self, chunk=65536):
+    """(chunks int64 [nchunks,3], tensor_chunk_start int64 [T+1]) for the multi-tensor ops."""
+    chunks, starts = [], [0]
+    for t, name in enumerate(self.trainable_names):
+      o, n, _ = self._off_tr[name]
+      for s in range(0, n, chunk):
+        chunks.append((t, o + s, min(chunk, n - s)))
+      starts.append(len(chunks))
+    dev = self.theta.device
+    return (torch.tensor(chunks, dtype=torch.int64, device=dev).reshape(-1, 3).contiguous(),
+            torch.tensor(starts, dtype=torch.int64, device=dev))
+
+
+def glorot_uniform(shape, gen):
+  rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+  fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+  limit = math.sqrt(6.0 / (fan_in + fan_out))
+  return (torch.rand(shape, generator=gen, dtype=torch.float32) * 2 - 1) * limit
+
+
+def zeros_init(shape, gen):
+  return torch.zeros(shape, dtype=torch.float32)
+
+
+def ones_init(shape, gen):
+  return torch.ones(shape, dtype=torch.float32)
+
+
+def truncated_normal_init(shape, gen, std=0.05):
+  # tf.initializers.TruncatedNormal(): N(0, 0.05) redrawn outside 2 sigma
+  t = torch.randn(shape, generator=gen, dtype=torch.float32)
+  for _ in range(8):
+    bad = t.abs() > 2
+    if not bool(bad.any()):
+      break
+    t = torch.where(bad, torch.randn(shape, generator=gen, dtype=torch.float32), t)
+  return t.clamp(-2, 2) * std
+
+
+# --------------------------------------------------------------------------------- context
+class Var:
+  """Activation handle: NHWC tensor in the compute dtype plus its (lazy) gradient."""
+  __slots__ = ('data', 'grad', 'requires_grad')
+
+  def __init__(self, data, requires_grad=True):
+    self.data = data
+    self.grad = None
+    self.requires_grad = requires_grad
+
+  @property
+  def shape(self):
+    return self.data.shape
+
+
+class Ctx:
+  """Per-call execution context: compute dtype, training flag, tape, replica group."""
+
+  def __init__(self, device, dtype=torch.float32, training=False, record=False,
+               group=None):
+    self.device = torch.device(device)
+    self.dtype = dtype
+    self.code = _lib.dtype_code(torch.empty(0, dtype=dtype))
+    self.training = training
+    self.tape = [] if record else None
+    self.param_grads = True   # False: backward passes only propagate input gradients
+    self.group = group
+    self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) \
+        else 1
+    self._ws = {}
+
+  def ws(self, key, nbytes):
+    t = self._ws.get(key)
+    if t is None or t.numel() < nbytes:
+      t = torch.empty((int(nbytes),), dtype=torch.uint8, device=self.device)
+      self._ws[key] = t
+    return t
+
+  def empty(self, shape, dtype=None):
+    return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
+
+  def record(self, fn):
+    if self.tape is not None:
+      self.tape.append(fn)
+
+  def backward(self):
+    tape, self.tape = self.tape, []
+    for fn in reversed(tape):
+      fn()
+
+  def allreduce_sum(self, t):
+    if self.world > 1:
+      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+
+_WS = {}
+
+
+def _global_ws(device, key, nbytes):
+  k = (str(device), key)
+  t = _WS.get(k)
+  if t is None or t.numel() < nbytes:
+    t = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
+    _WS[k] = t
+  return t
+
+
+def accumulate(var: Var, g: torch.Tensor):
+  """var.grad += g with our own kernel (tensors with several consumers)."""
+  if not var.requires_grad:
+    return
+  if var.grad is None:
+    var.grad = g
+  else:
+    _chk(_L().se3ds_add(var.grad.data_ptr(), g.data_ptr(), _lib.dtype_code(g), g.numel(),
+                        var.grad.data_ptr(), _lib.stream()), 'se3ds_add')
+
+
+def to_var(ctx: Ctx, t: torch.Tensor, requires_grad=False) -> Var:
+  """fp32 NHWC API tensor -> compute-dtype activation."""
+  out = ctx.empty(t.shape)
+  c = t.shape[-1]
+  rows = t.numel() // c
+  t = t.contiguous()
+  _chk(_L().se3ds_copy_channels(t.data_ptr(), _lib.dtype_code(t), c, 0, out.data_ptr(), ctx.code,
+                                c, 0, c, rows, _lib.stream()), 'se3ds_copy_channels')
+  return Var(out, requires_grad)
+
+
+def concat_channels(ctx: Ctx, parts: List, out_dtype=None) -> torch.Tensor:
+  """tf.concat(axis=-1) of NHWC tensors (any of fp32 / compute dtype) into one tensor."""
+  out_dtype = out_dtype or ctx.dtype
+  lead = parts[0].shape[:-1]
+  ctot = sum(p.shape[-1] for p in parts)
+  out = torch.empty(tuple(lead) + (ctot,), dtype=out_dtype, device=ctx.device)
+  rows = out.numel() // ctot
+  c0 = 0
+  for p in parts:
+    p = p.contiguous()
+    c = p.shape[-1]
+    _chk(_L().se3ds_copy_channels(p.data_ptr(), _lib.dtype_code(p), c, 0, out.data_ptr(),
+                                  _lib.dtype_code(out), ctot, c0, c, rows, _lib.stream()),
+         'se3ds_copy_channels')
+    c0 += c
+  return out
+
+
+def slice_channels(t: torch.Tensor, c0: int, n: int, out_dtype) -> torch.Tensor:
+  c = t.shape[-1]
+  out = torch.empty(tuple(t.shape[:-1]) + (n,), dtype=out_dtype, device=t.device)
+  rows = t.numel() // c
+  _chk(_L().se3ds_copy_channels(t.data_ptr(), _lib.dtype_code(t), c, c0, out.data_ptr(),
+                                _lib.dtype_code(out), n, 0, n, rows, _lib.stream()),
+       'se3ds_copy_channels')
+  return out
+
+
+# ------------------------------------------------------------------------------ conv layers
+def conv_out_size(size, k, stride, padding, pad):
+  """(out, pad_before) for an explicit PadLayer `pad` followed by a VALID / SAME conv."""
+  if padding == 'VALID':
+    return (size + 2 * pad - k) // stride + 1, pad
+  assert pad == 0
+  out = -(-size // stride)
+  total = max((out - 1) * stride + k - size, 0)
+  return out, total // 2
+
+
+class ConvLayer:
+  """Parameters + operand copies of one convolution (plain / partial / spectral)."""
+
+  def __init__(self, store: ParamStore, name, cin, cout, k, stride=1, padding='VALID',
+               use_bias=True, kind='plain', transpose=False):
+    # kind: 'plain' | 'partial' | 'spectral' | 'partial_spectral'
+    self.store, self.name = store, name
+    self.cin, self.cout, self.k, self.stride, self.padding = cin, cout, k, stride, padding.upper()
+    self.kind, self.transpose = kind, transpose
+    # Keras layouts: Conv2D (kh,kw,cin,cout); Conv2DTranspose (kh,kw,cout_T,cin_T)
+    kshape = (k, k, cout, cin) if transpose else (k, k, cin, cout)
+    store.add(name + '/kernel', kshape, glorot_uniform)
+    self.has_bias = use_bias
+    if use_bias:
+      store.add(name + '/bias', (cout,), zeros_init)
+    self.spectral = kind in ('spectral', 'partial_spectral')
+    if self.spectral:
+      store.add(name + '/u', (1, cout), truncated_normal_init, trainable=False)
+    self._copies = {}   # dtype -> (version, wt, wn)
+    self.sn = None      # spectral scratch: dict(v, uhat, sig, part, vpart)
+
+  @property
+  def kernel(self):
+    return self.store[self.name + '/kernel']
+
+  @property
+  def bias(self):
+    return self.store[self.name + '/bias'] if self.has_bias else None
+
+  def operands(self, ctx: Ctx):
+    """Compute-dtype operand copies: wt [cout_assoc][K] and wn [K][cout_assoc]."""
+    ent = self._copies.get(ctx.dtype)
+    if ent is not None and ent[0] == self.store.version:
+      return ent[1], ent[2]
+    w = self.kernel
+    K = w.shape[0] * w.shape[1] * w.shape[2]
+    co = w.shape[3]
+    if ent is None:
+      wt = torch.empty((co, K), dtype=ctx.dtype, device=ctx.device)
+      wn = torch.empty((K, co), dtype=ctx.dtype, device=ctx.device)
+    else:
+      wt, wn = ent[1], ent[2]
+    _chk(_L().se3ds_weight_prep(w.data_ptr(), K, co, ctx.code, wt.data_ptr(), wn.data_ptr(),
+                                _lib.stream()), 'se3ds_weight_prep')
+    self._copies[ctx.dtype] = (self.store.version, wt, wn)
+    return wt, wn
+
+
+class SpectralGroup:
+  """All spectrally-normalised layers of one model: batched power iteration (layers.py:312-331)
+  and the batched gradient fix-up through sigma."""
+
+  def __init__(self, layers: List[ConvLayer], device):
+    self.layers = [l for l in layers if l.spectral]
+    L = _L()
+    nf, pr, vl = (L.se3ds_spectral_table_fields(), L.se3ds_spectral_part_rows(),
+                  L.se3ds_spectral_vpart_len())
+    rows = []
+    for l in self.layers:
+      w = l.kernel
+      K, co = w.shape[0] * w.shape[1] * w.shape[2], w.shape[3]
+      l.sn = dict(v=torch.zeros(K, device=device), uhat=torch.zeros(co, device=device),
+                  sig=torch.ones(2, device=device), part=torch.zeros(pr * co, device=device),
+                  vpart=torch.zeros(vl, device=device))
+      g = l.store.grad_views[l.name + '/kernel']
+      rows.append([w.data_ptr(), l.store[l.name + '/u'].data_ptr(), l.sn['v'].data_ptr(),
+                   l.sn['uhat'].data_ptr(), l.sn['sig'].data_ptr(), l.sn['part'].data_ptr(),
+                   l.sn['vpart'].data_ptr(), K, co, g.data_ptr()])
+      assert len(rows[-1]) == nf
+    self.table = torch.tensor(rows, dtype=torch.int64, device=device) if rows else None
+    eff = [i for i, l in enumerate(self.layers) if l.kind == 'spectral']
+    self.eff_table = self.table[eff].contiguous() if eff else None
+
+  def power_iteration(self, training):
+    if self.table is not None:
+      _chk(_L().se3ds_spectral_power_iter(self.table.data_ptr(), self.table.shape[0],
+                                          1 if training else 0, _lib.stream()),
+           'se3ds_spectral_power_iter')
+
+  def backward_fixup(self):
+    """Only layers that convolve with W/sigma (SpectralConv); PartialSpectralConv computes
+    sigma but convolves with the raw kernel (layers.py:189-195)."""
+    if self.eff_table is not None:
+      _chk(_L().se3ds_spectral_bwd_fixup(self.eff_table.data_ptr(), self.eff_table.shape[0],
+                                         _lib.stream()), 'se3ds_spectral_bwd_fixup')
+
+
+def mask_window(ctx, mask, n, h, w, ho, wo, k, stride, pad_t, pad_l, wrap, want_bwd):
+  ratio = torch.empty((n, ho, wo), dtype=torch.float32, device=ctx.device)
+  um = torch.empty_like(ratio)
+  ru = torch.empty_like(ratio) if want_bwd else None
+  bu = torch.empty_like(ratio) if want_bwd else None
+  _chk(_L().se3ds_mask_window(mask.data_ptr(), n, h, w, ho, wo, k, k, stride, pad_t, pad_l,
+                              1 if wrap else 0, ratio.data_ptr(), um.data_ptr(), _lib.ptr(ru),
+                              _lib.ptr(bu), _lib.stream()), 'se3ds_mask_window')
+  return ratio, um, ru, bu
+
+
+def _colsum(ctx, t2d_ptr, dtype_code, rows, c, row_scale=None, groups=1):
+  """Column sums [groups][c] of a [groups][rows][c] tensor (bias / affine gradients)."""
+  sums = torch.empty((groups, 2, c), dtype=torch.float32, device=ctx.device)
+  L = _L()
+  ws = ctx.ws('norm', L.se3ds_norm_workspace_bytes(groups, c))
+  _chk(L.se3ds_norm_stats(t2d_ptr, dtype_code, groups, rows, c, _lib.ptr(row_scale),
+                          sums.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+       'se3ds_norm_stats')
+  return sums
+
+
+def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act=ACT_NONE,
+           alpha=0.0):
+  """PadLayer(pad, circular=wrap) + conv (+ partial-conv renormalisation / spectral scale /
+  bias / activation).  For partial kinds returns (Var, update_mask) (layers.py:140-209)."""
+  assert not layer.transpose
+  xd = x.data
+  n, h, w, cin = xd.shape
+  assert cin == layer.cin, (cin, layer.cin)
+  k, s = layer.k, layer.stride
+  ho, pt = conv_out_size(h, k, s, layer.padding, pad)
+  wo, pl = conv_out_size(w, k, s, layer.padding, pad)
+  wrap = bool(wrap and pad > 0)
+  L = _L()
+  wt, wn = layer.operands(ctx)
+  partial = layer.kind in ('partial', 'partial_spectral')
+  recording = ctx.tape is not None
+  ratio = um = ru = bu = None
+  in_mask = None
+  if partial:
+    m = mask
+    if m is None:
+      m = torch.empty((n, h, w), dtype=torch.float32, device=ctx.device)
+      _chk(L.se3ds_fill(m.data_ptr(), _lib.F32, m.numel(), 1.0, _lib.stream()), 'se3ds_fill')
+    else:
+      in_mask = m
+    ratio, um, ru, bu = mask_window(ctx, m, n, h, w, ho, wo, k, s, pt, pl, wrap, recording)
+  # SpectralConv convolves with W/(sigma+eps); PartialSpectralConv with the raw kernel.
+  scale = layer.sn['sig'][1:] if layer.kind == 'spectral' else None
+  bias = layer.bias
+  y = ctx.empty((n, ho, wo, layer.cout))
+  _chk(L.se3ds_conv2d_fwd(xd.data_ptr(), wt.data_ptr(), y.data_ptr(), ctx.code, n, h, w, cin, ho,
+                          wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0, _lib.ptr(in_mask),
+                          _lib.ptr(scale), _lib.ptr(bias), _lib.ptr(ratio),
+                          _lib.ptr(um if (partial and bias is not None) else None), act,
+                          float(alpha), _lib.stream()), 'se3ds_conv2d_fwd')
+  out = Var(y)
+  if recording:
+    def bwd():
+      dy = out.grad
+      out.grad = None
+      if dy is None:
+        return
+      if act != ACT_NONE:
+        _chk(L.se3ds_act_bwd(dy.data_ptr(), y.data_ptr(), ctx.code, dy.numel(), act, float(alpha),
+                             dy.data_ptr(), _lib.stream()), 'se3ds_act_bwd')
+      rows = n * ho * wo
+      row_scale = None
+      if partial:
+        row_scale = ru if bias is not None else ratio
+      st = layer.store
+      if ctx.param_grads:
+        if bias is not None:
+          sums = _colsum(ctx, dy.data_ptr(), ctx.code, rows, layer.cout,
+                         row_scale=bu if partial else None)
+          st.grad_views[layer.name + '/bias'].copy_(sums[0, 0])
+        wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, layer.cout, k, k)
+        ws = _global_ws(ctx.device, 'wgrad', wsz)
+        gk = st.grad_views[layer.name + '/kernel']
+        _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dy.data_ptr(), gk.data_ptr(), ctx.code, n, h, w,
+                                  cin, ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
+                                  _lib.ptr(in_mask), _lib.ptr(row_scale), None, 0, ws.data_ptr(),
+                                  ws.numel(), _lib.stream()), 'se3ds_conv2d_wgrad')
+      if x.requires_grad:
+        dx = ctx.empty(xd.shape)
+        _chk(L.se3ds_conv2d_dgrad(dy.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h, w,
+                                  cin, ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
+                                  _lib.ptr(row_scale), _lib.ptr(scale), None, _lib.ptr(in_mask),
+                                  ACT_NONE, 0.0, _lib.stream()), 'se3ds_conv2d_dgrad')
+        accumulate(x, dx)
+    ctx.record(bwd)
+  if partial:
+    return out, um
+  return out
+
+
+def conv_transpose2d(ctx: Ctx, x: Var, layer: ConvLayer):
+  """Keras Conv2DTranspose, stride 2: k3 'SAME' output_padding=1, k2 'VALID', k2 'SAME'
+  (layers.py:417-423,475-480; image_models.py:440-441); all produce 2H x 2W."""
+  assert layer.transpose and layer.stride == 2 and layer.k in (2, 3)
+  xd = x.data
+  n, hi, wi, cin_t = xd.shape
+  assert cin_t == layer.cin
+  k = layer.k
+  H, W = 2 * hi, 2 * wi          # the associated forward conv maps (H,W,cout_T) -> (hi,wi,cin_T)
+  L = _L()
+  wt, wn = layer.operands(ctx)   # kernel (k,k,cout_T,cin_T) == HWIO of the associated conv
+  y = ctx.empty((n, H, W, layer.cout))
+  bias = layer.bias
+  _chk(L.se3ds_conv2d_dgrad(xd.data_ptr(), wn.data_ptr(), y.data_ptr(), ctx.code, n, H, W,
+                            layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None,
+                            _lib.ptr(bias), None, ACT_NONE, 0.0, _lib.stream()),
+       'se3ds_conv2d_dgrad')
+  out = Var(y)
+  if ctx.tape is not None:
+    def bwd():
+      dy = out.grad
+      out.grad = None
+      if dy is None:
+        return
+      st = layer.store
+      if ctx.param_grads:
+        if bias is not None:
+          sums = _colsum(ctx, dy.data_ptr(), ctx.code, n * H * W, layer.cout)
+          st.grad_views[layer.name + '/bias'].copy_(sums[0, 0])
+        wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, hi, wi, layer.cout, cin_t, k, k)
+        ws = _global_ws(ctx.device, 'wgrad', wsz)
+        gk = st.grad_views[layer.name + '/kernel']
+        _chk(L.se3ds_conv2d_wgrad(dy.data_ptr(), xd.data_ptr(), gk.data_ptr(), ctx.code, n, H, W,
+                                  layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None, None, 0,
+                                  ws.data_ptr(), ws.numel(), _lib.stream()), 'se3ds_conv2d_wgrad')
+      if x.requires_grad:
+        dx = ctx.empty(xd.shape)
+        _chk(L.se3ds_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), ctx.code, n, H, W,
+                                layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None, None,
+                                None, None, ACT_NONE, 0.0, _lib.stream()), 'se3ds_conv2d_fwd')
+        accumulate(x, dx)
+    ctx.record(bwd)
+  return out
+
+
+# ------------------------------------------------------------------------------------ norms
+class NormLayer:
+  """SyncBatchNormalization (kind='batch') or tfa InstanceNormalization (kind='instance')."""
+
+  def __init__(self, store: ParamStore, name, c, kind='batch'):
+    self.store, self.name, self.c, self.kind = store, name, c, kind
+    store.add(name + '/gamma', (c,), ones_init)
+    store.add(name + '/beta', (c,), zeros_init)
+    if kind == 'batch':
+      store.add(name + '/moving_mean', (c,), zeros_init, trainable=False)
+      store.add(name + '/moving_variance', (c,), ones_init, trainable=False)
+
+
+def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: Var = None,
+             post: Var = None) -> Var:
+  """y = act(norm(x) [+ res]) [+ post].  Batch norm uses cross-replica batch statistics when
+  training (SyncBatchNormalization) and moving statistics otherwise."""
+  xd = x.data
+  n, h, w, c = xd.shape
+  st = layer.store
+  L = _L()
+  inst = layer.kind == 'instance'
+  g = n if inst else 1
+  r = h * w if inst else n * h * w
+  eps = IN_EPS if inst else BN_EPS
+  gamma, beta = st[layer.name + '/gamma'], st[layer.name + '/beta']
+  use_moving = (not inst) and (not ctx.training)
+  scale = torch.empty((g, c), dtype=torch.float32, device=ctx.device)
+  shift = torch.empty_like(scale)
+  mean = torch.empty_like(scale)
+  rstd = torch.empty_like(scale)
+  count = float(r)
+  if use_moving:
+    _chk(L.se3ds_norm_finalize(None, 1.0, g, c, gamma.data_ptr(), beta.data_ptr(), eps,
+                               BN_MOMENTUM, st[layer.name + '/moving_mean'].data_ptr(),
+                               st[layer.name + '/moving_variance'].data_ptr(), 1,
+                               scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                               rstd.data_ptr(), _lib.stream()), 'se3ds_norm_finalize')
+  else:
+    sums = _colsum(ctx, xd.data_ptr(), ctx.code, r, c, groups=g)
+    if not inst and ctx.world > 1:
+      ctx.allreduce_sum(sums)
+      count = float(r * ctx.world)
+    mm = st[layer.name + '/moving_mean'] if not inst else None
+    mv = st[layer.name + '/moving_variance'] if not inst else None
+    _chk(L.se3ds_norm_finalize(sums.data_ptr(), count, g, c, gamma.data_ptr(), beta.data_ptr(),
+                               eps, BN_MOMENTUM, _lib.ptr(mm), _lib.ptr(mv), 0, scale.data_ptr(),
+                               shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _lib.stream()),
+         'se3ds_norm_finalize')
+  y = ctx.empty(xd.shape)
+  _chk(L.se3ds_norm_apply(xd.data_ptr(), ctx.code, g, r, c, scale.data_ptr(), shift.data_ptr(),
+                          _lib.ptr(res.data if res is not None else None),
+                          _lib.ptr(post.data if post is not None else None), act, float(alpha),
+                          y.data_ptr(), _lib.stream()), 'se3ds_norm_apply')
+  out = Var(y)
+  if ctx.tape is not None:
+    def bwd():
+      dy = out.grad
+      out.grad = None
+      if dy is None:
+        return
+      if post is not None:
+        # y = act(.) + post: the activation mask must come from (y - post); recompute it
+        raise NotImplementedError
+      ws = ctx.ws('norm', L.se3ds_norm_workspace_bytes(g, c))
+      want_res = res is not None and res.requires_grad
+      dres = ctx.empty(xd.shape) if want_res else None
+      dx = ctx.empty(xd.shape)
+      if use_moving:
+        _chk(L.se3ds_affine_bwd(dy.data_ptr(), y.data_ptr(), ctx.code, g, r, c, scale.data_ptr(),
+                                act, float(alpha), dx.data_ptr(), _lib.ptr(dres), _lib.stream()),
+             'se3ds_affine_bwd')
+      else:
+        bs = torch.empty((g, 2, c), dtype=torch.float32, device=ctx.device)
+        _chk(L.se3ds_norm_bwd_stats(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c,
+                                    mean.data_ptr(), rstd.data_ptr(), act, float(alpha),
+                                    bs.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+             'se3ds_norm_bwd_stats')
+        # parameter gradients are the LOCAL sums (aggregated later with every other gradient)
+        if not ctx.param_grads:
+          pass
+        elif g == 1:
+          st.grad_views[layer.name + '/beta'].copy_(bs[0, 0])
+          st.grad_views[layer.name + '/gamma'].copy_(bs[0, 1])
+        else:
+          tot = _colsum(ctx, bs.data_ptr(), _lib.F32, g, 2 * c)
+          st.grad_views[layer.name + '/beta'].copy_(tot[0, 0, :c])
+          st.grad_views[layer.name + '/gamma'].copy_(tot[0, 0, c:])
+        if not inst and ctx.world > 1:
+          ctx.allreduce_sum(bs)   # SyncBN backward: statistics gradients are global
+        _chk(L.se3ds_norm_bwd_apply(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c,
+                                    mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                    bs.data_ptr(), count, act, float(alpha), dx.data_ptr(),
+                                    _lib.ptr(dres), _lib.stream()), 'se3ds_norm_bwd_apply')
+      accumulate(x, dx)
+      if want_res:
+        accumulate(res, dres)
+    ctx.record(bwd)
+  return out
+
+
+def add(ctx: Ctx, a: Var, b: Var) -> Var:
+  """out = a + b (decoder skip connections, image_models.py:455-482)."""
+  y = ctx.empty(a.data.shape)
+  _chk(_L().se3ds_add(a.data.data_ptr(), b.data.data_ptr(), ctx.code, y.numel(), y.data_ptr(),
+                      _lib.stream()), 'se3ds_add')
+  out = Var(y)
+  if ctx.tape is not None:
+    def bwd():
+      dy = out.grad
+      out.grad = None
+      if dy is None:
+        return
+      if a.requires_grad and b.requires_grad and a.grad is None and b.grad is None:
+        # both take the same gradient tensor; give b its own copy so later in-place
+        # accumulations into one do not leak into the other
+        a.grad = dy
+        b.grad = dy.clone()
+      else:
+        accumulate(a, dy)
+        accumulate(b, dy if a.grad is not dy else dy.clone())
+    ctx.record(bwd)
+  return out
+
+
+# ------------------------------------------------------------------------- pooling / resize
+def maxpool2x2(ctx: Ctx, x: Var) -> Var:
+  xd = x.data
+  n, h, w, c = xd.shape
+  y = ctx.empty((n, (h + 1) // 2, (w + 1) // 2, c))
+  L = _L()
+  _chk(L.se3ds_maxpool2x2_fwd(xd.data_ptr(), ctx.code, n, h, w, c, y.data_ptr(), _lib.stream()),
+       'se3ds_maxpool2x2_fwd')
+  out = Var(y)
+  if ctx.tape is not None:
+    def bwd():
+      dy = out.grad
+      out.grad = None
+      if dy is None or not x.requires_grad:
+        return
+      dx = ctx.empty(xd.shape)
+      _chk(L.se3ds_maxpool2x2_bwd(dy.data_ptr(), xd.data_ptr(), y.data_ptr(), ctx.code, n, h, w, c,
+                                  dx.data_ptr(), _lib.stream()), 'se3ds_maxpool2x2_bwd')
+      accumulate(x, dx)
+    ctx.record(bwd)
+  return out
+
+
+def maxpool2x2_mask(ctx: Ctx, m: torch.Tensor) -> torch.Tensor:
+  """MaxPool of the (N,H,W) fp32 mask (image_models.py:289); no gradient."""
+  n, h, w = m.shape
+  y = torch.empty((n, (h + 1) // 2, (w + 1) // 2), dtype=torch.float32, device=m.device)
+  _chk(_L().se3ds_maxpool2x2_fwd(m.data_ptr(), _lib.F32, n, h, w, 1, y.data_ptr(), _lib.stream()),
+       'se3ds_maxpool2x2_fwd')
+  return y
+
+
+def avgpool3s2(ctx: Ctx, x: Var) -> Var:
+  xd = x.data
+  n, h, w, c = xd.shape
+  y = ctx.empty((n, (h + 1) // 2, (w + 1) // 2, c))
+  L = _L()
+  _chk(L.se3ds_avgpool3s2_fwd(xd.data_ptr(), ctx.code, n, h, w, c, y.data_ptr(), _lib.stream()),
+       'se3ds_avgpool3s2_fwd')
+  out = Var(y, x.requires_grad)
+  if ctx.tape is not None:
+    def bwd():
+      dy = out.grad
+      out.grad = None
+      if dy is None or not x.requires_grad:
+        return
+      dx = ctx.empty(xd.shape)
+      _chk(L.se3ds_avgpool3s2_bwd(dy.data_ptr(), ctx.code, n, h, w, c, dx.data_ptr(),
+                                  _lib.stream()), 'se3ds_avgpool3s2_bwd')
+      accumulate(x, dx)
+    ctx.record(bwd)
+  return out
+
+
+def upsample2x(ctx: Ctx, x: Var) -> Var:
+  xd = x.data
+  n, h, w, c = xd.shape
+  y = ctx.empty((n, 2 * h, 2 * w, c))
+  L = _L()
+  _chk(L.se3ds_upsample2x_fwd(xd.data_ptr(), ctx.code, n, h, w, c, y.data_ptr(), _lib.stream()),
+       'se3ds_upsample2x_fwd')
+  out = Var(y)
+  if ctx.tape is not None:
+    def bwd():
+      dy = out.grad
+      out.grad = None
+      if dy is None or not x.requires_grad:
+        return
+      dx = ctx.empty(xd.shape)
+      _chk(L.se3ds_upsample2x_bwd(dy.data_ptr(), ctx.code, n, h, w, c, dx.data_ptr(),
+                                  _lib.stream()), 'se3ds_upsample2x_bwd')
+      accumulate(x, dx)
+    ctx.record(bwd)
+  return out
+
+
+def pad2d(x: torch.Tensor, pad: int, circular: bool, mode='CONSTANT', constant_value=0.0):
+  """Standalone PadLayer (models/layers.py:22-97) on an NHWC fp32/bf16 tensor."""
+  _lib.require_cuda(x)
+  n, h, w, c = x.shape
+  x = x.contiguous()
+  y = torch.empty((n, h + 2 * pad, w + 2 * pad, c), dtype=x.dtype, device=x.device)
+  code = {'CONSTANT': 0, 'REFLECT': 1, 'SYMMETRIC': 2}[mode.upper()]
+  _chk(_L().se3ds_pad2d(x.data_ptr(), _lib.dtype_code(x), n, h, w, c, pad, code,
+                        1 if circular else 0, float(constant_value), y.data_ptr(), _lib.stream()),
+       'se3ds_pad2d')
+  return y
+
+
+# ---------------------------------------------------------------------------------- heads
+def head(ctx: Ctx, x: Var, kind: int):
+  """kind 0: rgb = (tanh(x)+1)/2 ; kind 1: depth = clip(x, 0, 1)  (image_models.py:187-190).
+  Returns the fp32 output tensor and a function taking its fp32 gradient."""
+  xd = x.data
+  y = torch.empty(xd.shape, dtype=torch.float32, device=ctx.device)
+  L = _L()
+  _chk(L.se3ds_head_fwd(xd.data_ptr(), ctx.code, xd.numel(), kind, y.data_ptr(), _lib.stream()),
+       'se3ds_head_fwd')
+  def push_grad(dy: torch.Tensor):
+    dx = ctx.empty(xd.shape)
+    _chk(L.se3ds_head_bwd(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, xd.numel(), kind,
+                          dx.data_ptr(), _lib.stream()), 'se3ds_head_bwd')
+    accumulate(x, dx)
+  return y, push_grad

@@ -1,0 +1,263 @@
+"""GAN training manager -- MI355X implementation of the hot-path half of the reference's
+trainers/gan_manager.py: model / optimizer construction (:169-183), the cluster step
+(:351-385) and the EMA hooks (:642-655).  Dataset pipelines, checkpoint files, TensorBoard
+logging and the FID evaluation loop of the reference are out of scope;
+`train()` runs the same host loop on a synthetic (or user supplied) batch iterator."""
+import abc
+import random
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from se3ds_amd import _lib
+from se3ds_amd import gin_lite as gin
+from se3ds_amd import hipops  # noqa: F401
+from se3ds_amd.utils import ema
+
+
+class OneDeviceStrategy:
+  """Stands in for tf.distribute.OneDeviceStrategy (reference main.py:55-60)."""
+  num_replicas_in_sync = 1
+  group = None
+
+  def __init__(self, device='cuda:0'):
+    self.device = torch.device(device)
+
+
+class DataParallelStrategy:
+  """One process per GPU over RCCL (torch.distributed 'nccl'); stands in for
+  tf.distribute.MirroredStrategy (reference main.py:63)."""
+
+  def __init__(self, device, group=None):
+    self.device = torch.device(device)
+    self.group = group
+    self.num_replicas_in_sync = dist.get_world_size(group)
+
+
+class AdamState:
+  """Keras Adam slots over a model's flat trainable arena (reference :175-183)."""
+
+  def __init__(self, model, lr, beta_1, beta_2, epsilon=1e-7):
+    self.model = model
+    self.lr, self.beta_1, self.beta_2, self.epsilon = lr, beta_1, beta_2, epsilon
+    self.m = torch.zeros_like(model.store.theta)
+    self.v = torch.zeros_like(model.store.theta)
+    self.iterations = 0
+    self.chunks, self.tensor_chunk_start = model.store.chunk_tables()
+    dev = model.store.theta.device
+    self.partial = torch.empty(self.chunks.shape[0], dtype=torch.float32, device=dev)
+    self.sqnorm = torch.empty(len(model.store.trainable_names), dtype=torch.float32, device=dev)
+    self.mean_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+  def clip_gradients(self, clip_norm=5.0):
+    """Per-tensor tf.clip_by_norm, in place on the gradient arena (se3ds_trainer.py:27-32)."""
+    st = self.model.store
+    L = _lib.lib()
+    nt = len(st.trainable_names)
+    _lib.check(L.se3ds_multi_sqnorm(st.grad.data_ptr(), self.chunks.data_ptr(),
+                                    self.chunks.shape[0], self.tensor_chunk_start.data_ptr(), nt,
+                                    self.partial.data_ptr(), self.sqnorm.data_ptr(),
+                                    _lib.stream()), 'se3ds_multi_sqnorm')
+    _lib.check(L.se3ds_multi_clip_by_norm(st.grad.data_ptr(), self.chunks.data_ptr(),
+                                          self.chunks.shape[0], self.sqnorm.data_ptr(), nt,
+                                          float(clip_norm), self.mean_norm.data_ptr(),
+                                          _lib.stream()), 'se3ds_multi_clip_by_norm')
+    return self.mean_norm
+
+  def apply_gradients(self, group=None, world=1):
+    """Cross-replica SUM of the (already clipped, already 1/R-scaled) gradients, then the
+    Keras Adam update (reference se3ds_trainer.py:253-257)."""
+    st = self.model.store
+    if world > 1:
+      bucket = 64 * 1024 * 1024  # elements per all-reduce (256 MiB fp32)
+      for o in range(0, st.grad.numel(), bucket):
+        dist.all_reduce(st.grad[o:o + bucket], op=dist.ReduceOp.SUM, group=group)
+    self.iterations += 1
+    _lib.check(_lib.lib().se3ds_multi_adam_keras(
+        st.theta.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+        st.theta.numel(), self.lr, self.beta_1, self.beta_2, self.epsilon, self.iterations,
+        _lib.stream()), 'se3ds_multi_adam_keras')
+    st.version += 1
+
+
+class Mean:
+  """tf.keras.metrics.Mean over device scalars; values are read lazily (no sync per step)."""
+
+  def __init__(self, name):
+    self.name = name
+    self._vals = []
+
+  def update_state(self, v):
+    self._vals.append(v)
+
+  def reset_states(self):
+    self._vals = []
+
+  def result(self):
+    if not self._vals:
+      return np.float32(0.0)
+    tot = 0.0
+    for v in self._vals:
+      if callable(v):
+        v = v()
+      if isinstance(v, torch.Tensor):
+        v = float(v.detach().float().mean().cpu())
+      tot += float(v)
+    return np.float32(tot / len(self._vals))
+
+
+@gin.configurable(denylist=['strategy', 'model_dir'])
+class GANManager(abc.ABC):
+  """Constructor surface of the reference (:98-167)."""
+
+  def __init__(self, strategy, model_dir: str = '', image_size: int = 128, seed: int = 1,
+               optimizer_type: str = 'adam', beta1: float = 0.0, beta2: float = 0.999,
+               g_lr: float = 0.0002, d_lr: float = 0.0002, train_batch_size: int = 128,
+               test_batch_size: int = 128, parallel_calls: int = -1, log_every_steps: int = 1000,
+               save_every_steps: int = 2000, eval_every_steps: int = 2000, num_epochs: int = 100,
+               d_step_per_g_step: int = 1, num_batched_steps: int = 5, show_num: int = 16,
+               shuffle_buffer_size: int = 1000, ema_decay: float = 0.999, ema_init_step: int = 0,
+               generator_fn=None, discriminator_fn=None, train_dataset_glob: Optional[str] = None,
+               test_dataset_glob: Optional[str] = None, eval_size: Optional[int] = 10000,
+               test_split: str = 'val_seen', eval_seq_len: int = 4, predict_depth: bool = False,
+               compute_dtype=torch.float32):
+    self.strategy = strategy
+    self.model_dir = model_dir
+    self.image_size = image_size
+    self.seed = seed
+    self.optimizer_type = optimizer_type
+    self.beta1, self.beta2 = beta1, beta2
+    self.g_lr, self.d_lr = g_lr, d_lr
+    self.global_batch_size = train_batch_size
+    self.train_batch_size = train_batch_size
+    self.test_batch_size = test_batch_size
+    self.parallel_calls = parallel_calls
+    self.log_every_steps = log_every_steps
+    self.save_every_steps = save_every_steps
+    self.eval_every_steps = eval_every_steps
+    self.num_epochs = num_epochs
+    self.d_step_per_g_step = d_step_per_g_step
+    self.num_batched_steps = num_batched_steps
+    self.show_num = show_num
+    self.shuffle_buffer_size = shuffle_buffer_size
+    self.ema_decay = ema_decay
+    self.ema_init_step = ema_init_step
+    self.generator_fn = generator_fn
+    self.discriminator_fn = discriminator_fn
+    self.train_dataset_glob = train_dataset_glob
+    self.test_dataset_glob = test_dataset_glob
+    self.eval_size = eval_size
+    self.test_split = test_split
+    self.eval_seq_len = eval_seq_len
+    self.predict_depth = predict_depth
+    self.compute_dtype = compute_dtype
+    self.global_step = 0
+    self.train_ds = None
+    if seed > 0:   # reference :164-167 (the shipped configs set seed = 0: nothing is seeded)
+      random.seed(seed)
+      np.random.seed(seed)
+      torch.manual_seed(seed)
+
+  # ----------------------------------------------------------------------------- building
+  def _build_model(self):
+    """Creates Generator, Discriminator and EMA Generator (reference :169-173)."""
+    dev = self.strategy.device
+    kw = dict(device=dev, dtype=self.compute_dtype)
+    self.generator = self.generator_fn(image_size=self.image_size, seed=1000 + max(self.seed, 0),
+                                       **kw)
+    self.discriminator = self.discriminator_fn(image_size=self.image_size,
+                                               seed=2000 + max(self.seed, 0), **kw)
+    self.ema_generator = self.generator_fn(image_size=self.image_size,
+                                           seed=3000 + max(self.seed, 0), **kw)
+
+  def _build_optimizer(self):
+    """Creates optimizers for both Generator and Discriminator (reference :175-183)."""
+    if self.optimizer_type == 'adam':
+      self.g_optimizer = AdamState(self.generator, self.g_lr, self.beta1, self.beta2)
+      self.d_optimizer = AdamState(self.discriminator, self.d_lr, self.beta1, self.beta2)
+    else:
+      raise NotImplementedError
+
+  def _create_metrics(self):
+    self.metrics = {'gen_loss': Mean('gen_loss'), 'disc_loss': Mean('disc_loss')}
+
+  def _create_obj(self):
+    """reference :333-349 without the checkpoint objects."""
+    self.global_step = 0
+    self._build_model()
+    self._build_optimizer()
+    self._create_metrics()
+
+  def _split_input_dict(self, input_dict, splits):
+    """Splits a batch dict along axis 0 into `splits` dicts (reference :351-364)."""
+    output = [dict() for _ in range(splits)]
+    for key, item in input_dict.items():
+      n = item.shape[0]
+      if n % splits != 0:
+        raise ValueError(f'batch {n} of {key} is not divisible by {splits}')
+      for i, part in enumerate(torch.split(item, n // splits)):
+        output[i][key] = part
+    return output
+
+  @abc.abstractmethod
+  def train_d(self, inputs):
+    """Learns the Discriminator updates."""
+
+  @abc.abstractmethod
+  def train_g_d(self, inputs):
+    """Learns both the Generator and Discriminator updates."""
+
+  def train_cluster(self, steps=1):
+    """`steps` cluster steps: d_step_per_g_step-1 train_d calls then one train_g_d, each on
+    its own chunk of the cluster batch (reference :376-385)."""
+    for _ in range(int(steps)):
+      inputs = next(self.train_ds)
+      input_list = self._split_input_dict(inputs, self.d_step_per_g_step)
+      for i in range(self.d_step_per_g_step - 1):
+        self.train_d(input_list[i])
+      self.train_g_d(input_list[-1])
+
+  def train(self, train_ds=None, num_train_steps=None):
+    """Host loop of the reference (:387-423) minus logging / checkpoint files."""
+    self.global_batch_size = self.train_batch_size
+    if not hasattr(self, 'generator'):
+      self._create_obj()
+    if train_ds is not None:
+      self.train_ds = iter(train_ds)
+    if self.train_ds is None:
+      raise ValueError('no training data: pass train_ds (an iterator of batch dicts)')
+    if num_train_steps is None:
+      num_train_steps = 1 if self.num_epochs == -1 else self.num_batched_steps
+    for step in range(self.global_step, num_train_steps, self.num_batched_steps):
+      self.train_cluster(self.num_batched_steps)
+      if step % self.log_every_steps < self.num_batched_steps:
+        self._save_metrics_to_dict()
+        self._reset_metrics()
+      self.global_step += self.num_batched_steps
+
+  def _reset_metrics(self):
+    for key in self.metrics:
+      self.metrics[key].reset_states()
+
+  def _save_metrics_to_dict(self):
+    output_dict = {}
+    for key, value in self.metrics.items():
+      r = value.result()
+      if np.any(np.isnan(r)):
+        raise ValueError(f'NaN losses recorded for {key}.')
+      output_dict[key] = r
+    return output_dict
+
+  # ---------------------------------------------------------------------------------- EMA
+  def update_ema_model(self):
+    """reference :642-651."""
+    if self.global_step >= self.ema_init_step:
+      if self.global_step >= self.ema_init_step + self.num_batched_steps:
+        ema.update_ema_variables(self.ema_generator, self.generator, self.ema_decay)
+      else:
+        self.assign_ema_model_first_time()
+
+  def assign_ema_model_first_time(self):
+    ema.assign_ema_vars_from_initial_values(self.ema_generator, self.generator)

@@ -1,0 +1,268 @@
+"""Trainer for the SE3DS model -- MI355X implementation of the reference's
+trainers/se3ds_trainer.py: the hinge-GAN step (`train_g_d` :129-273, `train_d` :275-338) with
+its losses (:27-71).  Same class name, constructor arguments, attribute names and metric keys;
+all arithmetic runs in libse3ds_hip.so.
+
+Reference semantics kept on purpose:
+  * the generator loss is an (N,)-vector (the world-consistency term is not reduced) and its
+    gradient is the sum of the elements: G gradients carry a factor N for the scalar terms;
+  * losses are pre-divided by the replica count, gradients are clipped per tensor and per
+    replica BEFORE the cross-replica sum;
+  * hinge terms use only the last feature map of each sub-discriminator;
+  * `train_d` runs the generator in training mode outside any tape (BN moving statistics and
+    spectral `u` advance on D-only steps too).
+"""
+from typing import Dict
+
+import torch
+
+from se3ds_amd import _lib
+from se3ds_amd import gin_lite as gin
+from se3ds_amd.hipops import nn
+from se3ds_amd.hipops.nn import Var
+from se3ds_amd.models import image_models  # noqa: F401  (gin references)
+from se3ds_amd.trainers import gan_manager
+from se3ds_amd.trainers.gan_manager import Mean
+
+GRAD_CLIP_NORM = 5.0   # _clip_grad default, reference :27
+
+
+def _L():
+  return _lib.lib()
+
+
+@gin.configurable(denylist=['strategy', 'model_dir'])
+class GAN(gan_manager.GANManager):
+  """One stage GAN (reference :74-93)."""
+
+  def __init__(self, lambda_gan, lambda_kld, lambda_wc, lambda_depth, *args,
+               dis_use_pred_depth=True, mask_blurred=False, **kwargs):
+    super().__init__(*args, **kwargs)
+    self.lambda_gan = lambda_gan
+    self.lambda_kld = lambda_kld
+    self.lambda_wc = lambda_wc
+    self.lambda_depth = lambda_depth
+    self.dis_use_pred_depth = dis_use_pred_depth
+    self.mask_blurred = mask_blurred
+
+  def _create_metrics(self):
+    """Metric names of the reference (:107-127)."""
+    names = ['gen/gen_loss', 'dis/disc_loss', 'dis/grad_norm', 'gen/gen_feat_loss',
+             'gen/gen_gan_loss', 'gen/depth_loss', 'gen/seg_loss', 'gen/depth_seg_loss',
+             'gen/depth_seg_consistency', 'gen/kld_loss', 'gen/kld_nan', 'gen/wc_loss',
+             'gen/grad_norm']
+    self.metrics = {n: Mean(n.split('/')[-1]) for n in names}
+
+  # --------------------------------------------------------------------------- D plumbing
+  def _prep_inputs(self, inputs):
+    inputs = dict(inputs)
+    for k in ('image', 'proj_image', 'proj_depth', 'proj_mask', 'depth', 'blurred_mask'):
+      t = inputs[k]
+      _lib.require_cuda(t)
+      inputs[k] = t.to(torch.float32).contiguous()
+    if not self.mask_blurred:
+      bm = torch.empty_like(inputs['blurred_mask'])
+      _lib.check(_L().se3ds_fill(bm.data_ptr(), _lib.F32, bm.numel(), 0.0, _lib.stream()),
+                 'se3ds_fill')
+      inputs['blurred_mask'] = bm
+    return inputs
+
+  def _disc_input(self, ctx, generated, depth_out, image, depth):
+    """concat([fake(rgb|depth), real(image|depth)], axis=0) -> (2N,H,W,4) (reference :181-192)."""
+    n = image.shape[0]
+    fake_d = depth_out if self.dis_use_pred_depth else depth
+    fake = nn.concat_channels(ctx, [generated, fake_d])
+    real = nn.concat_channels(ctx, [image, depth])
+    x = ctx.empty((2 * n,) + tuple(fake.shape[1:]))
+    x[:n].copy_(fake)
+    x[n:].copy_(real)
+    return Var(x, requires_grad=False)
+
+  def _run_discriminator(self, ctx, x_all):
+    res = self.discriminator.forward(ctx, x_all)
+    return res
+
+  def _hinge(self, ctx, logits, coef_d, coef_g, want_g):
+    """Per sub-discriminator hinge sums + gradient seeds on the LAST feature map only."""
+    sums, seeds_d, seeds_g = [], [], []
+    for sub in logits:
+      last = sub[-1].data
+      half = last.numel() // 2
+      s = torch.empty(2, dtype=torch.float32, device=ctx.device)
+      gd = torch.empty_like(last)
+      gg = torch.empty_like(last) if want_g else None
+      cnt = float(half)
+      _lib.check(_L().se3ds_hinge(last.data_ptr(), ctx.code, half, coef_d / cnt, coef_g / cnt,
+                                  s.data_ptr(), gd.data_ptr(), _lib.ptr(gg), _lib.stream()),
+                 'se3ds_hinge')
+      sums.append((s, cnt))
+      seeds_d.append(gd)
+      seeds_g.append(gg)
+    return sums, seeds_d, seeds_g
+
+  def _backward_tape(self, ctx, tape, seeds, logits):
+    for sub, g in zip(logits, seeds):
+      sub[-1].grad = g
+    for fn in reversed(tape):
+      fn()
+
+  # ------------------------------------------------------------------------------ train_g_d
+  def train_g_d(self, inputs: Dict[str, torch.Tensor]) -> None:
+    """One generator + discriminator update (reference :129-273)."""
+    inputs = self._prep_inputs(inputs)
+    image, depth_t = inputs['image'], inputs['depth']
+    n, h, w, _ = image.shape
+    p = h * w
+    R = self.strategy.num_replicas_in_sync
+    group = self.strategy.group
+    G, D = self.generator, self.discriminator
+    L = _L()
+    dev = image.device
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    # ---- generator forward (both "tapes" of the reference share this forward)
+    ctx_g = G.make_ctx(training=True, record=True, group=group)
+    outs, (push_rgb, push_depth) = G.forward(ctx_g, inputs)
+    depth_out, generated = outs[3], outs[6]
+
+    # ---- per-sample normalisers and loss sums
+    npx = torch.empty(n, **f32)        # valid-depth pixel counts (:148-152)
+    _lib.check(L.se3ds_sample_sum(depth_t.data_ptr(), None, None, n, p, 1, 2, npx.data_ptr(),
+                                  _lib.stream()), 'se3ds_sample_sum')
+    wcm = torch.empty(n, **f32)        # sum of proj_mask * (1 - blurred_mask) (:176-178)
+    _lib.check(L.se3ds_sample_sum(inputs['proj_mask'].data_ptr(), inputs['blurred_mask'].data_ptr(),
+                                  None, n, p, 1, 3, wcm.data_ptr(), _lib.stream()),
+               'se3ds_sample_sum')
+    # gradient coefficients of the SUM over the (N,)-vector loss, already / replicas
+    coef_depth = torch.empty(n, **f32)
+    coef_wc = torch.empty(n, **f32)
+    depth_scale = (self.lambda_depth / R) if self.predict_depth else 0.0
+    _lib.check(L.se3ds_recip_clamp(npx.data_ptr(), n, depth_scale, coef_depth.data_ptr(),
+                                   _lib.stream()), 'se3ds_recip_clamp')
+    _lib.check(L.se3ds_recip_clamp(wcm.data_ptr(), n, self.lambda_wc / (3.0 * R),
+                                   coef_wc.data_ptr(), _lib.stream()), 'se3ds_recip_clamp')
+    d_depth = torch.empty_like(depth_out)
+    _lib.check(L.se3ds_l1_grad(depth_out.data_ptr(), depth_t.data_ptr(), None, None,
+                               coef_depth.data_ptr(), n, p, 1, 0, d_depth.data_ptr(),
+                               _lib.stream()), 'se3ds_l1_grad')
+    d_rgb = torch.empty_like(generated)
+    _lib.check(L.se3ds_l1_grad(generated.data_ptr(), inputs['proj_image'].data_ptr(),
+                               inputs['proj_mask'].data_ptr(), inputs['blurred_mask'].data_ptr(),
+                               coef_wc.data_ptr(), n, p, 3, 1, d_rgb.data_ptr(), _lib.stream()),
+               'se3ds_l1_grad')
+    # metric sums (read lazily)
+    depth_l1 = torch.empty(n, **f32)
+    tmask = torch.empty((n, p), **f32)   # 1[0 < depth < 1] as an explicit mask for mode 1
+    _lib.check(L.se3ds_l1_grad(depth_t.data_ptr(), depth_t.data_ptr(), None, None, None, n, p, 1, 2,
+                               tmask.data_ptr(), _lib.stream()), 'se3ds_l1_grad')
+    _lib.check(L.se3ds_sample_sum(depth_out.data_ptr(), depth_t.data_ptr(), tmask.data_ptr(), n, p,
+                                  1, 1, depth_l1.data_ptr(), _lib.stream()), 'se3ds_sample_sum')
+    wc_l1 = torch.empty(n, **f32)
+    wmask = torch.empty((n, p), **f32)
+    _lib.check(L.se3ds_l1_grad(inputs['proj_mask'].data_ptr(), inputs['proj_mask'].data_ptr(),
+                               inputs['proj_mask'].data_ptr(), inputs['blurred_mask'].data_ptr(),
+                               None, n, p, 1, 3, wmask.data_ptr(), _lib.stream()), 'se3ds_l1_grad')
+    _lib.check(L.se3ds_sample_sum(generated.data_ptr(), inputs['proj_image'].data_ptr(),
+                                  wmask.data_ptr(), n, p, 3, 1, wc_l1.data_ptr(), _lib.stream()),
+               'se3ds_sample_sum')
+
+    # ---- discriminator forward on [fake; real]
+    ctx_d = D.make_ctx(training=True, record=True, group=group)
+    x_all = self._disc_input(ctx_d, generated, depth_out, image, depth_t)
+    logits = self._run_discriminator(ctx_d, x_all)
+    n_dis = len(logits)
+    # d(disc_loss / R)/dlogit and d(sum_i gen_loss / R)/dlogit = N * d(gen_loss / R)/dlogit
+    coef_d = self.lambda_gan / (n_dis * R)
+    coef_g = self.lambda_gan * n / (n_dis * R)
+    hinge_sums, seeds_d, seeds_g = self._hinge(ctx_d, logits, coef_d, coef_g, want_g=True)
+    tape_d = ctx_d.tape
+    ctx_d.tape = None
+
+    # ---- pass 1: discriminator parameter gradients (disc_tape, :244)
+    ctx_d.param_grads = True
+    self._set_input_grad(x_all, False)
+    self._backward_tape(ctx_d, tape_d, seeds_d, logits)
+    D.spectral.backward_fixup()
+    # ---- pass 2: gradient of the generator loss w.r.t. the fake images (gen_tape, :236)
+    ctx_d.param_grads = False
+    self._set_input_grad(x_all, True)
+    self._backward_tape(ctx_d, tape_d, seeds_g, logits)
+    gx = x_all.grad
+    x_all.grad = None
+    del tape_d
+    g_rgb = nn.slice_channels(gx[:n], 0, 3, torch.float32)
+    _lib.check(L.se3ds_add(d_rgb.data_ptr(), g_rgb.data_ptr(), _lib.F32, d_rgb.numel(),
+                           d_rgb.data_ptr(), _lib.stream()), 'se3ds_add')
+    if self.dis_use_pred_depth:
+      g_dep = nn.slice_channels(gx[:n], 3, 1, torch.float32)
+      _lib.check(L.se3ds_add(d_depth.data_ptr(), g_dep.data_ptr(), _lib.F32, d_depth.numel(),
+                             d_depth.data_ptr(), _lib.stream()), 'se3ds_add')
+    # ---- generator backward
+    ctx_g.param_grads = True
+    push_rgb(d_rgb)
+    push_depth(d_depth)
+    ctx_g.backward()
+    G.spectral.backward_fixup()
+
+    # ---- clip per tensor (per replica), aggregate, apply (:238-257)
+    g_norm = self.g_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
+    d_norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
+    self.g_optimizer.apply_gradients(group, R)
+    self.d_optimizer.apply_gradients(group, R)
+    if self.global_step == 0:
+      # builds the EMA model's variables in the reference (:258-259): a throw-away forward
+      self.ema_generator.forward(self.ema_generator.make_ctx(training=True, group=group), inputs)
+    self.update_ema_model()
+
+    # ---- metrics (:261-273); values are resolved when read
+    lam_d = self.lambda_depth if self.predict_depth else 0.0
+    def gen_gan():
+      return self.lambda_gan * sum(float(s[0]) / c for s, c in hinge_sums) / n_dis
+    def disc():
+      return self.lambda_gan * sum(float(s[1]) / c for s, c in hinge_sums) / n_dis
+    def depth_loss():
+      return lam_d * float((depth_l1 / torch.clamp(npx, min=1)).mean())
+    def wc_loss():
+      return self.lambda_wc * float((wc_l1 / 3.0 / torch.clamp(wcm, min=1)).mean())
+    self.metrics['dis/disc_loss'].update_state(disc)
+    self.metrics['dis/grad_norm'].update_state(d_norm)
+    self.metrics['gen/gen_gan_loss'].update_state(gen_gan)
+    self.metrics['gen/gen_loss'].update_state(lambda: gen_gan() + depth_loss() + wc_loss())
+    self.metrics['gen/depth_loss'].update_state(depth_loss)
+    self.metrics['gen/seg_loss'].update_state(0.0)
+    self.metrics['gen/depth_seg_loss'].update_state(0.0)
+    self.metrics['gen/depth_seg_consistency'].update_state(0.0)
+    self.metrics['gen/kld_loss'].update_state(0.0)
+    self.metrics['gen/kld_nan'].update_state(0.0)
+    self.metrics['gen/wc_loss'].update_state(wc_loss)
+    self.metrics['gen/grad_norm'].update_state(g_norm)
+
+  def _set_input_grad(self, x_all, flag):
+    x_all.requires_grad = flag
+    for v in getattr(self.discriminator, '_scale_inputs', []):
+      v.requires_grad = flag
+
+  # -------------------------------------------------------------------------------- train_d
+  def train_d(self, inputs: Dict[str, torch.Tensor]) -> None:
+    """One discriminator-only update (reference :275-338)."""
+    inputs = self._prep_inputs(inputs)
+    image, depth_t = inputs['image'], inputs['depth']
+    R = self.strategy.num_replicas_in_sync
+    group = self.strategy.group
+    G, D = self.generator, self.discriminator
+    # generator forward in training mode, outside any tape (:292-293)
+    ctx_g = G.make_ctx(training=True, record=False, group=group)
+    outs, _ = G.forward(ctx_g, inputs)
+    depth_out, generated = outs[3], outs[6]
+    ctx_d = D.make_ctx(training=True, record=True, group=group)
+    x_all = self._disc_input(ctx_d, generated, depth_out, image, depth_t)
+    logits = self._run_discriminator(ctx_d, x_all)
+    coef_d = self.lambda_gan / (len(logits) * R)
+    _, seeds_d, _ = self._hinge(ctx_d, logits, coef_d, 0.0, want_g=False)
+    tape_d, ctx_d.tape = ctx_d.tape, None
+    ctx_d.param_grads = True
+    self._set_input_grad(x_all, False)
+    self._backward_tape(ctx_d, tape_d, seeds_d, logits)
+    D.spectral.backward_fixup()
+    self.d_optimizer.clip_gradients(GRAD_CLIP_NORM)
+    self.d_optimizer.apply_gradients(group, R)

@@ -1,0 +1,448 @@
+"""GPU parity tests: HIP network kernels (through the C ABI) vs the PyTorch-CPU oracle.
+
+Tolerances (north_star: "generator activations and grads within 1e-3 rel fp32"):
+  fp32 path  : max |a-b| <= 1e-3 * max|b| per tensor (most tensors are ~1e-5)
+  bf16 path  : 3e-2 * max|b| (bf16 has 8 mantissa bits; operands are rounded to bf16, the
+               accumulation is fp32)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_torch as O
+from se3ds_amd import gin_lite
+from se3ds_amd.hipops import nn
+from se3ds_amd.models import image_models
+from se3ds_amd.models import layers
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def rel_err(a, b):
+  a = np.asarray(a, np.float64)
+  b = np.asarray(b, np.float64)
+  return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-12))
+
+
+def tol(dtype):
+  return 1e-3 if dtype == torch.float32 else 3e-2
+
+
+def to_dev(x, dtype):
+  return torch.from_numpy(np.ascontiguousarray(x)).to(DEV).to(dtype)
+
+
+def _mk_layer(kind, cin, cout, k, stride, padding, bias, seed, transpose=False):
+  store = nn.ParamStore()
+  layer = nn.ConvLayer(store, 'c', cin, cout, k, stride, padding, bias, kind, transpose=transpose)
+  store.finalize(DEV, torch.Generator().manual_seed(seed))
+  if bias:
+    store['c/bias'].copy_(torch.randn(cout, generator=torch.Generator().manual_seed(seed + 1)).to(DEV) * 0.1)
+  sg = nn.SpectralGroup([layer], torch.device(DEV))
+  return store, layer, sg
+
+
+CONV_CASES = [
+    # kind, cin, cout, k, stride, padding, pad, wrap, bias, mask, n, h, w
+    ('plain', 32, 64, 3, 1, 'VALID', 1, False, True, False, 2, 16, 32),
+    ('plain', 32, 64, 3, 1, 'VALID', 1, True, False, False, 1, 16, 32),
+    ('spectral', 64, 160, 3, 1, 'VALID', 1, False, True, False, 2, 8, 16),
+    ('spectral', 32, 32, 4, 2, 'VALID', 2, False, True, False, 2, 18, 34),
+    ('spectral', 64, 32, 1, 1, 'SAME', 0, False, True, False, 2, 9, 17),
+    ('partial', 5, 16, 7, 2, 'VALID', 3, False, True, True, 2, 32, 64),
+    ('partial_spectral', 32, 32, 3, 2, 'VALID', 1, False, True, True, 2, 16, 32),
+    ('partial_spectral', 32, 128, 1, 2, 'SAME', 0, False, False, True, 2, 16, 32),
+    ('partial_spectral', 48, 32, 1, 1, 'SAME', 0, False, False, False, 1, 8, 16),
+    ('plain', 4, 16, 4, 2, 'VALID', 2, False, True, False, 2, 32, 64),
+    ('plain', 64, 1, 4, 1, 'SAME', 0, False, True, False, 2, 10, 18),
+    ('plain', 8, 8, 3, 1, 'VALID', 1, False, False, False, 1, 12, 24),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_bwd(case, dtype):
+  kind, cin, cout, k, stride, padding, pad, wrap, bias, use_mask, n, h, w = case
+  store, layer, sg = _mk_layer(kind, cin, cout, k, stride, padding, bias, 7)
+  gen = torch.Generator().manual_seed(11)
+  x = torch.randn((n, h, w, cin), generator=gen)
+  mask = (torch.rand((n, h, w, 1), generator=gen) > 0.4).float() if use_mask else None
+  if dtype == torch.bfloat16:   # compare against the oracle on bf16-representable inputs
+    x = x.bfloat16().float()
+  # ---- oracle
+  p = {kk: v.detach().cpu().clone() for kk, v in store.views.items()}
+  if dtype == torch.bfloat16:
+    p['c/kernel'] = p['c/kernel'].bfloat16().float()
+  xo = x.clone().requires_grad_(True)
+  ko = p['c/kernel'].clone().requires_grad_(True)
+  p['c/kernel'] = ko
+  if bias:
+    p['c/bias'] = p['c/bias'].clone().requires_grad_(True)
+  net = O.Net(p, training=not wrap)
+  xin = O.pad_layer(xo, pad, circular_pad=wrap, training=not wrap) if pad else xo
+  if kind.startswith('partial'):
+    m_in = None
+    if mask is not None:
+      m_in = O.pad_layer(mask, pad, circular_pad=wrap, training=not wrap) if pad else mask
+    yo, umo = net.partial_conv(xin, m_in, 'c', stride, padding, spectral=kind == 'partial_spectral')
+  elif kind == 'spectral':
+    yo = net.spectral_conv(xin, 'c', stride, padding)
+  else:
+    yo = net.conv2d(xin, 'c', stride, padding)
+  gy = torch.randn(yo.shape, generator=gen)
+  if dtype == torch.bfloat16:
+    gy = gy.bfloat16().float()
+  yo.backward(gy)
+  # ---- HIP
+  ctx = nn.Ctx(DEV, dtype, training=not wrap, record=True)
+  if dtype == torch.bfloat16:
+    store.load_dict({'c/kernel': p['c/kernel'].detach().numpy()})
+  sg.power_iteration(training=False)
+  xv = nn.Var(to_dev(x.numpy(), dtype), requires_grad=True)
+  mdev = to_dev(mask.numpy()[..., 0], torch.float32) if mask is not None else None
+  res = nn.conv2d(ctx, xv, layer, pad=pad, wrap=wrap, mask=mdev)
+  if kind.startswith('partial'):
+    yv, um = res
+    np.testing.assert_array_equal(um.cpu().numpy(), umo.detach().numpy()[..., 0])
+  else:
+    yv = res
+  t = tol(dtype)
+  assert rel_err(yv.data.float().cpu().numpy(), yo.detach().numpy()) < t
+  yv.grad = to_dev(gy.numpy(), dtype)
+  ctx.backward()
+  sg.backward_fixup()
+  assert rel_err(xv.grad.float().cpu().numpy(), xo.grad.numpy()) < t
+  assert rel_err(store.grad_views['c/kernel'].cpu().numpy(), ko.grad.numpy()) < t
+  if bias:
+    assert rel_err(store.grad_views['c/bias'].cpu().numpy(), p['c/bias'].grad.numpy()) < t
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('k,cin,cout,bias', [(3, 64, 32, False), (2, 32, 32, False), (2, 32, 48, True),
+                                             (3, 8, 4, False), (2, 4, 4, True)])
+def test_conv_transpose_fwd_bwd(k, cin, cout, bias, dtype):
+  store, layer, _ = _mk_layer('plain', cin, cout, k, 2, 'SAME', bias, 21, transpose=True)
+  gen = torch.Generator().manual_seed(5)
+  n, h, w = 2, 6, 10
+  x = torch.randn((n, h, w, cin), generator=gen)
+  kern = store['c/kernel'].cpu().clone()
+  if dtype == torch.bfloat16:
+    x = x.bfloat16().float()
+    kern = kern.bfloat16().float()
+    store.load_dict({'c/kernel': kern.numpy()})
+  xo = x.clone().requires_grad_(True)
+  ko = kern.clone().requires_grad_(True)
+  bo = store['c/bias'].cpu().clone().requires_grad_(True) if bias else None
+  yo = O.keras_conv2d_transpose(xo, ko, bo, 2)
+  gy = torch.randn(yo.shape, generator=gen)
+  if dtype == torch.bfloat16:
+    gy = gy.bfloat16().float()
+  yo.backward(gy)
+  ctx = nn.Ctx(DEV, dtype, training=True, record=True)
+  xv = nn.Var(to_dev(x.numpy(), dtype), requires_grad=True)
+  yv = nn.conv_transpose2d(ctx, xv, layer)
+  t = tol(dtype)
+  assert tuple(yv.data.shape) == (n, 2 * h, 2 * w, cout)
+  assert rel_err(yv.data.float().cpu().numpy(), yo.detach().numpy()) < t
+  yv.grad = to_dev(gy.numpy(), dtype)
+  ctx.backward()
+  assert rel_err(xv.grad.float().cpu().numpy(), xo.grad.numpy()) < t
+  assert rel_err(store.grad_views['c/kernel'].cpu().numpy(), ko.grad.numpy()) < t
+  if bias:
+    assert rel_err(store.grad_views['c/bias'].cpu().numpy(), bo.grad.numpy()) < t
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('kind,c,act,with_res,training', [
+    ('batch', 32, nn.ACT_RELU, True, True), ('batch', 4, nn.ACT_NONE, False, True),
+    ('batch', 64, nn.ACT_LRELU, False, False), ('instance', 32, nn.ACT_LRELU, False, True),
+    ('instance', 6, nn.ACT_LRELU, False, True)])
+def test_norm_fwd_bwd(kind, c, act, with_res, training, dtype):
+  store = nn.ParamStore()
+  layer = nn.NormLayer(store, 'n', c, kind)
+  store.finalize(DEV, None)
+  gen = torch.Generator().manual_seed(3)
+  store.load_dict({'n/gamma': (torch.rand(c, generator=gen) + 0.5).numpy(),
+                   'n/beta': (torch.randn(c, generator=gen) * 0.2).numpy()})
+  if kind == 'batch':
+    store.load_dict({'n/moving_mean': (torch.randn(c, generator=gen) * 0.1).numpy(),
+                     'n/moving_variance': (torch.rand(c, generator=gen) + 0.5).numpy()})
+  n, h, w = 3, 9, 14
+  x = torch.randn((n, h, w, c), generator=gen) * 1.5 + 0.3
+  r = torch.randn((n, h, w, c), generator=gen)
+  gy = torch.randn((n, h, w, c), generator=gen)
+  if dtype == torch.bfloat16:
+    x, r, gy = x.bfloat16().float(), r.bfloat16().float(), gy.bfloat16().float()
+  alpha = 0.2
+  p = {k: v.cpu().clone() for k, v in store.views.items()}
+  p['n/gamma'].requires_grad_(True)
+  p['n/beta'].requires_grad_(True)
+  xo, ro = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+  net = O.Net(p, training=training)
+  yo = net.sync_bn(xo, 'n') if kind == 'batch' else net.instance_norm(xo, 'n')
+  if with_res:
+    yo = yo + ro
+  if act == nn.ACT_RELU:
+    yo = torch.relu(yo)
+  elif act == nn.ACT_LRELU:
+    yo = O.leaky_relu(yo, alpha)
+  yo.backward(gy)
+  ctx = nn.Ctx(DEV, dtype, training=training, record=True)
+  xv = nn.Var(to_dev(x.numpy(), dtype))
+  rv = nn.Var(to_dev(r.numpy(), dtype)) if with_res else None
+  yv = nn.norm_act(ctx, xv, layer, act=act, alpha=alpha, res=rv)
+  t = tol(dtype)
+  assert rel_err(yv.data.float().cpu().numpy(), yo.detach().numpy()) < t
+  if kind == 'batch' and training:
+    for nm in ('moving_mean', 'moving_variance'):
+      assert rel_err(store['n/' + nm].cpu().numpy(), net.updates['n/' + nm].numpy()) < 1e-5
+  yv.grad = to_dev(gy.numpy(), dtype)
+  ctx.backward()
+  assert rel_err(xv.grad.float().cpu().numpy(), xo.grad.numpy()) < 2 * t
+  assert rel_err(store.grad_views['n/gamma'].cpu().numpy(), p['n/gamma'].grad.numpy()) < 2 * t
+  assert rel_err(store.grad_views['n/beta'].cpu().numpy(), p['n/beta'].grad.numpy()) < 2 * t
+  if with_res:
+    assert rel_err(rv.grad.float().cpu().numpy(), ro.grad.numpy()) < t
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_pools_and_upsample(dtype):
+  gen = torch.Generator().manual_seed(9)
+  for (h, w) in ((8, 12), (9, 13)):
+    x = torch.randn((2, h, w, 8), generator=gen)
+    if dtype == torch.bfloat16:
+      x = x.bfloat16().float()
+    for name, fn_o, fn_g in (('max', O.max_pool_same, nn.maxpool2x2),
+                             ('avg', O.avg_pool3s2_same, nn.avgpool3s2),
+                             ('up', lambda t: t.repeat_interleave(2, 1).repeat_interleave(2, 2),
+                              nn.upsample2x)):
+      xo = x.clone().requires_grad_(True)
+      yo = fn_o(xo)
+      gy = torch.randn(yo.shape, generator=gen)
+      if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+      yo.backward(gy)
+      ctx = nn.Ctx(DEV, dtype, training=True, record=True)
+      xv = nn.Var(to_dev(x.numpy(), dtype))
+      yv = fn_g(ctx, xv)
+      assert rel_err(yv.data.float().cpu().numpy(), yo.detach().numpy()) < tol(dtype), name
+      yv.grad = to_dev(gy.numpy(), dtype)
+      ctx.backward()
+      assert rel_err(xv.grad.float().cpu().numpy(), xo.grad.numpy()) < tol(dtype), name
+
+
+def test_pad_layer_golden_on_gpu(golden_dir):
+  # models/layers_test.py:136-179 through the product PadLayer
+  g = np.load(os.path.join(golden_dir, 'reference_literals.npz'))
+  x = torch.from_numpy(g['pad_input']).reshape(1, 4, 4, 1).to(DEV)
+  out = layers.PadLayer(2, True)(x)
+  np.testing.assert_array_equal(out[0, :, :, 0].cpu().numpy(), g['pad_const_circ'])
+  out = layers.PadLayer(2, False)(x)
+  np.testing.assert_array_equal(out[0, :, :, 0].cpu().numpy(), g['pad_const_nocirc'])
+  out = layers.PadLayer(2, True, mode='SYMMETRIC')(x)
+  np.testing.assert_array_equal(out[0, :, :, 0].cpu().numpy(), g['pad_symm_circ'])
+  out = layers.PadLayer(2, True)(x, training=True)
+  np.testing.assert_array_equal(out[0, :, :, 0].cpu().numpy(), g['pad_const_nocirc'])
+
+
+def synth_batch(n, h, seed=1234):
+  """SURVEY 8d synthetic inputs."""
+  g = torch.Generator().manual_seed(seed)
+  w = 2 * h
+  image = torch.rand((n, h, w, 3), generator=g)
+  depth = torch.rand((n, h, w, 1), generator=g)
+  poison = torch.rand((n, h, w, 1), generator=g)
+  depth = torch.where(poison < 0.02, torch.zeros_like(depth), depth)
+  depth = torch.where(poison > 0.99, torch.ones_like(depth), depth)
+  pm = (torch.rand((n, h, w, 1), generator=g) < 0.5).float()
+  pm[:, h // 3:h // 3 + max(1, h // 8)] = 0
+  bm = torch.zeros((n, h, w, 1))
+  bm[:, :h // 8] = 1
+  bm[:, -(h // 8):] = 1
+  return dict(image=image, depth=depth, proj_mask=pm, proj_image=image * pm,
+              proj_depth=depth * pm, blurred_mask=bm)
+
+
+def _oracle_params(model):
+  return {k: v.detach().cpu().clone() for k, v in model.store.views.items()}
+
+
+@pytest.mark.parametrize('size,version,context,training', [
+    (64, '50', 'convs', True), (64, '50', 'convs', False), (128, '101', 'none', False)])
+def test_generator_forward_parity_fp32(size, version, context, training):
+  # image_models_test.py:28-75 shapes/ranges + values vs the oracle
+  gin_lite.clear_config()
+  G = image_models.ResNetGenerator(image_size=size, gen_dims=4, z_dim=4, resnet_version=version,
+                                   context_layer=context, device=DEV, seed=3, dtype=torch.float32)
+  batch = synth_batch(2, size)
+  p = _oracle_params(G)
+  outs_o, upd = O.generator_forward(p, batch, training, gen_dims=4, resnet_version=version,
+                                    context_layer=context, z_dim=4)
+  dbatch = {k: v.to(DEV) for k, v in batch.items()}
+  outs = G([dbatch, None], training=training)
+  assert len(outs) == 7
+  assert tuple(outs[3].shape) == (2, size, 2 * size, 1) and tuple(outs[6].shape) == (2, size, 2 * size, 3)
+  assert tuple(outs[4].shape) == (2, size, 2 * size, 42)
+  assert tuple(outs[0].shape) == (2, size // 32, size // 16, 4)
+  for i in (3, 6):
+    o = outs[i].cpu().numpy()
+    assert o.min() >= 0 and o.max() <= 1
+    assert rel_err(o, outs_o[i].detach().numpy()) < 1e-3, i
+  if training:   # BN moving statistics and spectral u advanced identically
+    for k, v in upd.items():
+      assert rel_err(G.store[k].cpu().numpy(), v.detach().numpy()) < 1e-3, k
+  with pytest.raises(ValueError):
+    G([dbatch, None], sample_noise=True)
+
+
+def test_generator_errors():
+  with pytest.raises(NotImplementedError):
+    image_models.ResNetGenerator(context_layer='attention', gen_dims=4, device=DEV)
+  with pytest.raises(ValueError):
+    image_models.ResNetGenerator(resnet_version='18', gen_dims=4, device=DEV)
+
+
+@pytest.mark.parametrize('n_layers,kernel', [(5, 4), (3, 3)])
+def test_discriminator_parity_fp32(n_layers, kernel):
+  # image_models_test.py:77-104 structure + values vs the oracle
+  D = image_models.SNMultiScaleDiscriminator(n_dis=2, dis_dims=4, n_layers=n_layers,
+                                             kernel_size=kernel, device=DEV, seed=5)
+  x = torch.rand((2, 64, 128, 4), generator=torch.Generator().manual_seed(1))
+  res_o, _ = O.discriminator_forward(_oracle_params(D), x, False, n_dis=2, n_layers=n_layers,
+                                     kernel_size=kernel)
+  res = D(x.to(DEV))
+  assert len(res) == 2
+  for sub, sub_o in zip(res, res_o):
+    assert len(sub) == n_layers + 1 and sub[-1].shape[-1] == 1
+    for a, b in zip(sub, sub_o):
+      assert tuple(a.shape) == tuple(b.shape)
+      assert rel_err(a.cpu().numpy(), b.detach().numpy()) < 1e-3
+
+
+def _cfg(gen_dims, version, n_layers):
+  return dict(gen=dict(gen_dims=gen_dims, resnet_version=version, context_layer='convs', z_dim=4),
+              dis=dict(n_dis=2, n_layers=n_layers, kernel_size=4),
+              lambda_gan=1.0, lambda_kld=10.0, lambda_wc=10.0, lambda_depth=100.0,
+              mask_blurred=True,
+              g_train=lambda k: not k.endswith(('/u', '/moving_mean', '/moving_variance')),
+              d_train=lambda k: not k.endswith('/u'))
+
+
+def _make_gan(size, gen_dims, version, n_layers, dtype=torch.float32):
+  from se3ds_amd.trainers import gan_manager, se3ds_trainer
+  gin_lite.clear_config()
+  gin_lite.parse_config(f'''
+image_models.ResNetGenerator.gen_dims = {gen_dims}
+image_models.ResNetGenerator.z_dim = 4
+image_models.ResNetGenerator.resnet_version = "{version}"
+image_models.SNMultiScaleDiscriminator.dis_dims = 4
+image_models.SNMultiScaleDiscriminator.n_dis = 2
+image_models.SNMultiScaleDiscriminator.n_layers = {n_layers}
+''')
+  gan = se3ds_trainer.GAN(
+      strategy=gan_manager.OneDeviceStrategy(DEV), model_dir='', lambda_gan=1.0, lambda_kld=10.0,
+      lambda_wc=10.0, lambda_depth=100.0, mask_blurred=True, predict_depth=True, image_size=size,
+      beta1=0.5, g_lr=1e-4, d_lr=4e-4, d_step_per_g_step=1, num_batched_steps=1,
+      generator_fn=image_models.ResNetGenerator,
+      discriminator_fn=image_models.SNMultiScaleDiscriminator, seed=0, compute_dtype=dtype)
+  gan._create_obj()
+  return gan
+
+
+def test_train_g_d_gradients_and_update_fp32():
+  """One full train_g_d at toy dims vs the oracle: clipped gradients of every G and D tensor,
+  Adam-updated weights, BN/SN state, EMA copy and the metric values."""
+  size = 64
+  gan = _make_gan(size, 4, '50', 3)
+  batch = synth_batch(2, size, seed=77)
+  gp, dp = _oracle_params(gan.generator), _oracle_params(gan.discriminator)
+  cfg = _cfg(4, '50', 3)
+  ref = O.train_g_d(gp, dp, batch, cfg)
+  # capture the clipped gradients before Adam consumes them
+  captured = {}
+  for opt, tag in ((gan.g_optimizer, 'g'), (gan.d_optimizer, 'd')):
+    orig = opt.apply_gradients
+    def wrap(group=None, world=1, _orig=orig, _opt=opt, _tag=tag):
+      captured[_tag] = {n: _opt.model.store.grad_views[n].detach().cpu().numpy().copy()
+                        for n in _opt.model.store.trainable_names}
+      return _orig(group, world)
+    opt.apply_gradients = wrap
+  gan.train_g_d({k: v.to(DEV) for k, v in batch.items()})
+  worst = {}
+  for tag, refg in (('g', ref['g_grads']), ('d', ref['d_grads'])):
+    assert set(refg) == set(captured[tag])
+    errs = {k: rel_err(captured[tag][k], refg[k].numpy()) for k in refg}
+    worst[tag] = max(errs.items(), key=lambda kv: kv[1])
+    # gradients whose oracle value is numerically zero are compared absolutely
+    for k, e in errs.items():
+      scale = float(np.abs(refg[k].numpy()).max())
+      if scale < 1e-7:
+        assert float(np.abs(captured[tag][k]).max()) < 1e-5, (tag, k)
+      else:
+        assert e < 1e-3, (tag, k, e, scale)
+  # Adam: one Keras step from zero slots
+  for k in list(ref['g_grads'])[:5] + list(ref['g_grads'])[-5:]:
+    newp, _, _ = O.adam_keras(gp[k], ref['g_grads'][k], torch.zeros_like(gp[k]),
+                              torch.zeros_like(gp[k]), 1e-4, 0.5, 0.999, 1)
+    assert rel_err(gan.generator.store[k].cpu().numpy(), newp.numpy()) < 1e-5, k
+  # BN moving stats / spectral u advanced exactly once
+  for k, v in ref['g_updates'].items():
+    assert rel_err(gan.generator.store[k].cpu().numpy(), v.detach().numpy()) < 1e-3, k
+  # EMA generator is a hard copy during the first cluster (gan_manager.py:642-655)
+  np.testing.assert_array_equal(gan.ema_generator.store.theta.cpu().numpy(),
+                                gan.generator.store.theta.cpu().numpy())
+  m = gan._save_metrics_to_dict()
+  for key in ('gen/gen_gan_loss', 'dis/disc_loss', 'gen/depth_loss', 'gen/wc_loss', 'gen/gen_loss',
+              'gen/grad_norm', 'dis/grad_norm'):
+    assert abs(float(m[key]) - ref['metrics'][key]) <= 2e-3 * max(1.0, abs(ref['metrics'][key])), key
+  assert set(m) >= {'gen/gen_feat_loss', 'gen/kld_nan', 'gen/seg_loss'}
+
+
+def test_train_d_only_updates_discriminator():
+  size = 64
+  gan = _make_gan(size, 4, '50', 3)
+  batch = synth_batch(2, size, seed=78)
+  gp, dp = _oracle_params(gan.generator), _oracle_params(gan.discriminator)
+  ref = O.train_d(gp, dp, batch, _cfg(4, '50', 3))
+  theta_g = gan.generator.store.theta.clone()
+  gan.train_d({k: v.to(DEV) for k, v in batch.items()})
+  assert torch.equal(theta_g, gan.generator.store.theta)
+  # G ran in training mode: BN moving statistics / u advanced (se3ds_trainer.py:292-293)
+  for k, v in ref['g_updates'].items():
+    assert rel_err(gan.generator.store[k].cpu().numpy(), v.detach().numpy()) < 1e-3, k
+  for k, g in list(ref['d_grads'].items()):
+    newp, _, _ = O.adam_keras(dp[k], g, torch.zeros_like(g), torch.zeros_like(g), 4e-4, 0.5, 0.999, 1)
+    assert rel_err(gan.discriminator.store[k].cpu().numpy(), newp.numpy()) < 1e-4, k
+
+
+def test_bf16_step_runs_and_tracks_fp32():
+  """bf16 compute path (the throughput configuration): runs, stays finite, and its losses
+  track the fp32 path on identical weights."""
+  size = 64
+  vals = {}
+  for dtype in (torch.float32, torch.bfloat16):
+    gan = _make_gan(size, 32, '50', 3, dtype)
+    batch = synth_batch(2, size, seed=79)
+    gan.train_g_d({k: v.to(DEV) for k, v in batch.items()})
+    m = gan._save_metrics_to_dict()
+    assert all(np.isfinite(float(v)) for v in m.values())
+    assert bool(torch.isfinite(gan.generator.store.theta).all())
+    vals[dtype] = m
+  for key in ('gen/gen_gan_loss', 'dis/disc_loss', 'gen/depth_loss', 'gen/wc_loss'):
+    a, b = float(vals[torch.float32][key]), float(vals[torch.bfloat16][key])
+    assert abs(a - b) <= 5e-2 * max(1.0, abs(a)), (key, a, b)
+
+
+def test_split_input_dict_and_cluster():
+  gan = _make_gan(64, 4, '50', 3)
+  gan.d_step_per_g_step = 2
+  batch = {k: v.to(DEV) for k, v in synth_batch(4, 64, seed=80).items()}
+  parts = gan._split_input_dict(batch, 2)
+  assert len(parts) == 2 and parts[0]['image'].shape[0] == 2
+  assert torch.equal(parts[1]['depth'], batch['depth'][2:])
+  gan.train_ds = iter([batch])
+  gan.train_cluster(1)
+  assert gan.d_optimizer.iterations == 2 and gan.g_optimizer.iterations == 1
