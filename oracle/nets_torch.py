@@ -88,8 +88,8 @@ def tf_conv2d(x, kernel, stride, padding):
     pt, pb = _same_pads(x.shape[1], k, stride)
     pl, pr = _same_pads(x.shape[2], kernel.shape[1], stride)
     xn = F.pad(xn, (pl, pr, pt, pb))
-  w = kernel.permute(3, 2, 0, 1)
-  return _nhwc(F.conv2d(xn, w, stride=stride))
+  w = kernel.permute(3, 2, 0, 1).contiguous()
+  return _nhwc(F.conv2d(xn.contiguous(), w, stride=stride))
 
 
 def keras_conv2d_transpose(x, kernel, bias, stride):
@@ -98,8 +98,8 @@ def keras_conv2d_transpose(x, kernel, bias, stride):
   top/left padding is 0 for these shapes."""
   assert stride == 2
   n, h, w, _ = x.shape
-  wt = kernel.permute(3, 2, 0, 1)  # (cin, cout, kh, kw)
-  y = F.conv_transpose2d(_nchw(x), wt, stride=stride)
+  wt = kernel.permute(3, 2, 0, 1).contiguous()  # (cin, cout, kh, kw)
+  y = F.conv_transpose2d(_nchw(x).contiguous(), wt, stride=stride)
   y = _nhwc(y)[:, :2 * h, :2 * w, :]
   if bias is not None:
     y = y + bias
@@ -125,9 +125,11 @@ def leaky_relu(x, alpha):
 class Net:
   """Parameter access + side-effect bookkeeping (BN moving stats, spectral u)."""
 
-  def __init__(self, params, training, stats_hook=None):
+  def __init__(self, params, training, stats_hook=None, bn_training=None):
     self.p = params
     self.training = training
+    # test hook: decouple BN statistics mode from the padding / spectral-u training flag
+    self.bn_training = training if bn_training is None else bn_training
     self.updates = {}          # name -> new value of non-trainable variables
     self.stats_hook = stats_hook
 
@@ -140,7 +142,7 @@ class Net:
   # -- layers -----------------------------------------------------------------------------
   def sync_bn(self, x, name):
     g, b = self.get(name + '/gamma'), self.get(name + '/beta')
-    if self.training:
+    if self.bn_training:
       cnt = x.shape[0] * x.shape[1] * x.shape[2]
       s1 = x.sum(dim=(0, 1, 2))
       s2 = (x * x).sum(dim=(0, 1, 2))
@@ -348,9 +350,10 @@ def head(net, x, name, spectral):
 
 
 def generator_forward(params, cond, training, gen_dims, resnet_version='50', context_layer='convs',
-                      conv_mode='spectral', use_blurred_mask=True, z_dim=128, stats_hook=None):
+                      conv_mode='spectral', use_blurred_mask=True, z_dim=128, stats_hook=None,
+                      taps=None, bn_training=None):
   """image_models.py:132-193.  Returns (outputs list, net.updates)."""
-  net = Net(params, training, stats_hook)
+  net = Net(params, training, stats_hook, bn_training)
   spectral = conv_mode == 'spectral'
   d = gen_dims
   parts = [cond['proj_image'], cond['proj_depth']]
@@ -358,6 +361,8 @@ def generator_forward(params, cond, training, gen_dims, resnet_version='50', con
     parts.append(cond['blurred_mask'])
   x = torch.cat(parts, dim=-1)
   hidden, skip = encoder(net, x, cond['proj_mask'], d, resnet_version, spectral)
+  if taps is not None:
+    taps.update(b1=skip[0], s1=skip[1], s2=skip[2], s3=skip[3], enc=hidden)
   if context_layer == 'convs':
     for i in range(4):
       hidden = net.sync_bn(hidden, f'context/bn{i}')
@@ -367,6 +372,8 @@ def generator_forward(params, cond, training, gen_dims, resnet_version='50', con
   n, hh, hw, _ = hidden.shape
   out = decoder(net, hidden, skip, d, resnet_version, spectral, 'decoder')
   depth_out = decoder(net, hidden, skip, d, resnet_version, spectral, 'depth_decoder')
+  if taps is not None:
+    taps.update(ctx=hidden, dec=out, ddec=depth_out)
   rgb = head(net, out, 'rgb_conv', spectral)
   depth = head(net, depth_out, 'depth_conv', spectral)
   rgb = (torch.tanh(rgb) + 1) / 2

@@ -654,7 +654,9 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   if (n <= 0 || h <= 0 || wdt <= 0 || cin <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || kh <= 0 ||
       kw <= 0 || stride <= 0 || stride > 2)
     return SE3DS_E_BADSHAPE;
-  if (wrap_w && (stride != 1 || wo != wdt)) return SE3DS_E_UNSUPPORTED;
+  // circular W padding: any stride for the forward gather; the transposed gather only for the
+  // stride-1 'same width' case (inference-mode backward through strided convs is not needed)
+  if (wrap_w && mode == MODE_DGRAD && (stride != 1 || wo != wdt)) return SE3DS_E_UNSUPPORTED;
   if (dtype != SE3DS_F32 && dtype != SE3DS_BF16) return SE3DS_E_BADDTYPE;
   IgemmParams p;
   p.src = src; p.w = w; p.out = out;

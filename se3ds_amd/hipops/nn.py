@@ -519,7 +519,7 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
   r = h * w if inst else n * h * w
   eps = IN_EPS if inst else BN_EPS
   gamma, beta = st[layer.name + '/gamma'], st[layer.name + '/beta']
-  use_moving = (not inst) and (not ctx.training)
+  use_moving = (not inst) and (not ctx.training or getattr(ctx, 'bn_use_moving', False))
   scale = torch.empty((g, c), dtype=torch.float32, device=ctx.device)
   shift = torch.empty_like(scale)
   mean = torch.empty_like(scale)
@@ -562,6 +562,14 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
       dres = ctx.empty(xd.shape) if want_res else None
       dx = ctx.empty(xd.shape)
       if use_moving:
+        if ctx.param_grads:
+          bs = torch.empty((g, 2, c), dtype=torch.float32, device=ctx.device)
+          _chk(L.se3ds_norm_bwd_stats(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r,
+                                      c, mean.data_ptr(), rstd.data_ptr(), act, float(alpha),
+                                      bs.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+               'se3ds_norm_bwd_stats')
+          st.grad_views[layer.name + '/beta'].copy_(bs[0, 0])
+          st.grad_views[layer.name + '/gamma'].copy_(bs[0, 1])
         _chk(L.se3ds_affine_bwd(dy.data_ptr(), y.data_ptr(), ctx.code, g, r, c, scale.data_ptr(),
                                 act, float(alpha), dx.data_ptr(), _lib.ptr(dres), _lib.stream()),
              'se3ds_affine_bwd')

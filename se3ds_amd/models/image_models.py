@@ -258,6 +258,9 @@ class ResNetGenerator(_Model):
     mask = gm.to(torch.float32).reshape(n, h, w).contiguous()
     self.spectral.power_iteration(ctx.training)
     hidden, skip = self.encoder(ctx, x, mask)
+    taps = getattr(ctx, 'taps', None)
+    if taps is not None:
+      taps.update(b1=skip[0], s1=skip[1], s2=skip[2], s3=skip[3], enc=hidden)
     if self.context_layer == 'convs':
       for i in range(4):
         hidden = self.ctx_bn[i](ctx, hidden)
@@ -266,6 +269,8 @@ class ResNetGenerator(_Model):
     hh, hw = hidden.shape[1], hidden.shape[2]
     out = self.decoder(ctx, hidden, skip)
     depth_out = self.depth_decoder(ctx, hidden, skip)
+    if taps is not None:
+      taps.update(ctx=hidden, dec=out, ddec=depth_out)
     rgb_pre = self.rgb_conv(ctx, out)
     depth_pre = self.depth_conv(ctx, depth_out)
     rgb, push_rgb = nn.head(ctx, rgb_pre, 0)
