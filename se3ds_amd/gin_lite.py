@@ -112,9 +112,21 @@ def _parse_value(text):
 
 def parse_config(config: str):
   """Parses bindings from a string (one `selector.param = value` per logical line)."""
+  def strip_comment(raw):
+    quote = None
+    for i, ch in enumerate(raw):
+      if quote:
+        if ch == quote:
+          quote = None
+      elif ch in '\'"':
+        quote = ch
+      elif ch == '#':
+        return raw[:i]
+    return raw
+
   pending = ''
   for raw in config.splitlines():
-    line = raw.split('#', 1)[0].rstrip() if "'" not in raw and '"' not in raw else raw
+    line = strip_comment(raw).rstrip()
     if not line.strip():
       continue
     pending += line
@@ -129,8 +141,6 @@ def parse_config(config: str):
       lhs = lhs.split('/')[-1]   # drop scopes
     selector, param = lhs.rsplit('.', 1)
     rhs = rhs.strip()
-    if '#' in rhs and not (rhs.startswith("'") or rhs.startswith('"')):
-      rhs = rhs.split('#', 1)[0].strip()
     _BINDINGS.setdefault(selector, {})[param] = _parse_value(rhs)
 
 

@@ -37,9 +37,9 @@ class ParamStore:
     self._specs = []   # (name, shape, init, trainable)
     self.theta = None
     self.state = None
-    self.grad = None
+    self._grad = None
     self.views = {}
-    self.grad_views = {}
+    self.grad_views = _LazyGradViews(self)
     self.offsets = {}
     self.trainable_names = []
     self.state_names = []
@@ -63,18 +63,20 @@ class ParamStore:
       return off, offs
     n_tr, off_tr = pack(tr)
     n_st, off_st = pack(st)
-    host_tr = torch.zeros(max(n_tr, 4), dtype=torch.float32)
-    host_st = torch.zeros(max(n_st, 4), dtype=torch.float32)
+    # Initial values are drawn where the generator lives: a CPU generator (default, bit-stable
+    # across machines) or a device generator (1.1 B parameters in seconds instead of minutes).
+    init_dev = generator.device if generator is not None else torch.device('cpu')
+    host_tr = torch.zeros(max(n_tr, 4), dtype=torch.float32, device=init_dev)
+    host_st = torch.zeros(max(n_st, 4), dtype=torch.float32, device=init_dev)
     for specs, host, offs in ((tr, host_tr, off_tr), (st, host_st, off_st)):
       for name, shape, init, _ in specs:
         o, n, _ = offs[name]
         host[o:o + n] = init(shape, generator).reshape(-1)
     self.theta = host_tr.to(device)
     self.state = host_st.to(device)
-    self.grad = torch.zeros_like(self.theta)
+    self._grad = None
     for name, (o, n, shape) in off_tr.items():
       self.views[name] = self.theta[o:o + n].view(shape)
-      self.grad_views[name] = self.grad[o:o + n].view(shape)
       self.offsets[name] = ('theta', o, n)
     for name, (o, n, shape) in off_st.items():
       self.views[name] = self.state[o:o + n].view(shape)
@@ -86,6 +88,15 @@ class ParamStore:
 
   def __getitem__(self, name):
     return self.views[name]
+
+  @property
+  def grad(self):
+    """Gradient arena, allocated on first use (the EMA generator never needs one)."""
+    if self._grad is None:
+      self._grad = torch.zeros_like(self.theta)
+      for name, (o, n, shape) in self._off_tr.items():
+        self.grad_views[name] = self._grad[o:o + n].view(shape)
+    return self._grad
 
   def load_dict(self, d):
     """Overwrite parameters from {name: array-like} (tests inject identical weights)."""
@@ -110,29 +121,46 @@ class ParamStore:
             torch.tensor(starts, dtype=torch.int64, device=dev))
 
 
+class _LazyGradViews(dict):
+  """name -> view into the gradient arena; touching it allocates the arena."""
+
+  def __init__(self, store):
+    super().__init__()
+    self._store = store
+
+  def __missing__(self, name):
+    self._store.grad  # allocates and fills every view
+    return dict.__getitem__(self, name)
+
+
+def _gdev(gen):
+  return gen.device if gen is not None else torch.device('cpu')
+
+
 def glorot_uniform(shape, gen):
   rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
   fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
   limit = math.sqrt(6.0 / (fan_in + fan_out))
-  return (torch.rand(shape, generator=gen, dtype=torch.float32) * 2 - 1) * limit
+  return (torch.rand(shape, generator=gen, dtype=torch.float32, device=_gdev(gen)) * 2 - 1) * limit
 
 
 def zeros_init(shape, gen):
-  return torch.zeros(shape, dtype=torch.float32)
+  return torch.zeros(shape, dtype=torch.float32, device=_gdev(gen))
 
 
 def ones_init(shape, gen):
-  return torch.ones(shape, dtype=torch.float32)
+  return torch.ones(shape, dtype=torch.float32, device=_gdev(gen))
 
 
 def truncated_normal_init(shape, gen, std=0.05):
   # tf.initializers.TruncatedNormal(): N(0, 0.05) redrawn outside 2 sigma
-  t = torch.randn(shape, generator=gen, dtype=torch.float32)
+  dev = _gdev(gen)
+  t = torch.randn(shape, generator=gen, dtype=torch.float32, device=dev)
   for _ in range(8):
     bad = t.abs() > 2
     if not bool(bad.any()):
       break
-    t = torch.where(bad, torch.randn(shape, generator=gen, dtype=torch.float32), t)
+    t = torch.where(bad, torch.randn(shape, generator=gen, dtype=torch.float32, device=dev), t)
   return t.clamp(-2, 2) * std
 
 
@@ -192,6 +220,61 @@ class Ctx:
 
 
 _WS = {}
+
+
+class ConvProfiler:
+  """HIP-event timing of every convolution launch (bench.py roofline leg).  Events are
+  recorded on the stream the kernels are launched on (torch's current stream)."""
+
+  def __init__(self):
+    self.records = []   # (kind, flops, start_event, end_event)
+
+  def start(self):
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+  def stop(self, kind, flops, e0):
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    self.records.append((kind, flops, e0, e1))
+
+  def summary(self):
+    torch.cuda.synchronize()
+    tot_ms = tot_fl = 0.0
+    by = {}
+    for kind, fl, e0, e1 in self.records:
+      ms = e0.elapsed_time(e1)
+      tot_ms += ms
+      tot_fl += fl
+      b = by.setdefault(kind, [0.0, 0.0, 0])
+      b[0] += ms; b[1] += fl; b[2] += 1
+    return dict(ms=tot_ms, flops=tot_fl, launches=len(self.records),
+                by_kind={k: dict(ms=v[0], tflop=v[1] / 1e12, launches=v[2],
+                                 tflops=(v[1] / (v[0] * 1e-3) / 1e12) if v[0] > 0 else 0.0)
+                         for k, v in by.items()})
+
+
+_PROF = None
+
+
+def set_conv_profiler(p):
+  global _PROF
+  _PROF = p
+
+
+class _Timed:
+  """with _Timed(kind, flops): launch  -- no-op unless a profiler is installed."""
+
+  def __init__(self, kind, flops):
+    self.kind, self.flops = kind, flops
+
+  def __enter__(self):
+    self.e0 = _PROF.start() if _PROF is not None else None
+
+  def __exit__(self, *a):
+    if _PROF is not None and self.e0 is not None:
+      _PROF.stop(self.kind, self.flops, self.e0)
 
 
 def _global_ws(device, key, nbytes):
@@ -328,14 +411,28 @@ class SpectralGroup:
       l.sn = dict(v=torch.zeros(K, device=device), uhat=torch.zeros(co, device=device),
                   sig=torch.ones(2, device=device), part=torch.zeros(pr * co, device=device),
                   vpart=torch.zeros(vl, device=device))
-      g = l.store.grad_views[l.name + '/kernel']
       rows.append([w.data_ptr(), l.store[l.name + '/u'].data_ptr(), l.sn['v'].data_ptr(),
                    l.sn['uhat'].data_ptr(), l.sn['sig'].data_ptr(), l.sn['part'].data_ptr(),
-                   l.sn['vpart'].data_ptr(), K, co, g.data_ptr()])
+                   l.sn['vpart'].data_ptr(), K, co, 0])
       assert len(rows[-1]) == nf
+    self._rows = rows
     self.table = torch.tensor(rows, dtype=torch.int64, device=device) if rows else None
-    eff = [i for i, l in enumerate(self.layers) if l.kind == 'spectral']
-    self.eff_table = self.table[eff].contiguous() if eff else None
+    self._eff = [i for i, l in enumerate(self.layers) if l.kind == 'spectral']
+    self._eff_table = None
+
+  @property
+  def eff_table(self):
+    """Rows of the effective SpectralConv layers with their gradient pointers (built on first
+    use: touching the gradient views allocates the gradient arena)."""
+    if self._eff_table is None and self._eff:
+      rows = []
+      for i in self._eff:
+        l = self.layers[i]
+        r = list(self._rows[i])
+        r[9] = l.store.grad_views[l.name + '/kernel'].data_ptr()
+        rows.append(r)
+      self._eff_table = torch.tensor(rows, dtype=torch.int64, device=self.table.device)
+    return self._eff_table
 
   def power_iteration(self, training):
     if self.table is not None:
@@ -403,11 +500,13 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
   scale = layer.sn['sig'][1:] if layer.kind == 'spectral' else None
   bias = layer.bias
   y = ctx.empty((n, ho, wo, layer.cout))
-  _chk(L.se3ds_conv2d_fwd(xd.data_ptr(), wt.data_ptr(), y.data_ptr(), ctx.code, n, h, w, cin, ho,
-                          wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0, _lib.ptr(in_mask),
-                          _lib.ptr(scale), _lib.ptr(bias), _lib.ptr(ratio),
-                          _lib.ptr(um if (partial and bias is not None) else None), act,
-                          float(alpha), _lib.stream()), 'se3ds_conv2d_fwd')
+  flops = 2.0 * n * ho * wo * cin * layer.cout * k * k
+  with _Timed('fwd', flops):
+    _chk(L.se3ds_conv2d_fwd(xd.data_ptr(), wt.data_ptr(), y.data_ptr(), ctx.code, n, h, w, cin,
+                            ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
+                            _lib.ptr(in_mask), _lib.ptr(scale), _lib.ptr(bias), _lib.ptr(ratio),
+                            _lib.ptr(um if (partial and bias is not None) else None), act,
+                            float(alpha), _lib.stream()), 'se3ds_conv2d_fwd')
   out = Var(y)
   if recording:
     def bwd():
@@ -431,16 +530,20 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
         wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, layer.cout, k, k)
         ws = _global_ws(ctx.device, 'wgrad', wsz)
         gk = st.grad_views[layer.name + '/kernel']
-        _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dy.data_ptr(), gk.data_ptr(), ctx.code, n, h, w,
-                                  cin, ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
-                                  _lib.ptr(in_mask), _lib.ptr(row_scale), None, 0, ws.data_ptr(),
-                                  ws.numel(), _lib.stream()), 'se3ds_conv2d_wgrad')
+        with _Timed('wgrad', flops):
+          _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dy.data_ptr(), gk.data_ptr(), ctx.code, n, h,
+                                    w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
+                                    1 if wrap else 0, _lib.ptr(in_mask), _lib.ptr(row_scale),
+                                    None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
+               'se3ds_conv2d_wgrad')
       if x.requires_grad:
         dx = ctx.empty(xd.shape)
-        _chk(L.se3ds_conv2d_dgrad(dy.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h, w,
-                                  cin, ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
-                                  _lib.ptr(row_scale), _lib.ptr(scale), None, _lib.ptr(in_mask),
-                                  ACT_NONE, 0.0, _lib.stream()), 'se3ds_conv2d_dgrad')
+        with _Timed('dgrad', flops):
+          _chk(L.se3ds_conv2d_dgrad(dy.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h,
+                                    w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
+                                    1 if wrap else 0, _lib.ptr(row_scale), _lib.ptr(scale), None,
+                                    _lib.ptr(in_mask), ACT_NONE, 0.0, _lib.stream()),
+               'se3ds_conv2d_dgrad')
         accumulate(x, dx)
     ctx.record(bwd)
   if partial:
@@ -461,10 +564,12 @@ def conv_transpose2d(ctx: Ctx, x: Var, layer: ConvLayer):
   wt, wn = layer.operands(ctx)   # kernel (k,k,cout_T,cin_T) == HWIO of the associated conv
   y = ctx.empty((n, H, W, layer.cout))
   bias = layer.bias
-  _chk(L.se3ds_conv2d_dgrad(xd.data_ptr(), wn.data_ptr(), y.data_ptr(), ctx.code, n, H, W,
-                            layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None,
-                            _lib.ptr(bias), None, ACT_NONE, 0.0, _lib.stream()),
-       'se3ds_conv2d_dgrad')
+  flops = 2.0 * n * hi * wi * cin_t * layer.cout * k * k
+  with _Timed('convT_fwd', flops):
+    _chk(L.se3ds_conv2d_dgrad(xd.data_ptr(), wn.data_ptr(), y.data_ptr(), ctx.code, n, H, W,
+                              layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None,
+                              _lib.ptr(bias), None, ACT_NONE, 0.0, _lib.stream()),
+         'se3ds_conv2d_dgrad')
   out = Var(y)
   if ctx.tape is not None:
     def bwd():
@@ -480,14 +585,17 @@ def conv_transpose2d(ctx: Ctx, x: Var, layer: ConvLayer):
         wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, hi, wi, layer.cout, cin_t, k, k)
         ws = _global_ws(ctx.device, 'wgrad', wsz)
         gk = st.grad_views[layer.name + '/kernel']
-        _chk(L.se3ds_conv2d_wgrad(dy.data_ptr(), xd.data_ptr(), gk.data_ptr(), ctx.code, n, H, W,
-                                  layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None, None, 0,
-                                  ws.data_ptr(), ws.numel(), _lib.stream()), 'se3ds_conv2d_wgrad')
+        with _Timed('convT_wgrad', flops):
+          _chk(L.se3ds_conv2d_wgrad(dy.data_ptr(), xd.data_ptr(), gk.data_ptr(), ctx.code, n, H, W,
+                                    layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None, None,
+                                    0, ws.data_ptr(), ws.numel(), _lib.stream()),
+               'se3ds_conv2d_wgrad')
       if x.requires_grad:
         dx = ctx.empty(xd.shape)
-        _chk(L.se3ds_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), ctx.code, n, H, W,
-                                layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None, None,
-                                None, None, ACT_NONE, 0.0, _lib.stream()), 'se3ds_conv2d_fwd')
+        with _Timed('convT_dgrad', flops):
+          _chk(L.se3ds_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), ctx.code, n, H, W,
+                                  layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None, None,
+                                  None, None, ACT_NONE, 0.0, _lib.stream()), 'se3ds_conv2d_fwd')
         accumulate(x, dx)
     ctx.record(bwd)
   return out

@@ -38,7 +38,11 @@ class _Model:
   """Shared plumbing: parameter store, device placement, spectral-norm group, contexts."""
 
   def _finish(self, device, seed, dtype):
-    gen = torch.Generator().manual_seed(seed) if seed is not None else None
+    # seed < 0: draw the initial values on the device (fast path for the 1.1 B-parameter model)
+    if seed is not None and seed < 0:
+      gen = torch.Generator(device=device).manual_seed(-seed)
+    else:
+      gen = torch.Generator().manual_seed(seed) if seed is not None else None
     self.store.finalize(device, gen)
     self.device = torch.device(device)
     self.dtype = dtype

@@ -165,12 +165,13 @@ class GANManager(abc.ABC):
     """Creates Generator, Discriminator and EMA Generator (reference :169-173)."""
     dev = self.strategy.device
     kw = dict(device=dev, dtype=self.compute_dtype)
-    self.generator = self.generator_fn(image_size=self.image_size, seed=1000 + max(self.seed, 0),
-                                       **kw)
+    sgn = -1 if getattr(self, 'device_init', False) else 1   # negative seed: on-device init
+    self.generator = self.generator_fn(image_size=self.image_size,
+                                       seed=sgn * (1000 + max(self.seed, 0)), **kw)
     self.discriminator = self.discriminator_fn(image_size=self.image_size,
-                                               seed=2000 + max(self.seed, 0), **kw)
+                                               seed=sgn * (2000 + max(self.seed, 0)), **kw)
     self.ema_generator = self.generator_fn(image_size=self.image_size,
-                                           seed=3000 + max(self.seed, 0), **kw)
+                                           seed=sgn * (3000 + max(self.seed, 0)), **kw)
 
   def _build_optimizer(self):
     """Creates optimizers for both Generator and Discriminator (reference :175-183)."""
