@@ -19,6 +19,8 @@
 // gather; the partial-conv renormalisation, spectral 1/sigma scale, bias and activation are
 // the epilogue.  The weight operand is the MFMA "A" side so each lane ends up holding 4
 // consecutive output channels of one pixel (8/16-byte stores).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace se3ds {
@@ -118,6 +120,66 @@ struct RowInfo {
   bool valid;
 };
 
+// Epilogue shared by the two implicit-GEMM kernels.
+// acc[i][j][r]: channel = n0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*half, pixel row = wn*64 + j*32 + l32
+template <typename T, int MODE>
+__device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)[2][2], int tile_m,
+                                           int n0, int64_t Mc, int cH, int cW, int py, int px,
+                                           int wm, int wn, int half, int l32) {
+  using tt = TT<T>;
+  const int s = p.stride;
+  const float scale = p.scale ? *p.scale : 1.0f;
+  T* __restrict__ out = (T*)p.out;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int64_t m = (int64_t)tile_m * BM + wn * 64 + j * 32 + l32;
+    if (m >= Mc) continue;
+    int n = (int)(m / ((int64_t)cH * cW));
+    int rem = (int)(m - (int64_t)n * cH * cW);
+    int a = rem / cW, b = rem - a * cW;
+    if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
+    const int64_t opix = ((int64_t)n * p.oH + a) * p.oW + b;
+    const float ra = p.row_a ? p.row_a[opix] : 1.0f;
+    const float rb = p.row_b ? p.row_b[opix] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = n0 + wm * 64 + i * 32 + g * 8 + half * 4;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[i][j][g * 4 + e] * scale;
+          const float bv = (p.bias && co + e < p.oC) ? p.bias[co + e] : 0.0f;
+          if (p.row_a) {
+            if (p.bias) t = ((t - bv) * ra + bv) * rb;
+            else t = t * ra;
+          } else if (p.bias) {
+            t = t + bv;
+          }
+          if (p.act == 1) t = t > 0.f ? t : 0.f;
+          else if (p.act == 2) t = t > 0.f ? t : t * p.act_alpha;
+          v[e] = t;
+        }
+        T* o = out + opix * p.oC + co;
+        if (co + 3 < p.oC && (p.oC & 3) == 0) {
+          if (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(o) = pk;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.oC) o[e] = tt::from_f(v[e]);
+        }
+      }
+  }
+}
+
 template <typename T, int MODE>
 __global__ void __launch_bounds__(kThreads, 2)
 igemm_kernel(const IgemmParams p) {
@@ -197,21 +259,44 @@ igemm_kernel(const IgemmParams p) {
 
   uint4 rx[2], rw[2];  // staged chunks: X rows (srow, srow+64), W rows (srow, srow+64)
 
+  // Vector path state: everything that depends on the tap (source pixel of each staging row,
+  // its mask value, the weight row) is decoded ONCE per tap; the inner channel loop only
+  // advances an element offset, so a K step costs a handful of VALU instructions.
+  const T* xptr[2] = {nullptr, nullptr};
+  const T* wptr[2] = {nullptr, nullptr};
+  float xmk[2] = {1.0f, 1.0f};
+  int tap_i = 0, cstep = 0;
+  auto setup_tap = [&](int t) {
+    const int ky = ky0 + kstep * (t / nkx), kx = kx0 + kstep * (t % nkx);
+    const int tap_lin = ky * p.kw + kx;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int64_t pix;
+      xptr[h] = nullptr;
+      if (ri[h].valid && src_pixel(ri[h], ky, kx, pix)) {
+        xptr[h] = src + pix * Cr + chunk * EPC;
+        if (p.src_mask) xmk[h] = p.src_mask[pix];
+      }
+      const int co = n0 + srow + h * 64;
+      wptr[h] = co < p.oC ? wp + (int64_t)tap_lin * p.w_tap + (int64_t)co * p.w_n + chunk * EPC
+                          : nullptr;
+    }
+  };
+  if (p.vec && ntaps > 0) setup_tap(0);
+
   auto load_step = [&](int kstep_i) {
     if (p.vec) {
-      int tap = kstep_i / ksteps_per_tap;
-      int c0 = (kstep_i - tap * ksteps_per_tap) * BK + chunk * EPC;
-      int ky = ky0 + kstep * (tap / nkx), kx = kx0 + kstep * (tap % nkx);
-      int tap_lin = ky * p.kw + kx;
+      const int c_off = cstep * BK;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        int64_t pix;
-        if (ri[h].valid && src_pixel(ri[h], ky, kx, pix)) {
-          v = *reinterpret_cast<const uint4*>(src + pix * Cr + c0);
-          if (p.src_mask) {
-            float mk = p.src_mask[pix];
-            if (sizeof(T) == 4) {
+        if (xptr[h]) {
+          v = *reinterpret_cast<const uint4*>(xptr[h] + c_off);
+          if (p.src_mask && xmk[h] != 1.0f) {
+            const float mk = xmk[h];
+            if (mk == 0.0f) {
+              v = make_uint4(0, 0, 0, 0);
+            } else if (sizeof(T) == 4) {
               v.x = __float_as_uint(__uint_as_float(v.x) * mk);
               v.y = __float_as_uint(__uint_as_float(v.y) * mk);
               v.z = __float_as_uint(__uint_as_float(v.z) * mk);
@@ -228,12 +313,11 @@ igemm_kernel(const IgemmParams p) {
           }
         }
         rx[h] = v;
-        uint4 wv = make_uint4(0, 0, 0, 0);
-        int co = n0 + srow + h * 64;
-        if (co < p.oC)
-          wv = *reinterpret_cast<const uint4*>(wp + (int64_t)tap_lin * p.w_tap +
-                                               (int64_t)co * p.w_n + c0);
-        rw[h] = wv;
+        rw[h] = wptr[h] ? *reinterpret_cast<const uint4*>(wptr[h] + c_off) : make_uint4(0, 0, 0, 0);
+      }
+      if (++cstep == ksteps_per_tap) {
+        cstep = 0;
+        if (++tap_i < ntaps) setup_tap(tap_i);
       }
     } else {
       // generic gather: K is the linear (tap, channel) index, decoded per element
@@ -312,58 +396,180 @@ igemm_kernel(const IgemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue.  acc[i][j][r]: channel = n0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*half,
-  //                               pixel row = wn*64 + j*32 + l32
-  const float scale = p.scale ? *p.scale : 1.0f;
-  T* __restrict__ out = (T*)p.out;
+  store_tile<T, MODE>(p, acc, tile_m, n0, Mc, cH, cW, py, px, wm, wn, half, l32);
+}
+
+// ------------------------------------------------------------------ LDS-DMA implicit GEMM
+// Same tiling, but operand tiles go HBM -> LDS directly (global_load_lds, 16 B per lane), rows
+// are full 128-byte lines (K step = 64 bf16 / 32 fp32) and no staging registers or ds_write
+// pass exist.  The LDS image is lane-linear per wave instruction (8 rows x 8 chunks = 1 KiB),
+// so the bank-conflict swizzle is applied to the SOURCE chunk each lane fetches and to the
+// fragment read address (chunk ^= (row >> 1) & 7).  Rows that fall in the zero padding read a
+// 128-byte zero page.  Used whenever the reduction channels are a multiple of the K step and
+// no gather-side mask is needed (decoder, heads, discriminator: ~88 % of the step's FLOPs).
+__device__ __attribute__((aligned(128))) unsigned char g_zero_page[128];
+
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(kThreads, 2)
+igemm_glds_kernel(const IgemmParams p) {
+  using tt = TT<T>;
+  constexpr int EPC = tt::EPC, BK2 = 2 * tt::BK;
+  constexpr int ROW2 = 128, TILE2 = 128 * ROW2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE2];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int cls = 0;
+  if (MODE == MODE_DGRAD) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    int64_t m = (int64_t)tile_m * BM + wn * 64 + j * 32 + l32;
-    if (m >= Mc) continue;
-    int n = (int)(m / ((int64_t)cH * cW));
-    int rem = (int)(m - (int64_t)n * cH * cW);
-    int a = rem / cW, b = rem - a * cW;
-    if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
-    const int64_t opix = ((int64_t)n * p.oH + a) * p.oW + b;
-    const float ra = p.row_a ? p.row_a[opix] : 1.0f;
-    const float rb = p.row_b ? p.row_b[opix] : 1.0f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = n0 + wm * 64 + i * 32 + g * 8 + half * 4;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = acc[i][j][g * 4 + e] * scale;
-          const float bv = (p.bias && co + e < p.oC) ? p.bias[co + e] : 0.0f;
-          if (p.row_a) {
-            if (p.bias) t = ((t - bv) * ra + bv) * rb;
-            else t = t * ra;
-          } else if (p.bias) {
-            t = t + bv;
-          }
-          if (p.act == 1) t = t > 0.f ? t : 0.f;
-          else if (p.act == 2) t = t > 0.f ? t : t * p.act_alpha;
-          v[e] = t;
-        }
-        T* o = out + opix * p.oC + co;
-        if (co + 3 < p.oC && (p.oC & 3) == 0) {
-          if (sizeof(T) == 4) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2*>(o) = pk;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (co + e < p.oC) o[e] = tt::from_f(v[e]);
-        }
-      }
+    for (int c = 1; c < 4; ++c)
+      if (c < p.n_classes && (int)blockIdx.x >= p.cls_tile_start[c]) cls = c;
   }
+  const int tile_m = blockIdx.x - p.cls_tile_start[cls];
+  const int n0 = blockIdx.y * BN;
+  const int s = p.stride;
+  int py = 0, px = 0, cH = p.oH, cW = p.oW;
+  int ky0 = 0, kx0 = 0, kstep = 1, nky = p.kh, nkx = p.kw;
+  if (MODE == MODE_DGRAD) {
+    py = p.cls_py[cls]; px = p.cls_px[cls];
+    cH = (p.oH - py + s - 1) / s;
+    cW = (p.oW - px + s - 1) / s;
+    ky0 = (py + p.pad_t) % s; kx0 = (px + p.pad_l) % s; kstep = s;
+    nky = ky0 < p.kh ? (p.kh - ky0 + s - 1) / s : 0;
+    nkx = kx0 < p.kw ? (p.kw - kx0 + s - 1) / s : 0;
+  }
+  const int64_t Mc = (int64_t)p.N * cH * cW;
+  const int ntaps = nky * nkx;
+  const int Cr = p.sC;
+
+  // staging slots: instruction j of this wave fills rows (j*4 + wave)*8 .. +7
+  RowInfo ri[4];
+  int lch[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 4 + wave) * 8 + (lane >> 3);
+    lch[j] = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t m = (int64_t)tile_m * BM + row;
+    ri[j].valid = m < Mc;
+    int64_t mm = ri[j].valid ? m : 0;
+    int n = (int)(mm / ((int64_t)cH * cW));
+    int rem = (int)(mm - (int64_t)n * cH * cW);
+    int a = rem / cW, b = rem - a * cW;
+    ri[j].n = n;
+    ri[j].a = MODE == MODE_DGRAD ? py + a * s : a;
+    ri[j].b = MODE == MODE_DGRAD ? px + b * s : b;
+  }
+  const T* __restrict__ src = (const T*)p.src;
+  const T* __restrict__ wp = (const T*)p.w;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page);
+
+  auto src_pixel = [&](const RowInfo& r, int ky, int kx, int64_t& pix) -> bool {
+    int sy, sx;
+    if (MODE == MODE_FWD) {
+      sy = r.a * s - p.pad_t + ky;
+      sx = r.b * s - p.pad_l + kx;
+      if (p.wrap_w) { sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx); }
+    } else {
+      int ty = r.a + p.pad_t - ky, tx = r.b + p.pad_l - kx;
+      if (p.wrap_w) { tx = tx < 0 ? tx + p.sW : (tx >= p.sW ? tx - p.sW : tx); }
+      if (ty < 0 || tx < 0) return false;
+      sy = ty / s; sx = tx / s;
+    }
+    if (sy < 0 || sy >= p.sH || sx < 0 || sx >= p.sW) return false;
+    pix = ((int64_t)r.n * p.sH + sy) * p.sW + sx;
+    return true;
+  };
+
+  const int ksteps_per_tap = Cr / BK2;
+  const int nk = ntaps * ksteps_per_tap;
+  const T* xsrc[4];
+  const T* wsrc[4];
+  int xm[4], wmk[4];   // -1: advance with the channel offset, 0: parked on the zero page
+  int tap_i = 0, cstep = 0;
+  auto setup_tap = [&](int t) {
+    const int ky = ky0 + kstep * (t / nkx), kx = kx0 + kstep * (t % nkx);
+    const int tap_lin = ky * p.kw + kx;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t pix;
+      if (ri[j].valid && src_pixel(ri[j], ky, kx, pix)) {
+        xsrc[j] = src + pix * Cr + lch[j] * EPC;
+        xm[j] = -1;
+      } else {
+        xsrc[j] = zero + lch[j] * EPC;
+        xm[j] = 0;
+      }
+      const int row = (j * 4 + wave) * 8 + (lane >> 3);
+      const int co = n0 + row;
+      if (co < p.oC) {
+        wsrc[j] = wp + (int64_t)tap_lin * p.w_tap + (int64_t)co * p.w_n + lch[j] * EPC;
+        wmk[j] = -1;
+      } else {
+        wsrc[j] = zero + lch[j] * EPC;
+        wmk[j] = 0;
+      }
+    }
+  };
+  auto issue = [&](int stage) {
+    unsigned char* wt = smem + stage * 2 * TILE2;
+    unsigned char* xt = wt + TILE2;
+    const int c_off = cstep * BK2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int slab = (j * 4 + wave) * 8 * ROW2;   // wave-uniform LDS byte offset
+      __builtin_amdgcn_global_load_lds((gas_ptr)(wsrc[j] + (c_off & wmk[j])), (las_ptr)(wt + slab),
+                                       16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)(xsrc[j] + (c_off & xm[j])), (las_ptr)(xt + slab),
+                                       16, 0, 0);
+    }
+    if (++cstep == ksteps_per_tap) {
+      cstep = 0;
+      if (++tap_i < ntaps) setup_tap(tap_i);
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    setup_tap(0);
+    issue(0);
+  }
+  __syncthreads();   // drains the LDS-DMA of stage 0 (vmcnt(0)) before anyone reads it
+  const int half = lane >> 5, l32 = lane & 31;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int stage = kt & 1;
+    if (kt + 1 < nk) issue(stage ^ 1);   // DMA for the next tile flies under the MFMAs below
+    const unsigned char* wt = smem + stage * 2 * TILE2;
+    const unsigned char* xt = wt + TILE2;
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+      uint4 wf[2][2], xf[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int wrow = wm * 64 + i * 32 + l32;
+          const int xrow = wn * 64 + i * 32 + l32;
+          const int c = (kp * 2 + ks) * 2 + half;
+          wf[i][ks] = *reinterpret_cast<const uint4*>(wt + wrow * ROW2 + ((c ^ ((wrow >> 1) & 7)) * 16));
+          xf[i][ks] = *reinterpret_cast<const uint4*>(xt + xrow * ROW2 + ((c ^ ((xrow >> 1) & 7)) * 16));
+        }
+      mfma_tile<T>(acc, wf, xf);
+    }
+    __syncthreads();
+  }
+  store_tile<T, MODE>(p, acc, tile_m, n0, Mc, cH, cW, py, px, wm, wn, half, l32);
 }
 
 // ------------------------------------------------------------------------------- wgrad
@@ -415,6 +621,22 @@ wgrad_kernel(const WgradParams p) {
 
   uint4 rx[CH_PER_THREAD], ry[CH_PER_THREAD];
 
+  // Each thread stages CH_PER_THREAD fixed (row, chunk) slots of every 32-pixel step; the pixel
+  // of a slot advances by 32 per step, so (n, oy, ox) is updated incrementally (no divisions
+  // in the loop).
+  int pn[CH_PER_THREAD], poy[CH_PER_THREAD], pox[CH_PER_THREAD];
+#pragma unroll
+  for (int q = 0; q < CH_PER_THREAD; ++q) {
+    int id = tid + q * kThreads;
+    int r = id / CHUNKS_PER_ROW;
+    int64_t l = l_begin + r;
+    if (l >= L) l = L - 1;   // clamped rows are never loaded (l < l_end is re-checked)
+    pn[q] = (int)(l / ((int64_t)p.Ho * p.Wo));
+    int rem = (int)(l - (int64_t)pn[q] * p.Ho * p.Wo);
+    poy[q] = rem / p.Wo;
+    pox[q] = rem - poy[q] * p.Wo;
+  }
+
   auto load_step = [&](int st) {
 #pragma unroll
     for (int q = 0; q < CH_PER_THREAD; ++q) {
@@ -425,9 +647,7 @@ wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int e = 0; e < EPC; ++e) { xe[e] = tt::from_f(0.f); ye[e] = tt::from_f(0.f); }
       if (l < l_end) {
-        int n = (int)(l / ((int64_t)p.Ho * p.Wo));
-        int rem = (int)(l - (int64_t)n * p.Ho * p.Wo);
-        int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int n = pn[q], oy = poy[q], ox = pox[q];
         int sy = oy * p.stride - p.pad_t + ky, sx = ox * p.stride - p.pad_l + kx;
         if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
         if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
@@ -441,7 +661,7 @@ wgrad_kernel(const WgradParams p) {
             for (int e = 0; e < EPC; ++e)
               if (ci0 + c + e < p.Cin) xe[e] = xs[e];
           }
-          if (p.src_mask) {
+          if (p.src_mask && mk != 1.0f) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) xe[e] = tt::from_f(tt::to_f(xe[e]) * mk);
           }
@@ -456,12 +676,20 @@ wgrad_kernel(const WgradParams p) {
         }
         if (p.row_scale) {
           const float rs = p.row_scale[l];
+          if (rs != 1.0f) {
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) ye[e] = tt::from_f(tt::to_f(ye[e]) * rs);
+            for (int e = 0; e < EPC; ++e) ye[e] = tt::from_f(tt::to_f(ye[e]) * rs);
+          }
         }
       }
       rx[q] = *reinterpret_cast<uint4*>(xe);
       ry[q] = *reinterpret_cast<uint4*>(ye);
+      // advance this slot's pixel by one step (32 pixels)
+      pox[q] += WG_BL;
+      while (pox[q] >= p.Wo) {
+        pox[q] -= p.Wo;
+        if (++poy[q] == p.Ho) { poy[q] = 0; ++pn[q]; }
+      }
     }
   };
   auto store_step = [&](int stage) {
@@ -573,6 +801,183 @@ wgrad_kernel(const WgradParams p) {
   }
 }
 
+// ------------------------------------------------------------------------ LDS-DMA wgrad
+// Same contraction as wgrad_kernel with both operand tiles DMA'd HBM -> LDS.  bf16: 64-pixel
+// steps, rows of 256 B kept unpadded (the DMA image is lane-linear) and made conflict-free
+// for the transposing reads by XOR-ing the 16-byte chunk index with (row & 3) << 2 on the
+// source side and on the read side.  fp32: 32-pixel steps, plain ds_read_b32 (no swizzle).
+// Used when no gather-side mask / row scale is needed.
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page_w[512];
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads, 2)
+wgrad_glds_kernel(const WgradParams p) {
+  using tt = TT<T>;
+  constexpr int EPC = tt::EPC;
+  constexpr int BL = sizeof(T) == 2 ? 64 : 32;          // pixels per step
+  constexpr int ROWBYTES = 128 * sizeof(T);             // 256 (bf16) / 512 (f32)
+  constexpr int CPR = 128 / EPC;                        // 16-byte chunks per row: 16 / 32
+  constexpr int RPI = 64 / CPR;                         // rows per wave instruction: 4 / 2
+  constexpr int NI = BL / RPI / 4;                      // instructions per wave per operand: 4
+  constexpr int TILE = BL * ROWBYTES;                   // 16 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tap = blockIdx.x / p.ci_tiles;
+  const int ci0 = (blockIdx.x - tap * p.ci_tiles) * 128;
+  const int co0 = blockIdx.y * 128;
+  const int split = blockIdx.z;
+  const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int64_t L = (int64_t)p.N * p.Ho * p.Wo;
+  const int64_t l_begin = (int64_t)split * p.l_per_split;
+  int64_t l_end = l_begin + p.l_per_split;
+  if (l_end > L) l_end = L;
+  const int nsteps = l_begin < l_end ? (int)((l_end - l_begin + BL - 1) / BL) : 0;
+  const T* __restrict__ x = (const T*)p.x;
+  const T* __restrict__ dy = (const T*)p.dy;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page_w);
+
+  // slot j: rows (j*4 + wave)*RPI + lane/CPR; physical chunk lane%CPR
+  int srow[NI], lch[NI];
+  bool xc_ok[NI], yc_ok[NI];
+  int pn[NI], poy[NI], pox[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    srow[j] = (j * 4 + wave) * RPI + lane / CPR;
+    const int pch = lane % CPR;
+    lch[j] = sizeof(T) == 2 ? (pch ^ ((srow[j] & 3) << 2)) : pch;
+    xc_ok[j] = ci0 + lch[j] * EPC + EPC <= p.Cin;
+    yc_ok[j] = co0 + lch[j] * EPC + EPC <= p.Cout;
+    int64_t l = l_begin + srow[j];
+    if (l >= L) l = L - 1;
+    pn[j] = (int)(l / ((int64_t)p.Ho * p.Wo));
+    int rem = (int)(l - (int64_t)pn[j] * p.Ho * p.Wo);
+    poy[j] = rem / p.Wo;
+    pox[j] = rem - poy[j] * p.Wo;
+  }
+
+  auto issue = [&](int st, int stage) {
+    unsigned char* xt = smem + stage * 2 * TILE;
+    unsigned char* yt = xt + TILE;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int64_t l = l_begin + (int64_t)st * BL + srow[j];
+      const T* xs = zero + lch[j] * EPC;
+      const T* ys = xs;
+      if (l < l_end) {
+        int sy = poy[j] * p.stride - p.pad_t + ky, sx = pox[j] * p.stride - p.pad_l + kx;
+        if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
+        if (xc_ok[j] && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+          xs = x + (((int64_t)pn[j] * p.H + sy) * p.W + sx) * p.Cin + ci0 + lch[j] * EPC;
+        if (yc_ok[j]) ys = dy + l * p.Cout + co0 + lch[j] * EPC;
+      }
+      const int slab = (j * 4 + wave) * RPI * ROWBYTES;   // wave-uniform
+      __builtin_amdgcn_global_load_lds((gas_ptr)xs, (las_ptr)(xt + slab), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)ys, (las_ptr)(yt + slab), 16, 0, 0);
+      pox[j] += BL;
+      while (pox[j] >= p.Wo) {
+        pox[j] -= p.Wo;
+        if (++poy[j] == p.Ho) { poy[j] = 0; ++pn[j]; }
+      }
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nsteps > 0) issue(0, 0);
+  __syncthreads();
+  const int half = lane >> 5, l32 = lane & 31;
+  for (int st = 0; st < nsteps; ++st) {
+    const int stage = st & 1;
+    if (st + 1 < nsteps) issue(st + 1, stage ^ 1);
+    const unsigned char* xt = smem + stage * 2 * TILE;
+    const unsigned char* yt = xt + TILE;
+    if (sizeof(T) == 2) {
+      const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+      const int jrow = i16 >> 2, qcol = i16 & 3;
+#pragma unroll
+      for (int ks = 0; ks < BL / 16; ++ks) {
+        uint4 xf[2], yf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int lb = ks * 16 + half * 8;
+          // channel byte offset -> (chunk, 8-byte half); rows lb+jrow and lb+4+jrow share row&3
+          const int xcol = wm * 64 + t * 32 + g16 * 16 + qcol * 4;
+          const int ycol = wn * 64 + t * 32 + g16 * 16 + qcol * 4;
+          const int sw = (jrow & 3) << 2;
+          const int xo = (((xcol >> 3) ^ sw) << 4) + ((xcol & 4) << 1);
+          const int yo = (((ycol >> 3) ^ sw) << 4) + ((ycol & 4) << 1);
+          s16x4_t x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(xt + (lb + jrow) * ROWBYTES + xo));
+          s16x4_t x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(xt + (lb + 4 + jrow) * ROWBYTES + xo));
+          s16x4_t y0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(yt + (lb + jrow) * ROWBYTES + yo));
+          s16x4_t y1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(yt + (lb + 4 + jrow) * ROWBYTES + yo));
+          uint2 a0 = __builtin_bit_cast(uint2, x0), a1 = __builtin_bit_cast(uint2, x1);
+          uint2 b0 = __builtin_bit_cast(uint2, y0), b1 = __builtin_bit_cast(uint2, y1);
+          xf[t] = make_uint4(a0.x, a0.y, a1.x, a1.y);
+          yf[t] = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8_t, yf[j]), __builtin_bit_cast(bf16x8_t, xf[i]),
+                acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int k2 = 0; k2 < BL / 2; ++k2) {
+        const int l = k2 * 2 + half;
+        float xa[2], yb[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          xa[t] = *reinterpret_cast<const float*>(xt + l * ROWBYTES + (wm * 64 + t * 32 + l32) * 4);
+          yb[t] = *reinterpret_cast<const float*>(yt + l * ROWBYTES + (wn * 64 + t * 32 + l32) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(yb[j], xa[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int64_t K = (int64_t)p.kh * p.kw * p.Cin;
+  float* __restrict__ dw = p.dw + (int64_t)split * K * p.Cout;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ci = ci0 + wm * 64 + i * 32 + l32;
+    if (ci >= p.Cin) continue;
+    float* row = dw + ((int64_t)tap * p.Cin + ci) * p.Cout;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + wn * 64 + j * 32 + g * 8 + half * 4;
+        if (co + 3 < p.Cout && (p.Cout & 3) == 0) {
+          *reinterpret_cast<float4*>(row + co) = make_float4(acc[i][j][g * 4], acc[i][j][g * 4 + 1],
+                                                             acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.Cout) row[co + e] = acc[i][j][g * 4 + e];
+        }
+      }
+  }
+}
+
 // sum the split partials: out[i] (+)= sum_s part[s][i]
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t n, int accumulate,
@@ -644,6 +1049,8 @@ int fill_classes(IgemmParams& p, int mode) {
 
 using namespace se3ds;
 
+static const bool g_disable_glds = getenv("SE3DS_NO_GLDS") != nullptr;
+
 extern "C" {
 
 static int conv_common(int mode, const void* src, const void* w, void* out, int dtype, int n,
@@ -677,6 +1084,17 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   if (tiles <= 0) return SE3DS_OK;
   dim3 grid((unsigned)tiles, (unsigned)ceil_div(p.oC, BN));
   hipStream_t s = as_stream(stream);
+  const bool glds = (p.sC % (2 * bk)) == 0 && src_mask == nullptr && !g_disable_glds;
+  if (glds) {
+    if (dtype == SE3DS_F32) {
+      if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_glds_kernel<float, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
+      else hipLaunchKernelGGL((igemm_glds_kernel<float, MODE_DGRAD>), grid, dim3(kThreads), 0, s, p);
+    } else {
+      if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
+      else hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_DGRAD>), grid, dim3(kThreads), 0, s, p);
+    }
+    return check_launch(mode == MODE_FWD ? "conv2d_fwd(glds)" : "conv2d_dgrad(glds)");
+  }
   if (dtype == SE3DS_F32) {
     if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_kernel<float, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
     else hipLaunchKernelGGL((igemm_kernel<float, MODE_DGRAD>), grid, dim3(kThreads), 0, s, p);
@@ -748,8 +1166,18 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   p.l_per_split = ceil_div(ceil_div(L, p.splits), WG_BL) * WG_BL;
   dim3 grid((unsigned)(kh * kw * p.ci_tiles), (unsigned)ceil_div(cout, 128), (unsigned)p.splits);
   hipStream_t s = as_stream(stream);
-  if (dtype == SE3DS_F32) hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(kThreads), 0, s, p);
-  else hipLaunchKernelGGL(wgrad_kernel<uint16_t>, grid, dim3(kThreads), 0, s, p);
+  const int epc = dtype == SE3DS_F32 ? 4 : 8;
+  const bool glds = !g_disable_glds && in_mask == nullptr && row_scale == nullptr &&
+                    (cin % epc) == 0 && (cout % epc) == 0;
+  if (glds) {
+    p.l_per_split = ceil_div(ceil_div(L, p.splits), 64) * 64;
+    if (dtype == SE3DS_F32) hipLaunchKernelGGL(wgrad_glds_kernel<float>, grid, dim3(kThreads), 0, s, p);
+    else hipLaunchKernelGGL(wgrad_glds_kernel<uint16_t>, grid, dim3(kThreads), 0, s, p);
+  } else if (dtype == SE3DS_F32) {
+    hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(kThreads), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(wgrad_kernel<uint16_t>, grid, dim3(kThreads), 0, s, p);
+  }
   const int64_t nel = (int64_t)kh * kw * cin * cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nel, 256)), dim3(256), 0, s,
                      (const float*)workspace, p.splits, nel, accumulate, out_scale, dw);

@@ -111,18 +111,24 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
   }
 }
 
-// sums[g][k][c] = sum_b partial[g][b][k][c]
+// sums[g][k][c] = sum_b partial[g][b][k][c].  Block = 32 columns x 8 partial-lanes.
 __global__ void __launch_bounds__(256)
 norm_final_reduce_kernel(const float* __restrict__ partial, int rblocks, int C, int G,
                          float* __restrict__ sums) {
-  const int64_t total = (int64_t)G * 2 * C;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * 256) {
-    int g = (int)(i / (2 * C));
-    int kc = (int)(i - (int64_t)g * 2 * C);
-    float s = 0.f;
-    for (int b = 0; b < rblocks; ++b) s += partial[((int64_t)g * rblocks + b) * 2 * C + kc];
-    sums[i] = s;
+  __shared__ float sh[8][33];
+  const int g = blockIdx.y;
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31);   // index into [2][C]
+  const int lane_b = threadIdx.x >> 5;
+  float s = 0.f;
+  if (col < 2 * C)
+    for (int b = lane_b; b < rblocks; b += 8) s += partial[((int64_t)g * rblocks + b) * 2 * C + col];
+  sh[lane_b][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (lane_b == 0 && col < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += sh[i][threadIdx.x & 31];
+    sums[(int64_t)g * 2 * C + col] = t;
   }
 }
 
@@ -163,22 +169,29 @@ norm_finalize_kernel(const float* __restrict__ sums, float count, int G, int C,
   }
 }
 
+// Elementwise kernels use the same 2-D thread layout as the statistics kernel: a thread owns
+// VEC consecutive channels (scale/shift/mean/rstd live in registers) and strides over rows, so
+// the inner loop has no integer divisions.  grid = (row blocks, channel tiles, G).
+
 // y = act(x * scale + shift [+ res]) [+ post]
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                   const float* __restrict__ shift, const T* __restrict__ res,
-                  const T* __restrict__ post, int64_t R, int C, int G, int act, float alpha,
-                  T* __restrict__ y) {
-  const int cvec = C / VEC;
-  const int64_t total = (int64_t)G * R * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % cvec);
-    const int64_t row = i / cvec;
-    const int g = (int)(row / R);
-    const int c0 = cv * VEC;
-    const int64_t off = row * C + c0;
+                  const T* __restrict__ post, int64_t R, int C, int cx, int ry, int act,
+                  float alpha, T* __restrict__ y) {
+  const int g = blockIdx.z;
+  const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
+  const int c0 = (blockIdx.y * cx + tx) * VEC;
+  if (c0 >= C) return;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    sc[e] = scale[(int64_t)g * C + c0 + e];
+    sh[e] = shift[(int64_t)g * C + c0 + e];
+  }
+  for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
+    const int64_t off = ((int64_t)g * R + r) * C + c0;
     float xv[VEC], rv[VEC], pv[VEC], o[VEC];
     if constexpr (VEC > 1) {
       VT<T>::load(x + off, reinterpret_cast<float(&)[VT<T>::V]>(xv));
@@ -191,7 +204,7 @@ norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float v = xv[e] * scale[(int64_t)g * C + c0 + e] + shift[(int64_t)g * C + c0 + e];
+      float v = xv[e] * sc[e] + sh[e];
       if (res) v += rv[e];
       v = act_apply(v, act, alpha);
       if (post) v += pv[e];
@@ -208,17 +221,24 @@ __global__ void __launch_bounds__(256)
 norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
                       const float* __restrict__ mean, const float* __restrict__ rstd,
                       const float* __restrict__ gamma, const float* __restrict__ sums, float count,
-                      int64_t R, int C, int G, int act, float alpha, T* __restrict__ dx,
+                      int64_t R, int C, int cx, int ry, int act, float alpha, T* __restrict__ dx,
                       T* __restrict__ dres) {
-  const int cvec = C / VEC;
-  const int64_t total = (int64_t)G * R * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % cvec);
-    const int64_t row = i / cvec;
-    const int g = (int)(row / R);
-    const int c0 = cv * VEC;
-    const int64_t off = row * C + c0;
+  const int g = blockIdx.z;
+  const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
+  const int c0 = (blockIdx.y * cx + tx) * VEC;
+  if (c0 >= C) return;
+  float mu[VEC], rs[VEC], gr[VEC], s0[VEC], s1[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int64_t gc = (int64_t)g * C + c0 + e;
+    mu[e] = mean[gc];
+    rs[e] = rstd[gc];
+    gr[e] = (gamma ? gamma[c0 + e] : 1.0f) * rs[e];
+    s0[e] = sums[((int64_t)g * 2) * C + c0 + e] / count;
+    s1[e] = sums[((int64_t)g * 2 + 1) * C + c0 + e] / count;
+  }
+  for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
+    const int64_t off = ((int64_t)g * R + r) * C + c0;
     float dv[VEC], yv[VEC], xv[VEC], o[VEC], dr[VEC];
     if constexpr (VEC > 1) {
       VT<T>::load(dy + off, reinterpret_cast<float(&)[VT<T>::V]>(dv));
@@ -231,13 +251,10 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const int64_t gc = (int64_t)g * C + c0 + e;
       float d = dv[e] * (act ? act_grad_from_out(yv[e], act, alpha) : 1.f);
       dr[e] = d;
-      float xh = (xv[e] - mean[gc]) * rstd[gc];
-      float s0 = sums[((int64_t)g * 2) * C + c0 + e] / count;
-      float s1 = sums[((int64_t)g * 2 + 1) * C + c0 + e] / count;
-      o[e] = (gamma ? gamma[c0 + e] : 1.0f) * rstd[gc] * (d - s0 - xh * s1);
+      float xh = (xv[e] - mu[e]) * rs[e];
+      o[e] = gr[e] * (d - s0[e] - xh * s1[e]);
     }
     if constexpr (VEC > 1) {
       VT<T>::store(dx + off, reinterpret_cast<float(&)[VT<T>::V]>(o));
@@ -253,17 +270,17 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
-                  const float* __restrict__ scale, int64_t R, int C, int G, int act, float alpha,
-                  T* __restrict__ dx, T* __restrict__ dres) {
-  const int cvec = C / VEC;
-  const int64_t total = (int64_t)G * R * cvec;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * 256) {
-    const int cv = (int)(i % cvec);
-    const int64_t row = i / cvec;
-    const int g = (int)(row / R);
-    const int c0 = cv * VEC;
-    const int64_t off = row * C + c0;
+                  const float* __restrict__ scale, int64_t R, int C, int cx, int ry, int act,
+                  float alpha, T* __restrict__ dx, T* __restrict__ dres) {
+  const int g = blockIdx.z;
+  const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
+  const int c0 = (blockIdx.y * cx + tx) * VEC;
+  if (c0 >= C) return;
+  float sc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) sc[e] = scale[(int64_t)g * C + c0 + e];
+  for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
+    const int64_t off = ((int64_t)g * R + r) * C + c0;
     float dv[VEC], yv[VEC], o[VEC], dr[VEC];
     if constexpr (VEC > 1) {
       VT<T>::load(dy + off, reinterpret_cast<float(&)[VT<T>::V]>(dv));
@@ -276,7 +293,7 @@ affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
     for (int e = 0; e < VEC; ++e) {
       float d = dv[e] * (act ? act_grad_from_out(yv[e], act, alpha) : 1.f);
       dr[e] = d;
-      o[e] = d * scale[(int64_t)g * C + c0 + e];
+      o[e] = d * sc[e];
     }
     if constexpr (VEC > 1) {
       VT<T>::store(dx + off, reinterpret_cast<float(&)[VT<T>::V]>(o));
@@ -288,13 +305,22 @@ affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
   }
 }
 
+// row blocks for the elementwise kernels: ~8 blocks per CU in total
+inline dim3 ew_grid(const Layout2D& l, int64_t R, int G) {
+  int64_t want = (256 * 8) / ((int64_t)l.ctiles * G);
+  if (want < 1) want = 1;
+  int64_t max_rb = ceil_div(R, l.ry);
+  if (want > max_rb) want = max_rb;
+  return dim3((unsigned)want, (unsigned)l.ctiles, (unsigned)G);
+}
+
 int pick_rblocks(int64_t R, int ry, int ctiles, int G) {
   int64_t want = 1024 / ((int64_t)ctiles * G);
   if (want < 1) want = 1;
   int64_t max_rb = ceil_div(R, (int64_t)ry * 4);
   if (max_rb < 1) max_rb = 1;
   if (want > max_rb) want = max_rb;
-  if (want > 512) want = 512;
+  if (want > 128) want = 128;
   return (int)want;
 }
 
@@ -312,8 +338,8 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
   else
     hipLaunchKernelGGL((norm_partial_kernel<T, 1, MODE>), grid, dim3(256), 0, s, a, y, x, mean,
                        rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws);
-  hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(grid_for((int64_t)G * 2 * C, 256)), dim3(256),
-                     0, s, ws, rb, C, G, sums);
+  hipLaunchKernelGGL(norm_final_reduce_kernel, dim3((unsigned)ceil_div(2 * C, 32), (unsigned)G),
+                     dim3(256), 0, s, ws, rb, C, G, sums);
   return check_launch("norm_partial");
 }
 
@@ -325,7 +351,7 @@ using namespace se3ds;
 extern "C" {
 
 size_t se3ds_norm_workspace_bytes(int g, int c) {
-  return sizeof(float) * (size_t)g * 512 * 2 * (size_t)c + 16;
+  return sizeof(float) * (size_t)g * 128 * 2 * (size_t)c + 16;
 }
 
 int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const float* row_scale,
@@ -358,28 +384,20 @@ int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const fl
                      void* y, void* stream) {
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
+#define LAUNCH_APPLY(T, V)                                                                        \
+  hipLaunchKernelGGL((norm_apply_kernel<T, V>), ew_grid(l, r, g), dim3(256), 0, s, (const T*)x,   \
+                     scale, shift, (const T*)res, (const T*)post, r, c, l.cx, l.ry, act, alpha,   \
+                     (T*)y)
   if (dtype == SE3DS_F32) {
-    if (c % 4 == 0)
-      hipLaunchKernelGGL((norm_apply_kernel<float, 4>), dim3(grid_for((int64_t)g * r * c / 4, 256)),
-                         dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res,
-                         (const float*)post, r, c, g, act, alpha, (float*)y);
-    else
-      hipLaunchKernelGGL((norm_apply_kernel<float, 1>), dim3(grid_for((int64_t)g * r * c, 256)),
-                         dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res,
-                         (const float*)post, r, c, g, act, alpha, (float*)y);
+    Layout2D l = make_layout(c, 4);
+    if (l.vec > 1) LAUNCH_APPLY(float, 4); else LAUNCH_APPLY(float, 1);
   } else if (dtype == SE3DS_BF16) {
-    if (c % 8 == 0)
-      hipLaunchKernelGGL((norm_apply_kernel<uint16_t, 8>),
-                         dim3(grid_for((int64_t)g * r * c / 8, 256)), dim3(256), 0, s,
-                         (const uint16_t*)x, scale, shift, (const uint16_t*)res,
-                         (const uint16_t*)post, r, c, g, act, alpha, (uint16_t*)y);
-    else
-      hipLaunchKernelGGL((norm_apply_kernel<uint16_t, 1>), dim3(grid_for((int64_t)g * r * c, 256)),
-                         dim3(256), 0, s, (const uint16_t*)x, scale, shift, (const uint16_t*)res,
-                         (const uint16_t*)post, r, c, g, act, alpha, (uint16_t*)y);
+    Layout2D l = make_layout(c, 8);
+    if (l.vec > 1) LAUNCH_APPLY(uint16_t, 8); else LAUNCH_APPLY(uint16_t, 1);
   } else {
     return SE3DS_E_BADDTYPE;
   }
+#undef LAUNCH_APPLY
   return check_launch("norm_apply");
 }
 
@@ -406,13 +424,15 @@ int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
 #define LAUNCH_BWD(T, V)                                                                         \
-  hipLaunchKernelGGL((norm_bwd_apply_kernel<T, V>), dim3(grid_for((int64_t)g * r * c / V, 256)), \
-                     dim3(256), 0, s, (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, \
-                     sums, count, r, c, g, act, alpha, (T*)dx, (T*)dres)
+  hipLaunchKernelGGL((norm_bwd_apply_kernel<T, V>), ew_grid(l, r, g), dim3(256), 0, s,           \
+                     (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, sums, count, r,  \
+                     c, l.cx, l.ry, act, alpha, (T*)dx, (T*)dres)
   if (dtype == SE3DS_F32) {
-    if (c % 4 == 0) LAUNCH_BWD(float, 4); else LAUNCH_BWD(float, 1);
+    Layout2D l = make_layout(c, 4);
+    if (l.vec > 1) LAUNCH_BWD(float, 4); else LAUNCH_BWD(float, 1);
   } else if (dtype == SE3DS_BF16) {
-    if (c % 8 == 0) LAUNCH_BWD(uint16_t, 8); else LAUNCH_BWD(uint16_t, 1);
+    Layout2D l = make_layout(c, 8);
+    if (l.vec > 1) LAUNCH_BWD(uint16_t, 8); else LAUNCH_BWD(uint16_t, 1);
   } else {
     return SE3DS_E_BADDTYPE;
   }
@@ -426,13 +446,15 @@ int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r,
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
 #define LAUNCH_AFF(T, V)                                                                      \
-  hipLaunchKernelGGL((affine_bwd_kernel<T, V>), dim3(grid_for((int64_t)g * r * c / V, 256)),  \
-                     dim3(256), 0, s, (const T*)dy, (const T*)y, scale, r, c, g, act, alpha,  \
-                     (T*)dx, (T*)dres)
+  hipLaunchKernelGGL((affine_bwd_kernel<T, V>), ew_grid(l, r, g), dim3(256), 0, s,            \
+                     (const T*)dy, (const T*)y, scale, r, c, l.cx, l.ry, act, alpha, (T*)dx,  \
+                     (T*)dres)
   if (dtype == SE3DS_F32) {
-    if (c % 4 == 0) LAUNCH_AFF(float, 4); else LAUNCH_AFF(float, 1);
+    Layout2D l = make_layout(c, 4);
+    if (l.vec > 1) LAUNCH_AFF(float, 4); else LAUNCH_AFF(float, 1);
   } else if (dtype == SE3DS_BF16) {
-    if (c % 8 == 0) LAUNCH_AFF(uint16_t, 8); else LAUNCH_AFF(uint16_t, 1);
+    Layout2D l = make_layout(c, 8);
+    if (l.vec > 1) LAUNCH_AFF(uint16_t, 8); else LAUNCH_AFF(uint16_t, 1);
   } else {
     return SE3DS_E_BADDTYPE;
   }
