@@ -58,12 +58,18 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
   n = args.batch if args.batch > 0 else 4
   h = args.image_size
   batch = synth_batch(n, h, 1234 + rank, dev)
-  for _ in range(args.warmup):
+  def step():
+    # one cluster step of the host loop (gan_manager.py:409-421 with num_batched_steps = 1):
+    # train_g_d, then the host advances global_step.  From the second step on the EMA model
+    # is updated by decay and the step-0-only EMA forward (se3ds_trainer.py:258-259) is gone.
     gan.train_g_d(batch)
+    gan.global_step += gan.num_batched_steps
+  for _ in range(args.warmup):
+    step()
   barrier(world)
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    gan.train_g_d(batch)
+    step()
   barrier(world)
   dt = max_over_ranks(time.perf_counter() - t0, world, dev)
   ms = 1e3 * dt / args.steps
@@ -72,7 +78,7 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
   # instrumented step with HIP events around every conv launch on the launch stream
   prof = nn.ConvProfiler()
   nn.set_conv_profiler(prof)
-  gan.train_g_d(batch)
+  step()
   torch.cuda.synchronize()
   nn.set_conv_profiler(None)
   summ = prof.summary()

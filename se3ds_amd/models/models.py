@@ -1,0 +1,184 @@
+"""Interface for using SE3DS models for prediction -- MI355X implementation of the reference's
+models/models.py: `SE3DSModel` keeps a point-cloud memory (coords / semantic feats / rgb coords /
+rgb), adds equirectangular observations to it (`add_to_memory`, reference :180-245) and renders +
+inpaints a panorama at a new position (`__call__`, reference :247-366).  The whole per-call
+pipeline (two projections over the memory, mask, generator forward with circular padding,
+quantisation, optional feedback into the memory) stays on the device."""
+from typing import List, NamedTuple, Optional
+
+import numpy as np
+import torch
+
+from se3ds_amd import _lib
+from se3ds_amd import constants
+from se3ds_amd.models import image_models
+from se3ds_amd.utils import pano_utils
+
+
+class PanoData(NamedTuple):
+  position: torch.Tensor
+  rgb: torch.Tensor
+  semantic: torch.Tensor
+  depth: torch.Tensor
+
+
+class OutputData(NamedTuple):
+  """Output tuple (reference :41-74)."""
+  proj_semantic: torch.Tensor
+  pred_semantic: torch.Tensor
+  proj_rgb: torch.Tensor
+  pred_rgb: torch.Tensor
+  proj_depth: torch.Tensor
+  pred_depth: torch.Tensor
+  mu: torch.Tensor
+  logvar: torch.Tensor
+  proj_mask: Optional[torch.Tensor] = None
+  heading_enc: Optional[np.ndarray] = None
+  pitch_enc: Optional[np.ndarray] = None
+  features_enc: Optional[np.ndarray] = None
+  predicted_bucket_probs: Optional[torch.Tensor] = None
+  predicted_node_xyz: Optional[List[torch.Tensor]] = None
+
+
+class MemoryState(NamedTuple):
+  """coords (N,4,M) fp32; feats (N,M,1) uint8; rgb_coords (N,4,M'); rgb (N,M',3) int32."""
+  coords: torch.Tensor
+  feats: torch.Tensor
+  rgb_coords: torch.Tensor
+  rgb: torch.Tensor
+
+
+class SE3DSModel(object):
+  """Interface to use an SE3DS model for predictions (reference :90-366)."""
+
+  def __init__(self, config, device='cuda:0', dtype=torch.float32):
+    self.config = config
+    if config.batch_size != 1:
+      raise ValueError('Several methods do not support batch_size > 1.')
+    self.device = torch.device(device)
+    self.model = image_models.ResNetGenerator(
+        resnet_version=config.resnet_version, gen_dims=config.gen_dims,
+        use_blurred_mask=config.use_blurred_mask, device=self.device, dtype=dtype)
+    if config.ckpt_path is not None:
+      # TF object-graph checkpoints cannot be read here (no TensorFlow): the state-dict converter
+      # is the first "next" row of SURVEY.md section 8f.
+      raise NotImplementedError(
+          'loading tf.train.Checkpoint files is not supported yet; use config.ckpt_path = None '
+          'and SE3DSModel.model.store.load_dict(...)')
+    print('Initializing SE3DS model from scratch.')
+    self.prev_rgb_frame = None
+    self.batch_size = config.batch_size
+    self.height = config.image_height
+    self.width = config.image_height * 2
+    self.depth_scale = config.depth_scale
+    self.reset_memory()
+
+  def _check_batch_size(self, input_batch_size):
+    if input_batch_size != self.batch_size:
+      raise ValueError('Input batch size is not suitable. Expected '
+                       f'{self.batch_size}, got {input_batch_size} instead.')
+
+  def reset_memory(self):
+    """Resets memory to empty (reference :127-134)."""
+    d = self.device
+    self._memory = MemoryState(
+        coords=torch.zeros((self.batch_size, 4, 0), device=d),
+        feats=torch.zeros((self.batch_size, 0, 1), dtype=torch.uint8, device=d),
+        rgb_coords=torch.zeros((self.batch_size, 4, 0), device=d),
+        rgb=torch.zeros((self.batch_size, 0, 3), dtype=torch.int32, device=d))
+
+  def get_memory_state(self) -> MemoryState:
+    return MemoryState(*[t.clone() for t in self._memory])
+
+  def set_memory_state(self, state: MemoryState):
+    self._memory = MemoryState(*[t.clone() for t in state])
+
+  def write_memory_as_pointcloud(self, filename):
+    """Writes memory at batch position 0 to an ASCII .ply file (reference :154-178)."""
+    state = self.get_memory_state()
+    xyz = state.rgb_coords[0, 0:3].cpu().numpy().T
+    rgb = state.rgb[0].cpu().numpy()
+    with open(filename, 'w') as fp:
+      fp.write('ply\nformat ascii 1.0 \n')
+      fp.write('element vertex %d\n' % xyz.shape[0])
+      fp.write('property float x\nproperty float y\nproperty float z\n')
+      fp.write('property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n')
+      for i in range(xyz.shape[0]):
+        fp.write('{} {} {} {} {} {} \n'.format(xyz[i, 0], xyz[i, 1], xyz[i, 2], rgb[i, 0],
+                                               rgb[i, 1], rgb[i, 2]))
+
+  def add_to_memory(self, pano_rgb, pano_semantic, pano_depth, position, mask_blurred=True):
+    """Adds an equirectangular observation to the memory (reference :180-245)."""
+    self._check_batch_size(pano_semantic.shape[0])
+    assert pano_rgb.dtype in [torch.uint8, torch.int32]
+    assert pano_semantic.dtype in [torch.uint8, torch.int32]
+    _lib.require_cuda(pano_rgb, pano_semantic, pano_depth, position)
+    pano_rgb = pano_rgb.to(torch.int32)
+    pano_semantic = pano_semantic.to(torch.uint8)
+    self.prev_rgb_frame = pano_rgb.to(torch.float32) / 255
+    if mask_blurred:
+      pano_rgb = pano_utils.mask_pano(pano_rgb, masked_region_value=constants.INVALID_RGB_VALUE)
+    position = position.to(torch.float32)
+    xyz1, feats = pano_utils.equirectangular_to_pointcloud(
+        pano_semantic, pano_depth, constants.INVALID_SEM_VALUE, self.depth_scale,
+        interpolation_method='nearest', position=position)
+    rgb_xyz1, rgb_feats = pano_utils.equirectangular_to_pointcloud(
+        pano_rgb, pano_depth, constants.INVALID_RGB_VALUE, self.depth_scale,
+        interpolation_method='bilinear', position=position)
+    # Filter coords if they are not valid (stream compaction, reference :229-236)
+    f_xyz1, f_feats = pano_utils.compact_valid_points(xyz1, feats, constants.INVALID_SEM_VALUE)
+    f_rgb_xyz1, f_rgb = pano_utils.compact_valid_points(rgb_xyz1, rgb_feats,
+                                                        constants.INVALID_RGB_VALUE)
+    f_rgb = f_rgb.to(self._memory.rgb.dtype)
+    self.set_memory_state(MemoryState(
+        coords=torch.cat([self._memory.coords, f_xyz1], dim=2),
+        feats=torch.cat([self._memory.feats, f_feats], dim=1),
+        rgb_coords=torch.cat([self._memory.rgb_coords, f_rgb_xyz1], dim=2),
+        rgb=torch.cat([self._memory.rgb, f_rgb], dim=1)))
+
+  def __call__(self, position, add_preds_to_memory: bool = False, sample_noise: bool = False,
+               use_projected_rgb: bool = False, z: Optional[torch.Tensor] = None) -> OutputData:
+    """Predicts the frame at `position` (reference :247-366)."""
+    batch_size = position.shape[0]
+    self._check_batch_size(batch_size)
+    _lib.require_cuda(position)
+    position = position.to(torch.float32)
+    h, w = self.height, self.width
+    _, proj_semantic = pano_utils.project_feats_to_equirectangular(
+        self._memory.feats, self._memory.coords, h, w, constants.INVALID_SEM_VALUE,
+        self.depth_scale, offset=position)
+    proj_depth, proj_rgb, proj_mask = pano_utils.project_feats_to_equirectangular(
+        self._memory.rgb, self._memory.rgb_coords, h, w, constants.INVALID_RGB_VALUE,
+        self.depth_scale, offset=position, with_mask=True,
+        mask_void=constants.INVALID_RGB_VALUE)
+    proj_mask = proj_mask[..., None]
+    proj_semantic = proj_semantic[..., 0].to(torch.uint8)
+    proj_rgb = torch.clamp(proj_rgb / 255, 0, 1)   # quantisation glue on (N,H,W,3)
+    assert self.prev_rgb_frame is not None
+    inputs = {
+        'prev_image': self.prev_rgb_frame, 'proj_image': proj_rgb,
+        'proj_depth': proj_depth[..., None], 'proj_mask': proj_mask,
+        'blurred_mask': torch.zeros_like(proj_mask),
+        'dataset_type': torch.zeros((batch_size,), dtype=torch.int32, device=self.device),
+    }
+    (mu, logvar, _, pred_depth, pred_semantic, _, generated_pred_rgb) = self.model(
+        inputs=[inputs, None], sample_noise=sample_noise, training=False)
+    pred_depth = torch.clamp(pred_depth[..., 0], 0, 1)
+    pc_rgb_tensor = torch.clamp((generated_pred_rgb * 255).to(torch.int32),
+                                constants.INVALID_RGB_VALUE, 255)   # truncation, as tf.cast
+    pred_rgb = (torch.clamp(generated_pred_rgb, 0, 1) * 255).to(torch.int32)
+    pred_semantic = torch.zeros(pred_semantic.shape[:-1], dtype=torch.uint8, device=self.device)
+    if add_preds_to_memory:
+      pred_rgb_mem, pred_semantic_mem, pred_depth_mem = pc_rgb_tensor, pred_semantic, pred_depth
+      if use_projected_rgb:
+        pred_rgb = proj_rgb + pred_rgb_mem
+        pred_semantic = proj_semantic + pred_semantic_mem
+        pred_depth = proj_depth + pred_depth_mem
+        generated_pred_rgb = torch.clamp(pred_rgb_mem, 0, 255).to(torch.float32) / 255
+      self.prev_rgb_frame = generated_pred_rgb
+      self.add_to_memory(pred_rgb_mem, pred_semantic_mem[..., None], pred_depth_mem, position)
+    pred_rgb = pred_rgb.to(torch.uint8)
+    return OutputData(proj_semantic=proj_semantic, pred_semantic=pred_semantic,
+                      proj_rgb=(proj_rgb * 255).to(torch.uint8), pred_rgb=pred_rgb,
+                      proj_depth=proj_depth, pred_depth=pred_depth, mu=mu, logvar=logvar,
+                      proj_mask=proj_mask)

@@ -14,6 +14,7 @@ import torch.distributed as dist
 from se3ds_amd import _lib
 from se3ds_amd import gin_lite as gin
 from se3ds_amd import hipops  # noqa: F401
+from se3ds_amd.trainers import dist_utils
 from se3ds_amd.utils import ema
 
 
@@ -71,9 +72,7 @@ class AdamState:
     Keras Adam update (reference se3ds_trainer.py:253-257)."""
     st = self.model.store
     if world > 1:
-      bucket = 64 * 1024 * 1024  # elements per all-reduce (256 MiB fp32)
-      for o in range(0, st.grad.numel(), bucket):
-        dist.all_reduce(st.grad[o:o + bucket], op=dist.ReduceOp.SUM, group=group)
+      dist_utils.allreduce_arena_sum(st.grad, group)
     self.iterations += 1
     _lib.check(_lib.lib().se3ds_multi_adam_keras(
         st.theta.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),

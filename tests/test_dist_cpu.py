@@ -1,0 +1,127 @@
+"""CPU tests (gloo, world_size 2) of the replica plumbing and of the data-parallel semantics the
+GPU path implements: SyncBN statistics pooled over replicas, per-replica per-tensor clipping
+BEFORE the cross-replica sum, losses pre-divided by the replica count."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import nets_torch as O
+from se3ds_amd.trainers import dist_utils
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _toy_params(seed=0):
+  from se3ds_amd.models import image_models
+  G = image_models.ResNetGenerator(image_size=64, gen_dims=4, z_dim=4, device='cpu', seed=seed)
+  D = image_models.SNMultiScaleDiscriminator(dis_dims=4, n_layers=3, device='cpu', seed=seed + 1)
+  return ({k: v.clone() for k, v in G.store.views.items()},
+          {k: v.clone() for k, v in D.store.views.items()})
+
+
+def _batch(n, h, seed):
+  g = torch.Generator().manual_seed(seed)
+  w = 2 * h
+  image = torch.rand((n, h, w, 3), generator=g)
+  depth = torch.rand((n, h, w, 1), generator=g)
+  pm = (torch.rand((n, h, w, 1), generator=g) < 0.5).float()
+  bm = torch.zeros((n, h, w, 1))
+  bm[:, :h // 8] = 1
+  return dict(image=image, depth=depth, proj_mask=pm, proj_image=image * pm,
+              proj_depth=depth * pm, blurred_mask=bm)
+
+
+def _cfg():
+  return dict(gen=dict(gen_dims=4, resnet_version='50', context_layer='convs', z_dim=4),
+              dis=dict(n_dis=2, n_layers=3, kernel_size=4), lambda_gan=1.0, lambda_kld=10.0,
+              lambda_wc=10.0, lambda_depth=100.0, mask_blurred=True,
+              g_train=lambda k: not k.endswith(('/u', '/moving_mean', '/moving_variance')),
+              d_train=lambda k: not k.endswith('/u'))
+
+
+def _worker(rank, world, port, mode, out):
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  torch.set_num_threads(2)
+  try:
+    if mode == 'arena':
+      arena = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+      dist_utils.allreduce_arena_sum(arena, bucket_elems=256)
+      out[rank] = arena.numpy().copy()
+      full = {'x': torch.arange(8).reshape(4, 2)}
+      shard = dist_utils.shard_batch(full, rank, world)
+      assert shard['x'].tolist() == [[4 * rank, 4 * rank + 1], [4 * rank + 2, 4 * rank + 3]]
+    elif mode == 'replica_step':
+      gp, dp = _toy_params()
+      full = _batch(2, 64, 5)
+      shard = dist_utils.shard_batch(full, rank, world)
+      def pooled(name, s1, s2, cnt):   # SyncBN: statistics over all replicas
+        t = torch.stack([s1.detach(), s2.detach()])
+        dist.all_reduce(t)
+        # keep autograd: replace the values, keep the local graph contribution (as TF does
+        # with the cross-replica sum inside the tape)
+        s1 = s1 + (t[0] - s1.detach())
+        s2 = s2 + (t[1] - s2.detach())
+        return s1, s2, cnt * world
+      torch.manual_seed(0)
+      cfg = _cfg()
+      # the oracle's generator takes the hook through a patched Net
+      orig = O.Net.__init__
+      def patched(self, params, training, stats_hook=None, bn_training=None):
+        orig(self, params, training, pooled if training else None, bn_training)
+      O.Net.__init__ = patched
+      try:
+        ref = O.train_g_d(gp, dp, shard, cfg, replicas=world)
+      finally:
+        O.Net.__init__ = orig
+      flat = torch.cat([g.reshape(-1) for g in ref['g_grads'].values()])
+      dist_utils.allreduce_arena_sum(flat)   # SUM of per-replica clipped gradients
+      out[rank] = dict(sum=flat.numpy().copy(),
+                       local_norms=np.array([float(g.norm()) for g in ref['g_grads'].values()]),
+                       mm=ref['g_updates']['encoder/bn1/moving_mean'].numpy().copy())
+  finally:
+    dist.destroy_process_group()
+
+
+def _run(mode):
+  ctx = mp.get_context('spawn')
+  mgr = ctx.Manager()
+  out = mgr.dict()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, out)) for r in range(2)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(timeout=600)
+    assert p.exitcode == 0
+  return dict(out)
+
+
+def test_arena_allreduce_and_sharding_gloo():
+  out = _run('arena')
+  expect = np.arange(1000, dtype=np.float32) * 3
+  np.testing.assert_array_equal(out[0], expect)
+  np.testing.assert_array_equal(out[1], expect)
+
+
+def test_two_replica_step_semantics_gloo():
+  """Two replicas, one sample each: every replica ends with the same summed gradient, the
+  clip is applied per replica (local norms <= 5), and the BN moving statistics are identical on
+  both replicas because the batch statistics were pooled."""
+  out = _run('replica_step')
+  np.testing.assert_array_equal(out[0]['sum'], out[1]['sum'])
+  np.testing.assert_allclose(out[0]['mm'], out[1]['mm'], rtol=0, atol=0)
+  assert out[0]['local_norms'].max() <= 5.0 + 1e-4 and out[1]['local_norms'].max() <= 5.0 + 1e-4
+  assert np.isfinite(out[0]['sum']).all()

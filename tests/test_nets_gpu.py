@@ -575,3 +575,35 @@ def test_split_input_dict_and_cluster():
   gan.train_ds = iter([batch])
   gan.train_cluster(1)
   assert gan.d_optimizer.iterations == 2 and gan.g_optimizer.iterations == 1
+
+
+def test_se3ds_model_roundtrip_and_shapes():
+  """models/models_test.py:38-79: add a pano to the memory, predict at the same position ->
+  projected RGB equals the input on >= 95 % of the pixels; shapes and ranges."""
+  from se3ds_amd.models import model_config, models
+  gin_lite.clear_config()
+  size = 128
+  g = torch.Generator().manual_seed(3)
+  rgb = torch.randint(0, 255, (1, size, size * 2, 3), generator=g, dtype=torch.int32).to(torch.uint8)
+  seg = torch.randint(0, 42, (1, size, size * 2, 1), generator=g, dtype=torch.int32).to(torch.uint8)
+  depth = torch.rand((1, size, size * 2), generator=g)
+  pos = torch.randn((1, 3), generator=g)
+  config = model_config.get_test_config()
+  config.image_height = size
+  model = models.SE3DSModel(config, device=DEV)
+  model.add_to_memory(rgb.to(DEV), seg.to(DEV), depth.to(DEV), pos.to(DEV), mask_blurred=False)
+  out = model(pos.to(DEV))
+  eq = torch.all(out.proj_rgb.cpu() == rgb, dim=-1).float().mean()
+  assert float(eq) >= 0.95
+  assert tuple(out.proj_semantic.shape) == (1, size, size * 2)
+  assert tuple(out.pred_semantic.shape) == (1, size, size * 2)
+  assert tuple(out.pred_rgb.shape) == tuple(rgb.shape) and out.pred_rgb.dtype == torch.uint8
+  assert tuple(out.pred_depth.shape) == (1, size, size * 2)
+  assert float(out.pred_depth.min()) >= 0 and float(out.pred_depth.max()) <= 1
+  # feedback path: predictions become part of the memory
+  m0 = model.get_memory_state().rgb.shape[1]
+  model(pos.to(DEV) + 0.1, add_preds_to_memory=True)
+  assert model.get_memory_state().rgb.shape[1] > m0
+  config.batch_size = 2
+  with pytest.raises(ValueError):
+    models.SE3DSModel(config, device=DEV)

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests -m gpu -q --tb=line 2>&1 | tail -6 | cut -c1-400
+python __graft_entry__.py smoke 2>&1 | tail -3
+timeout 1200 python -m pytest tests -m gpu -q --tb=short 2>&1 | tail -8 | cut -c1-400
