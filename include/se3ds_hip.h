@@ -150,7 +150,9 @@ int se3ds_weight_prep(const float* w, int64_t k, int cout, int dtype, void* wt, 
 
 /* y = epilogue(conv(x * in_mask, W)).  Replaces tf.nn.conv2d at models/layers.py:193-198
  * (PartialConv), :334-339 (SpectralConv), Keras Conv2D (image_models.py:513-517,542-543),
- * and is the input-gradient of Conv2DTranspose.  in_mask (n,h,w) fp32 or NULL.  Epilogue:
+ * and is the input-gradient of Conv2DTranspose.  in_mask (n,h,w) fp32 or NULL;
+ * in_mask_binary != 0 promises that it only holds 0.0 / 1.0 (the reference's masks are binary),
+ * which lets masked pixels be fetched from a zero page by the LDS-DMA kernel.  Epilogue:
  *   t = acc * (*scale)                                  scale: device scalar or NULL
  *   row_a != NULL, bias != NULL: t = ((t - b)*row_a + b) * row_b   (layers.py:199-202)
  *   row_a != NULL, bias == NULL: t = t * row_a                     (layers.py:203-204)
@@ -159,9 +161,9 @@ int se3ds_weight_prep(const float* w, int64_t k, int cout, int dtype, void* wt, 
  * row_a / row_b are (n*ho*wo) fp32 vectors (mask_ratio / update_mask). */
 int se3ds_conv2d_fwd(const void* x, const void* wt, void* y, int dtype, int n, int h, int w,
                      int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
-                     int pad_l, int wrap_w, const float* in_mask, const float* scale,
-                     const float* bias, const float* row_a, const float* row_b, int act,
-                     float act_alpha, void* stream);
+                     int pad_l, int wrap_w, const float* in_mask, int in_mask_binary,
+                     const float* scale, const float* bias, const float* row_a,
+                     const float* row_b, int act, float act_alpha, void* stream);
 
 /* dx = epilogue(conv_transpose(dy, W)): the input-gradient of the conv above AND the forward
  * of Keras Conv2DTranspose (models/layers.py:417-423,475-480; image_models.py:440-441), whose
@@ -181,9 +183,9 @@ size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int co
                                           int kw);
 int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int n, int h, int w,
                        int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
-                       int pad_l, int wrap_w, const float* in_mask, const float* row_scale,
-                       const float* out_scale, int accumulate, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       int pad_l, int wrap_w, const float* in_mask, int in_mask_binary,
+                       const float* row_scale, const float* out_scale, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Partial-conv mask statistics -- models/layers.py:153-163: cnt = window sum of the mask
  * (n,h,w); ratio = kh*kw/(cnt+1e-6)*clip(cnt,0,1); um = clip(cnt,0,1); optionally
@@ -232,6 +234,9 @@ int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r,
 int se3ds_act_bwd(const void* dy, const void* y, int dtype, int64_t n, int act, float alpha,
                   void* dx, void* stream);
 int se3ds_add(const void* a, const void* b, int dtype, int64_t n, void* out, void* stream);
+/* out[r,:] = x[r,:] * scale[r] (partial-conv backward: dy * ratio * update_mask). */
+int se3ds_row_scale(const void* x, int dtype, int64_t rows, int c, const float* scale, void* out,
+                    void* stream);
 /* Keras MaxPool2D(2, padding='SAME') -- image_models.py:267,289 */
 int se3ds_maxpool2x2_fwd(const void* x, int dtype, int n, int h, int w, int c, void* y,
                          void* stream);

@@ -64,6 +64,7 @@ struct IgemmParams {
   int n_classes; int cls_tile_start[5]; int cls_py[4], cls_px[4];
   // gather-side per-pixel multiplier (partial conv: x * mask), (N,sH,sW) fp32 or null
   const float* src_mask;
+  int mask_binary;        // src_mask holds only {0,1}: masked rows may be fetched from the zero page
   // epilogue
   const float* scale;     // device scalar (1/(sigma+eps)) or null
   const float* bias;      // (oC) or null
@@ -497,7 +498,8 @@ igemm_glds_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       int64_t pix;
-      if (ri[j].valid && src_pixel(ri[j], ky, kx, pix)) {
+      if (ri[j].valid && src_pixel(ri[j], ky, kx, pix) &&
+          !(p.src_mask && p.src_mask[pix] == 0.0f)) {
         xsrc[j] = src + pix * Cr + lch[j] * EPC;
         xm[j] = -1;
       } else {
@@ -582,6 +584,7 @@ struct WgradParams {
   const void* dy; int Ho, Wo, Cout;   // output-side operand
   int N, kh, kw, stride, pad_t, pad_l, wrap_w;
   const float* src_mask;              // (N,H,W) or null: x * mask (partial conv)
+  int mask_binary;                    // src_mask is {0,1}
   const float* row_scale;             // (N*Ho*Wo) or null: dy * row_scale (partial renorm)
   float* dw;                          // [split][kh*kw*Cin][Cout] fp32 partial sums
   int splits; int64_t l_per_split;    // pixels per split (multiple of 32)
@@ -868,8 +871,10 @@ wgrad_glds_kernel(const WgradParams p) {
       if (l < l_end) {
         int sy = poy[j] * p.stride - p.pad_t + ky, sx = pox[j] * p.stride - p.pad_l + kx;
         if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
-        if (xc_ok[j] && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
-          xs = x + (((int64_t)pn[j] * p.H + sy) * p.W + sx) * p.Cin + ci0 + lch[j] * EPC;
+        if (xc_ok[j] && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
+          const int64_t pix = ((int64_t)pn[j] * p.H + sy) * p.W + sx;
+          if (!(p.src_mask && p.src_mask[pix] == 0.0f)) xs = x + pix * p.Cin + ci0 + lch[j] * EPC;
+        }
         if (yc_ok[j]) ys = dy + l * p.Cout + co0 + lch[j] * EPC;
       }
       const int slab = (j * 4 + wave) * RPI * ROWBYTES;   // wave-uniform
@@ -1056,7 +1061,7 @@ extern "C" {
 static int conv_common(int mode, const void* src, const void* w, void* out, int dtype, int n,
                        int h, int wdt, int cin, int ho, int wo, int cout, int kh, int kw,
                        int stride, int pad_t, int pad_l, int wrap_w, const float* src_mask,
-                       const float* scale, const float* bias, const float* row_a,
+                       int mask_binary, const float* scale, const float* bias, const float* row_a,
                        const float* row_b, int act, float act_alpha, void* stream) {
   if (n <= 0 || h <= 0 || wdt <= 0 || cin <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || kh <= 0 ||
       kw <= 0 || stride <= 0 || stride > 2)
@@ -1068,7 +1073,8 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   IgemmParams p;
   p.src = src; p.w = w; p.out = out;
   p.N = n; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
-  p.wrap_w = wrap_w; p.src_mask = src_mask; p.scale = scale; p.bias = bias; p.row_a = row_a;
+  p.wrap_w = wrap_w; p.src_mask = src_mask; p.mask_binary = mask_binary; p.scale = scale;
+  p.bias = bias; p.row_a = row_a;
   p.row_b = row_b; p.act = act; p.act_alpha = act_alpha;
   const int bk = dtype == SE3DS_F32 ? 16 : 32;
   const int64_t K = (int64_t)kh * kw * cin;
@@ -1084,7 +1090,8 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   if (tiles <= 0) return SE3DS_OK;
   dim3 grid((unsigned)tiles, (unsigned)ceil_div(p.oC, BN));
   hipStream_t s = as_stream(stream);
-  const bool glds = (p.sC % (2 * bk)) == 0 && src_mask == nullptr && !g_disable_glds;
+  const bool glds = (p.sC % (2 * bk)) == 0 && (src_mask == nullptr || mask_binary) &&
+                    !g_disable_glds;
   if (glds) {
     if (dtype == SE3DS_F32) {
       if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_glds_kernel<float, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
@@ -1107,11 +1114,12 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
 
 int se3ds_conv2d_fwd(const void* x, const void* wt, void* y, int dtype, int n, int h, int w,
                      int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
-                     int pad_l, int wrap_w, const float* in_mask, const float* scale,
-                     const float* bias, const float* row_a, const float* row_b, int act,
-                     float act_alpha, void* stream) {
+                     int pad_l, int wrap_w, const float* in_mask, int in_mask_binary,
+                     const float* scale, const float* bias, const float* row_a,
+                     const float* row_b, int act, float act_alpha, void* stream) {
   return conv_common(MODE_FWD, x, wt, y, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride, pad_t,
-                     pad_l, wrap_w, in_mask, scale, bias, row_a, row_b, act, act_alpha, stream);
+                     pad_l, wrap_w, in_mask, in_mask_binary, scale, bias, row_a, row_b, act,
+                     act_alpha, stream);
 }
 
 int se3ds_conv2d_dgrad(const void* dy, const void* wn, void* dx, int dtype, int n, int h, int w,
@@ -1120,18 +1128,20 @@ int se3ds_conv2d_dgrad(const void* dy, const void* wn, void* dx, int dtype, int 
                        const float* bias, const float* row_a, int act, float act_alpha,
                        void* stream) {
   return conv_common(MODE_DGRAD, dy, wn, dx, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride,
-                     pad_t, pad_l, wrap_w, dy_row_scale, scale, bias, row_a, nullptr, act,
+                     pad_t, pad_l, wrap_w, dy_row_scale, 0, scale, bias, row_a, nullptr, act,
                      act_alpha, stream);
 }
 
 static int wgrad_splits(int64_t L, int64_t tiles) {
-  // enough blocks to fill 256 CUs x 2, but keep >= 256 pixels per split
-  int64_t want = (512 + tiles - 1) / tiles;
-  int64_t max_by_l = L / 256;
+  // Work items = tiles x splits, all of equal cost; ~512 run concurrently (2 per CU).  Aim for
+  // >= 4 rounds of work items so the last, partially filled round costs little, but keep at
+  // least 512 pixels (8 steps) per item and bound the partial-sum traffic.
+  int64_t want = (2048 + tiles - 1) / tiles;
+  int64_t max_by_l = L / 512;
   if (max_by_l < 1) max_by_l = 1;
   if (want > max_by_l) want = max_by_l;
   if (want < 1) want = 1;
-  if (want > 1024) want = 1024;
+  if (want > 256) want = 256;
   return (int)want;
 }
 
@@ -1145,9 +1155,9 @@ size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int co
 
 int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int n, int h, int w,
                        int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
-                       int pad_l, int wrap_w, const float* in_mask, const float* row_scale,
-                       const float* out_scale, int accumulate, void* workspace,
-                       size_t workspace_bytes, void* stream) {
+                       int pad_l, int wrap_w, const float* in_mask, int in_mask_binary,
+                       const float* row_scale, const float* out_scale, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream) {
   if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || kh <= 0 ||
       kw <= 0 || stride <= 0)
     return SE3DS_E_BADSHAPE;
@@ -1157,7 +1167,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   WgradParams p;
   p.x = x; p.H = h; p.W = w; p.Cin = cin; p.dy = dy; p.Ho = ho; p.Wo = wo; p.Cout = cout;
   p.N = n; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
-  p.wrap_w = wrap_w; p.src_mask = in_mask; p.row_scale = row_scale;
+  p.wrap_w = wrap_w; p.src_mask = in_mask; p.mask_binary = in_mask_binary; p.row_scale = row_scale;
   p.dw = (float*)workspace;
   p.ci_tiles = (int)ceil_div(cin, 128);
   const int64_t L = (int64_t)n * ho * wo;
@@ -1167,7 +1177,8 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   dim3 grid((unsigned)(kh * kw * p.ci_tiles), (unsigned)ceil_div(cout, 128), (unsigned)p.splits);
   hipStream_t s = as_stream(stream);
   const int epc = dtype == SE3DS_F32 ? 4 : 8;
-  const bool glds = !g_disable_glds && in_mask == nullptr && row_scale == nullptr &&
+  const bool glds = !g_disable_glds && (in_mask == nullptr || in_mask_binary) &&
+                    row_scale == nullptr &&
                     (cin % epc) == 0 && (cout % epc) == 0;
   if (glds) {
     p.l_per_split = ceil_div(ceil_div(L, p.splits), 64) * 64;

@@ -315,12 +315,14 @@ inline dim3 ew_grid(const Layout2D& l, int64_t R, int G) {
 }
 
 int pick_rblocks(int64_t R, int ry, int ctiles, int G) {
-  int64_t want = 1024 / ((int64_t)ctiles * G);
+  // ~2048 blocks in total (8 per CU) so the streaming reads have enough waves in flight, at
+  // least 4 row-iterations per thread, at most 1024 partials per column.
+  int64_t want = 2048 / ((int64_t)ctiles * G);
   if (want < 1) want = 1;
   int64_t max_rb = ceil_div(R, (int64_t)ry * 4);
   if (max_rb < 1) max_rb = 1;
   if (want > max_rb) want = max_rb;
-  if (want > 128) want = 128;
+  if (want > 1024) want = 1024;
   return (int)want;
 }
 
@@ -351,7 +353,7 @@ using namespace se3ds;
 extern "C" {
 
 size_t se3ds_norm_workspace_bytes(int g, int c) {
-  return sizeof(float) * (size_t)g * 128 * 2 * (size_t)c + 16;
+  return sizeof(float) * (size_t)g * 1024 * 2 * (size_t)c + 16;
 }
 
 int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const float* row_scale,

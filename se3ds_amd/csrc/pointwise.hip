@@ -64,6 +64,25 @@ act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, int64_t nvec, 
   }
 }
 
+// out[r, :] = x[r, :] * scale[r]   (partial-conv backward: dy * ratio * update_mask)
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kB)
+row_scale_kernel(const T* __restrict__ x, const float* __restrict__ scale, int64_t rows, int cvec,
+                 T* __restrict__ out) {
+  const int64_t total = rows * cvec;
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kB) {
+    const float sc = scale[i / cvec];
+    float v[VEC];
+    if constexpr (VEC > 1) VT<T>::load(x + i * VEC, reinterpret_cast<float(&)[VT<T>::V]>(v));
+    else v[0] = VT<T>::ld1(x + i);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] *= sc;
+    if constexpr (VEC > 1) VT<T>::store(out + i * VEC, reinterpret_cast<float(&)[VT<T>::V]>(v));
+    else VT<T>::st1(out + i, v[0]);
+  }
+}
+
 // dst (+)= src, elementwise, same dtype
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kB)
@@ -427,6 +446,18 @@ int se3ds_act_bwd(const void* dy, const void* y, int dtype, int64_t n, int act, 
              if (n % 8 == 0) L(uint16_t, 8); else L(uint16_t, 1))
 #undef L
   return check_launch("act_bwd");
+}
+
+int se3ds_row_scale(const void* x, int dtype, int64_t rows, int c, const float* scale, void* out,
+                    void* stream) {
+  if (rows <= 0 || c <= 0) return SE3DS_OK;
+  hipStream_t s = as_stream(stream);
+#define L(T, V) hipLaunchKernelGGL((row_scale_kernel<T, V>), dim3(grid_for(rows * (c / V), kB)), dim3(kB), \
+                                   0, s, (const T*)x, scale, rows, c / V, (T*)out)
+  DISPATCH_T(dtype, if (c % 4 == 0) L(float, 4); else L(float, 1),
+             if (c % 8 == 0) L(uint16_t, 8); else L(uint16_t, 1))
+#undef L
+  return check_launch("row_scale");
 }
 
 int se3ds_add(const void* a, const void* b, int dtype, int64_t n, void* out, void* stream) {

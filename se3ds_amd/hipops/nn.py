@@ -190,6 +190,9 @@ class Ctx:
     self.training = training
     self.tape = [] if record else None
     self.param_grads = True   # False: backward passes only propagate input gradients
+    # PartialConv masks hold only 0/1 (true for the reference's data pipeline and for every
+    # update_mask derived from a binary mask).  Set False for fractional masks: exact, slower.
+    self.binary_masks = True
     self.group = group
     self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) \
         else 1
@@ -504,7 +507,8 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
   with _Timed('fwd', flops):
     _chk(L.se3ds_conv2d_fwd(xd.data_ptr(), wt.data_ptr(), y.data_ptr(), ctx.code, n, h, w, cin,
                             ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
-                            _lib.ptr(in_mask), _lib.ptr(scale), _lib.ptr(bias), _lib.ptr(ratio),
+                            _lib.ptr(in_mask), 1 if ctx.binary_masks else 0, _lib.ptr(scale),
+                            _lib.ptr(bias), _lib.ptr(ratio),
                             _lib.ptr(um if (partial and bias is not None) else None), act,
                             float(alpha), _lib.stream()), 'se3ds_conv2d_fwd')
   out = Var(y)
@@ -519,8 +523,15 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
                              dy.data_ptr(), _lib.stream()), 'se3ds_act_bwd')
       rows = n * ho * wo
       row_scale = None
+      dys = dy
       if partial:
         row_scale = ru if bias is not None else ratio
+        if ctx.binary_masks:
+          # pre-scale dy once so that wgrad / dgrad can take the LDS-DMA kernels
+          dys = ctx.empty(dy.shape)
+          _chk(L.se3ds_row_scale(dy.data_ptr(), ctx.code, rows, layer.cout, row_scale.data_ptr(),
+                                 dys.data_ptr(), _lib.stream()), 'se3ds_row_scale')
+          row_scale = None
       st = layer.store
       if ctx.param_grads:
         if bias is not None:
@@ -531,15 +542,16 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
         ws = _global_ws(ctx.device, 'wgrad', wsz)
         gk = st.grad_views[layer.name + '/kernel']
         with _Timed('wgrad', flops):
-          _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dy.data_ptr(), gk.data_ptr(), ctx.code, n, h,
+          _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dys.data_ptr(), gk.data_ptr(), ctx.code, n, h,
                                     w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
-                                    1 if wrap else 0, _lib.ptr(in_mask), _lib.ptr(row_scale),
+                                    1 if wrap else 0, _lib.ptr(in_mask),
+                                    1 if ctx.binary_masks else 0, _lib.ptr(row_scale),
                                     None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
                'se3ds_conv2d_wgrad')
       if x.requires_grad:
         dx = ctx.empty(xd.shape)
         with _Timed('dgrad', flops):
-          _chk(L.se3ds_conv2d_dgrad(dy.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h,
+          _chk(L.se3ds_conv2d_dgrad(dys.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h,
                                     w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
                                     1 if wrap else 0, _lib.ptr(row_scale), _lib.ptr(scale), None,
                                     _lib.ptr(in_mask), ACT_NONE, 0.0, _lib.stream()),
@@ -587,14 +599,14 @@ def conv_transpose2d(ctx: Ctx, x: Var, layer: ConvLayer):
         gk = st.grad_views[layer.name + '/kernel']
         with _Timed('convT_wgrad', flops):
           _chk(L.se3ds_conv2d_wgrad(dy.data_ptr(), xd.data_ptr(), gk.data_ptr(), ctx.code, n, H, W,
-                                    layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None, None,
-                                    0, ws.data_ptr(), ws.numel(), _lib.stream()),
+                                    layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, 0, None,
+                                    None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
                'se3ds_conv2d_wgrad')
       if x.requires_grad:
         dx = ctx.empty(xd.shape)
         with _Timed('convT_dgrad', flops):
           _chk(L.se3ds_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), ctx.code, n, H, W,
-                                  layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None, None,
+                                  layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, 0, None, None,
                                   None, None, ACT_NONE, 0.0, _lib.stream()), 'se3ds_conv2d_fwd')
         accumulate(x, dx)
     ctx.record(bwd)

@@ -607,3 +607,32 @@ def test_se3ds_model_roundtrip_and_shapes():
   config.batch_size = 2
   with pytest.raises(ValueError):
     models.SE3DSModel(config, device=DEV)
+
+
+@pytest.mark.parametrize('cin', [32, 64])
+def test_partial_conv_fractional_mask_exact_path(cin):
+  """Fractional (non-binary) masks take the exact register-staged kernels (Ctx.binary_masks =
+  False): x * mask in the gather, dy * ratio * update_mask in the transposed gather."""
+  store, layer, sg = _mk_layer('partial', cin, 32, 3, 1, 'VALID', True, 9)
+  gen = torch.Generator().manual_seed(13)
+  n, h, w = 2, 12, 20
+  x = torch.randn((n, h, w, cin), generator=gen)
+  mask = torch.rand((n, h, w, 1), generator=gen)
+  mask[:, 3:6] = 0
+  p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in store.views.items()}
+  xo = x.clone().requires_grad_(True)
+  net = O.Net(p, training=True)
+  yo, umo = net.partial_conv(O.pad_layer(xo, 1), O.pad_layer(mask, 1), 'c', 1, 'VALID')
+  gy = torch.randn(yo.shape, generator=gen)
+  yo.backward(gy)
+  ctx = nn.Ctx(DEV, torch.float32, training=True, record=True)
+  ctx.binary_masks = False
+  xv = nn.Var(to_dev(x.numpy(), torch.float32))
+  yv, um = nn.conv2d(ctx, xv, layer, pad=1, mask=to_dev(mask.numpy()[..., 0], torch.float32))
+  assert rel_err(um.cpu().numpy(), umo.detach().numpy()[..., 0]) < 1e-6
+  assert rel_err(yv.data.cpu().numpy(), yo.detach().numpy()) < 1e-4
+  yv.grad = to_dev(gy.numpy(), torch.float32)
+  ctx.backward()
+  assert rel_err(xv.grad.cpu().numpy(), xo.grad.numpy()) < 1e-4
+  assert rel_err(store.grad_views['c/kernel'].cpu().numpy(), p['c/kernel'].grad.numpy()) < 1e-4
+  assert rel_err(store.grad_views['c/bias'].cpu().numpy(), p['c/bias'].grad.numpy()) < 1e-3
