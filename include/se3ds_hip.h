@@ -201,9 +201,11 @@ int se3ds_mask_window(const float* mask, int n, int h, int w, int ho, int wo, in
  * ====================================================================================== */
 size_t se3ds_norm_workspace_bytes(int g, int c);
 /* sums[g][0][c] = sum_r x*row_scale, sums[g][1][c] = sum_r (x*row_scale)^2 (row_scale may be NULL);
- * also the column-sum primitive behind bias gradients. */
+ * also the column-sum primitive behind bias gradients: colsum_out (c floats, may be NULL)
+ * additionally receives sums[0][0][:] (written straight into a gradient arena). */
 int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const float* row_scale,
-                     float* sums, void* workspace, size_t workspace_bytes, void* stream);
+                     float* sums, float* colsum_out, void* workspace, size_t workspace_bytes,
+                     void* stream);
 /* mean = S0/count, var = S1/count - mean^2 (biased); scale = gamma*rsqrt(var+eps),
  * shift = beta - mean*scale; moving stats (c) updated in place unless NULL;
  * use_moving != 0: inference (statistics from moving_mean / moving_var). */
@@ -215,10 +217,12 @@ int se3ds_norm_finalize(const float* sums, float count, int g, int c, const floa
 int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const float* scale,
                      const float* shift, const void* res, const void* post, int act, float alpha,
                      void* y, void* stream);
-/* sums[g][0][c] = sum dpre, sums[g][1][c] = sum dpre*xhat with dpre = dy*act'(y). */
+/* sums[g][0][c] = sum dpre, sums[g][1][c] = sum dpre*xhat with dpre = dy*act'(y).  For g == 1
+ * dbeta_out / dgamma_out (c floats, may be NULL) receive the two rows directly. */
 int se3ds_norm_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
                          int c, const float* mean, const float* rstd, int act, float alpha,
-                         float* sums, void* workspace, size_t workspace_bytes, void* stream);
+                         float* sums, float* dbeta_out, float* dgamma_out, void* workspace,
+                         size_t workspace_bytes, void* stream);
 /* dx = gamma*rstd*(dpre - S0/count - xhat*S1/count); dres = dpre when non-NULL. */
 int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
                          int c, const float* mean, const float* rstd, const float* gamma,

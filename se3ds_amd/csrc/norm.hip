@@ -111,24 +111,41 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
   }
 }
 
-// sums[g][k][c] = sum_b partial[g][b][k][c].  Block = 32 columns x 8 partial-lanes.
+// sums[g][k][c] = sum_b partial[g][b][k][c].  Block = 32 columns x 8 partial-lanes, four
+// independent accumulators per lane so the (L2-resident) partial loads overlap.  Optional
+// direct outputs dst0 / dst1 (length C) receive row 0 / row 1 of group 0 (bias / affine
+// gradients written straight into the gradient arena).
 __global__ void __launch_bounds__(256)
 norm_final_reduce_kernel(const float* __restrict__ partial, int rblocks, int C, int G,
-                         float* __restrict__ sums) {
+                         float* __restrict__ sums, float* __restrict__ dst0,
+                         float* __restrict__ dst1) {
   __shared__ float sh[8][33];
   const int g = blockIdx.y;
   const int col = blockIdx.x * 32 + (threadIdx.x & 31);   // index into [2][C]
   const int lane_b = threadIdx.x >> 5;
-  float s = 0.f;
-  if (col < 2 * C)
-    for (int b = lane_b; b < rblocks; b += 8) s += partial[((int64_t)g * rblocks + b) * 2 * C + col];
-  sh[lane_b][threadIdx.x & 31] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < 2 * C) {
+    const float* P = partial + (int64_t)g * rblocks * 2 * C + col;
+    int b = lane_b;
+    for (; b + 24 < rblocks; b += 32) {
+      s0 += P[(int64_t)b * 2 * C];
+      s1 += P[(int64_t)(b + 8) * 2 * C];
+      s2 += P[(int64_t)(b + 16) * 2 * C];
+      s3 += P[(int64_t)(b + 24) * 2 * C];
+    }
+    for (; b < rblocks; b += 8) s0 += P[(int64_t)b * 2 * C];
+  }
+  sh[lane_b][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (lane_b == 0 && col < 2 * C) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) t += sh[i][threadIdx.x & 31];
     sums[(int64_t)g * 2 * C + col] = t;
+    if (g == 0) {
+      if (dst0 && col < C) dst0[col] = t;
+      if (dst1 && col >= C) dst1[col - C] = t;
+    }
   }
 }
 
@@ -322,14 +339,15 @@ int pick_rblocks(int64_t R, int ry, int ctiles, int G) {
   int64_t max_rb = ceil_div(R, (int64_t)ry * 4);
   if (max_rb < 1) max_rb = 1;
   if (want > max_rb) want = max_rb;
-  if (want > 1024) want = 1024;
+  if (want > 512) want = 512;
   return (int)want;
 }
 
 template <typename T, int MODE>
 int launch_partial(const T* a, const T* y, const T* x, const float* mean, const float* rstd,
                    const float* row_scale, int G, int64_t R, int C, int act, float alpha,
-                   float* sums, float* ws, size_t ws_bytes, hipStream_t s) {
+                   float* sums, float* dst0, float* dst1, float* ws, size_t ws_bytes,
+                   hipStream_t s) {
   Layout2D l = make_layout(C, VT<T>::V);
   int rb = pick_rblocks(R, l.ry, l.ctiles, G);
   if (ws_bytes < sizeof(float) * (size_t)G * rb * 2 * C) return SE3DS_E_WORKSPACE;
@@ -341,7 +359,7 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
     hipLaunchKernelGGL((norm_partial_kernel<T, 1, MODE>), grid, dim3(256), 0, s, a, y, x, mean,
                        rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws);
   hipLaunchKernelGGL(norm_final_reduce_kernel, dim3((unsigned)ceil_div(2 * C, 32), (unsigned)G),
-                     dim3(256), 0, s, ws, rb, C, G, sums);
+                     dim3(256), 0, s, ws, rb, C, G, sums, dst0, dst1);
   return check_launch("norm_partial");
 }
 
@@ -357,16 +375,18 @@ size_t se3ds_norm_workspace_bytes(int g, int c) {
 }
 
 int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const float* row_scale,
-                     float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+                     float* sums, float* colsum_out, void* workspace, size_t workspace_bytes,
+                     void* stream) {
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
   if (dtype == SE3DS_F32)
     return launch_partial<float, 0>((const float*)x, nullptr, nullptr, nullptr, nullptr, row_scale,
-                                    g, r, c, 0, 0.f, sums, (float*)workspace, workspace_bytes, s);
+                                    g, r, c, 0, 0.f, sums, colsum_out, nullptr, (float*)workspace,
+                                    workspace_bytes, s);
   if (dtype == SE3DS_BF16)
     return launch_partial<uint16_t, 0>((const uint16_t*)x, nullptr, nullptr, nullptr, nullptr,
-                                       row_scale, g, r, c, 0, 0.f, sums, (float*)workspace,
-                                       workspace_bytes, s);
+                                       row_scale, g, r, c, 0, 0.f, sums, colsum_out, nullptr,
+                                       (float*)workspace, workspace_bytes, s);
   return SE3DS_E_BADDTYPE;
 }
 
@@ -405,17 +425,18 @@ int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const fl
 
 int se3ds_norm_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
                          int c, const float* mean, const float* rstd, int act, float alpha,
-                         float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+                         float* sums, float* dbeta_out, float* dgamma_out, void* workspace,
+                         size_t workspace_bytes, void* stream) {
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
   if (dtype == SE3DS_F32)
     return launch_partial<float, 1>((const float*)dy, (const float*)y, (const float*)x, mean, rstd,
-                                    nullptr, g, r, c, act, alpha, sums, (float*)workspace,
-                                    workspace_bytes, s);
+                                    nullptr, g, r, c, act, alpha, sums, dbeta_out, dgamma_out,
+                                    (float*)workspace, workspace_bytes, s);
   if (dtype == SE3DS_BF16)
     return launch_partial<uint16_t, 1>((const uint16_t*)dy, (const uint16_t*)y, (const uint16_t*)x,
-                                       mean, rstd, nullptr, g, r, c, act, alpha, sums,
-                                       (float*)workspace, workspace_bytes, s);
+                                       mean, rstd, nullptr, g, r, c, act, alpha, sums, dbeta_out,
+                                       dgamma_out, (float*)workspace, workspace_bytes, s);
   return SE3DS_E_BADDTYPE;
 }
 

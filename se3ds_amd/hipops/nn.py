@@ -462,14 +462,15 @@ def mask_window(ctx, mask, n, h, w, ho, wo, k, stride, pad_t, pad_l, wrap, want_
   return ratio, um, ru, bu
 
 
-def _colsum(ctx, t2d_ptr, dtype_code, rows, c, row_scale=None, groups=1):
-  """Column sums [groups][c] of a [groups][rows][c] tensor (bias / affine gradients)."""
+def _colsum(ctx, t2d_ptr, dtype_code, rows, c, row_scale=None, groups=1, out=None):
+  """Column sums [groups][c] of a [groups][rows][c] tensor (bias / affine gradients); `out`
+  (c floats, e.g. a view of the gradient arena) also receives the sums of group 0."""
   sums = torch.empty((groups, 2, c), dtype=torch.float32, device=ctx.device)
   L = _L()
   ws = ctx.ws('norm', L.se3ds_norm_workspace_bytes(groups, c))
   _chk(L.se3ds_norm_stats(t2d_ptr, dtype_code, groups, rows, c, _lib.ptr(row_scale),
-                          sums.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
-       'se3ds_norm_stats')
+                          sums.data_ptr(), _lib.ptr(out), ws.data_ptr(), ws.numel(),
+                          _lib.stream()), 'se3ds_norm_stats')
   return sums
 
 
@@ -535,9 +536,8 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
       st = layer.store
       if ctx.param_grads:
         if bias is not None:
-          sums = _colsum(ctx, dy.data_ptr(), ctx.code, rows, layer.cout,
-                         row_scale=bu if partial else None)
-          st.grad_views[layer.name + '/bias'].copy_(sums[0, 0])
+          _colsum(ctx, dy.data_ptr(), ctx.code, rows, layer.cout,
+                  row_scale=bu if partial else None, out=st.grad_views[layer.name + '/bias'])
         wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, layer.cout, k, k)
         ws = _global_ws(ctx.device, 'wgrad', wsz)
         gk = st.grad_views[layer.name + '/kernel']
@@ -592,8 +592,8 @@ def conv_transpose2d(ctx: Ctx, x: Var, layer: ConvLayer):
       st = layer.store
       if ctx.param_grads:
         if bias is not None:
-          sums = _colsum(ctx, dy.data_ptr(), ctx.code, n * H * W, layer.cout)
-          st.grad_views[layer.name + '/bias'].copy_(sums[0, 0])
+          _colsum(ctx, dy.data_ptr(), ctx.code, n * H * W, layer.cout,
+                  out=st.grad_views[layer.name + '/bias'])
         wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, hi, wi, layer.cout, cin_t, k, k)
         ws = _global_ws(ctx.device, 'wgrad', wsz)
         gk = st.grad_views[layer.name + '/kernel']
@@ -686,25 +686,26 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
           bs = torch.empty((g, 2, c), dtype=torch.float32, device=ctx.device)
           _chk(L.se3ds_norm_bwd_stats(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r,
                                       c, mean.data_ptr(), rstd.data_ptr(), act, float(alpha),
-                                      bs.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+                                      bs.data_ptr(), st.grad_views[layer.name + '/beta'].data_ptr(),
+                                      st.grad_views[layer.name + '/gamma'].data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _lib.stream()),
                'se3ds_norm_bwd_stats')
-          st.grad_views[layer.name + '/beta'].copy_(bs[0, 0])
-          st.grad_views[layer.name + '/gamma'].copy_(bs[0, 1])
         _chk(L.se3ds_affine_bwd(dy.data_ptr(), y.data_ptr(), ctx.code, g, r, c, scale.data_ptr(),
                                 act, float(alpha), dx.data_ptr(), _lib.ptr(dres), _lib.stream()),
              'se3ds_affine_bwd')
       else:
         bs = torch.empty((g, 2, c), dtype=torch.float32, device=ctx.device)
-        _chk(L.se3ds_norm_bwd_stats(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c,
-                                    mean.data_ptr(), rstd.data_ptr(), act, float(alpha),
-                                    bs.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
-             'se3ds_norm_bwd_stats')
-        # parameter gradients are the LOCAL sums (aggregated later with every other gradient)
-        if not ctx.param_grads:
+        direct = ctx.param_grads and g == 1
+        # parameter gradients are the LOCAL sums (aggregated later with every other gradient);
+        # for batch norm the reduction writes them straight into the gradient arena
+        _chk(L.se3ds_norm_bwd_stats(
+            dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c, mean.data_ptr(),
+            rstd.data_ptr(), act, float(alpha), bs.data_ptr(),
+            st.grad_views[layer.name + '/beta'].data_ptr() if direct else None,
+            st.grad_views[layer.name + '/gamma'].data_ptr() if direct else None,
+            ws.data_ptr(), ws.numel(), _lib.stream()), 'se3ds_norm_bwd_stats')
+        if not ctx.param_grads or direct:
           pass
-        elif g == 1:
-          st.grad_views[layer.name + '/beta'].copy_(bs[0, 0])
-          st.grad_views[layer.name + '/gamma'].copy_(bs[0, 1])
         else:
           tot = _colsum(ctx, bs.data_ptr(), _lib.F32, g, 2 * c)
           st.grad_views[layer.name + '/beta'].copy_(tot[0, 0, :c])
