@@ -492,30 +492,59 @@ igemm_glds_kernel(const IgemmParams p) {
   const T* wsrc[4];
   int xm[4], wmk[4];   // -1: advance with the channel offset, 0: parked on the zero page
   int tap_i = 0, cstep = 0;
-  auto setup_tap = [&](int t) {
-    const int ky = ky0 + kstep * (t / nkx), kx = kx0 + kstep * (t % nkx);
-    const int tap_lin = ky * p.kw + kx;
+  // Per-slot constants so that a tap change costs a few adds / compares (32-bit pixel math):
+  //   FWD  : source row/col = a0 + ky, b0 + kx        with a0 = a*s - pad_t, b0 = b*s - pad_l
+  //   DGRAD: numerators       a0 - ky, b0 - kx        with a0 = a + pad_t,   b0 = b + pad_l
+  int a0[4], b0[4], img0[4];
+  const T* wrow[4];
+  const int sshift = s == 2 ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    a0[j] = MODE == MODE_FWD ? ri[j].a * s - p.pad_t : ri[j].a + p.pad_t;
+    b0[j] = MODE == MODE_FWD ? ri[j].b * s - p.pad_l : ri[j].b + p.pad_l;
+    img0[j] = ri[j].n * p.sH * p.sW;
+    const int row = (j * 4 + wave) * 8 + (lane >> 3);
+    const int co = n0 + row;
+    if (co < p.oC) {
+      wrow[j] = wp + (int64_t)co * p.w_n + lch[j] * EPC;
+      wmk[j] = -1;
+    } else {
+      wrow[j] = nullptr;
+      wmk[j] = 0;
+    }
+  }
+  int tky = 0, tkx = 0;   // running tap counters (index inside the class tap list)
+  auto setup_tap = [&](int) {
+    const int ky = ky0 + kstep * tky, kx = kx0 + kstep * tkx;
+    const int64_t wtap = (int64_t)(ky * p.kw + kx) * p.w_tap;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int64_t pix;
-      if (ri[j].valid && src_pixel(ri[j], ky, kx, pix) &&
-          !(p.src_mask && p.src_mask[pix] == 0.0f)) {
-        xsrc[j] = src + pix * Cr + lch[j] * EPC;
+      int sy, sx;
+      bool ok = ri[j].valid;
+      if (MODE == MODE_FWD) {
+        sy = a0[j] + ky;
+        sx = b0[j] + kx;
+        if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+      } else {
+        int ty = a0[j] - ky, tx = b0[j] - kx;
+        if (p.wrap_w) tx = tx < 0 ? tx + p.sW : (tx >= p.sW ? tx - p.sW : tx);
+        ok = ok && ty >= 0 && tx >= 0;
+        sy = ty >> sshift;
+        sx = tx >> sshift;
+      }
+      ok = ok && (unsigned)sy < (unsigned)p.sH && (unsigned)sx < (unsigned)p.sW;
+      const int pix = img0[j] + sy * p.sW + sx;
+      if (ok && p.src_mask) ok = p.src_mask[pix] != 0.0f;
+      if (ok) {
+        xsrc[j] = src + (int64_t)pix * Cr + lch[j] * EPC;
         xm[j] = -1;
       } else {
         xsrc[j] = zero + lch[j] * EPC;
         xm[j] = 0;
       }
-      const int row = (j * 4 + wave) * 8 + (lane >> 3);
-      const int co = n0 + row;
-      if (co < p.oC) {
-        wsrc[j] = wp + (int64_t)tap_lin * p.w_tap + (int64_t)co * p.w_n + lch[j] * EPC;
-        wmk[j] = -1;
-      } else {
-        wsrc[j] = zero + lch[j] * EPC;
-        wmk[j] = 0;
-      }
+      wsrc[j] = wmk[j] ? wrow[j] + wtap : zero + lch[j] * EPC;
     }
+    if (++tkx == nkx) { tkx = 0; ++tky; }
   };
   auto issue = [&](int stage) {
     unsigned char* wt = smem + stage * 2 * TILE2;
@@ -860,22 +889,28 @@ wgrad_glds_kernel(const WgradParams p) {
     pox[j] = rem - poy[j] * p.Wo;
   }
 
+  // Per-slot running state (all 32-bit): pixel coordinates and the linear index of the
+  // un-shifted pixel; the tap shift and the bounds test are a few adds / compares per step.
+  const int dyoff = ky - p.pad_t, dxoff = kx - p.pad_l;
+  const int st_ = p.stride;
+  const int l_end_rel = (int)(l_end - l_begin);
   auto issue = [&](int st, int stage) {
     unsigned char* xt = smem + stage * 2 * TILE;
     unsigned char* yt = xt + TILE;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int64_t l = l_begin + (int64_t)st * BL + srow[j];
+      const int lrel = st * BL + srow[j];
       const T* xs = zero + lch[j] * EPC;
       const T* ys = xs;
-      if (l < l_end) {
-        int sy = poy[j] * p.stride - p.pad_t + ky, sx = pox[j] * p.stride - p.pad_l + kx;
+      if (lrel < l_end_rel) {
+        int sy = poy[j] * st_ + dyoff, sx = pox[j] * st_ + dxoff;
         if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
-        if (xc_ok[j] && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
-          const int64_t pix = ((int64_t)pn[j] * p.H + sy) * p.W + sx;
-          if (!(p.src_mask && p.src_mask[pix] == 0.0f)) xs = x + pix * p.Cin + ci0 + lch[j] * EPC;
+        if (xc_ok[j] && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W) {
+          const int pix = (pn[j] * p.H + sy) * p.W + sx;
+          if (!(p.src_mask && p.src_mask[pix] == 0.0f))
+            xs = x + (int64_t)pix * p.Cin + ci0 + lch[j] * EPC;
         }
-        if (yc_ok[j]) ys = dy + l * p.Cout + co0 + lch[j] * EPC;
+        if (yc_ok[j]) ys = dy + (l_begin + lrel) * p.Cout + co0 + lch[j] * EPC;
       }
       const int slab = (j * 4 + wave) * RPI * ROWBYTES;   // wave-uniform
       __builtin_amdgcn_global_load_lds((gas_ptr)xs, (las_ptr)(xt + slab), 16, 0, 0);
@@ -1132,24 +1167,30 @@ int se3ds_conv2d_dgrad(const void* dy, const void* wn, void* dx, int dtype, int 
                      act_alpha, stream);
 }
 
-static int wgrad_splits(int64_t L, int64_t tiles) {
-  // Work items = tiles x splits, all of equal cost; ~512 run concurrently (2 per CU).  Aim for
-  // >= 4 rounds of work items so the last, partially filled round costs little, but keep at
-  // least 512 pixels (8 steps) per item and bound the partial-sum traffic.
-  int64_t want = (2048 + tiles - 1) / tiles;
-  int64_t max_by_l = L / 512;
-  if (max_by_l < 1) max_by_l = 1;
-  if (want > max_by_l) want = max_by_l;
-  if (want < 1) want = 1;
-  if (want > 256) want = 256;
-  return (int)want;
+static int wgrad_splits(int64_t L, int64_t tiles, int64_t nel) {
+  // Work items = tiles x splits, equal cost; ~512 run concurrently (2 per CU).  Cost model
+  // (microseconds): rounds of items x steps per item x time per 64-pixel step, plus the write +
+  // read of the fp32 partial slabs by the deterministic reduce.  Pick the cheapest split count.
+  const double kStepUs = 2.15, kBytesPerUs = 3.0e6, kSlots = 512.0;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 256; ++s) {
+    int64_t per = (L + s - 1) / s;
+    if (s > 1 && per < 256) break;
+    double steps = (double)((per + 63) / 64);
+    double rounds = (double)((tiles * s + (int64_t)kSlots - 1) / (int64_t)kSlots);
+    double cost = rounds * steps * kStepUs + (s > 1 ? 5.0 : 0.0) +
+                  (double)s * (double)nel * 8.0 / kBytesPerUs * (s > 1 ? 1.0 : 0.5);
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
 }
 
 size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int cout, int kh,
                                           int kw) {
   int64_t L = (int64_t)n * ho * wo;
   int64_t tiles = (int64_t)kh * kw * ceil_div(cin, 128) * ceil_div(cout, 128);
-  int splits = wgrad_splits(L, tiles);
+  int splits = wgrad_splits(L, tiles, (int64_t)kh * kw * cin * cout);
   return sizeof(float) * (size_t)splits * (size_t)kh * kw * cin * cout + 16;
 }
 
@@ -1172,7 +1213,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   p.ci_tiles = (int)ceil_div(cin, 128);
   const int64_t L = (int64_t)n * ho * wo;
   const int64_t tiles = (int64_t)kh * kw * p.ci_tiles * ceil_div(cout, 128);
-  p.splits = wgrad_splits(L, tiles);
+  p.splits = wgrad_splits(L, tiles, (int64_t)kh * kw * cin * cout);
   p.l_per_split = ceil_div(ceil_div(L, p.splits), WG_BL) * WG_BL;
   dim3 grid((unsigned)(kh * kw * p.ci_tiles), (unsigned)ceil_div(cout, 128), (unsigned)p.splits);
   hipStream_t s = as_stream(stream);
