@@ -277,7 +277,7 @@ int se3ds_head_bwd(const float* dy, const float* y, const void* x, int dtype, in
 /* out[n] = per-sample sum; mode 0: sum(a); 1: sum(|a-b|*m[p]); 2: count(0<a<1);
  * 3: sum(a*(1-b)).  a,b: (n,p,c); m: (n,p). */
 int se3ds_sample_sum(const float* a, const float* b, const float* m, int n, int64_t p, int c,
-                     int mode, float* out, void* stream);
+                     int mode, float* out, float* workspace /* n*256 floats */, void* stream);
 /* grad = coef[n]*sign(a-b)*w; mode 0: w = 1[0<b<1] (depth L1); mode 1: w = m*(1-m2) (wc). */
 int se3ds_l1_grad(const float* a, const float* b, const float* m, const float* m2,
                   const float* coef, int n, int64_t p, int c, int mode, float* grad, void* stream);

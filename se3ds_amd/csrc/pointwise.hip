@@ -344,17 +344,28 @@ __device__ __forceinline__ float block_sum(float v) {
 __global__ void __launch_bounds__(kB)
 sample_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
                   const float* __restrict__ m, int64_t P, int C, int mode,
-                  float* __restrict__ out) {
-  const int n = blockIdx.x;
+                  float* __restrict__ partial) {
+  // grid (chunks, N): partial[n][chunk]; summed by sample_sum_final_kernel (deterministic)
+  const int n = blockIdx.y;
   const int64_t total = P * C;
   float s = 0.f;
-  for (int64_t i = threadIdx.x; i < total; i += kB) {
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kB) {
     const int64_t idx = (int64_t)n * total + i;
     if (mode == 0) s += a[idx];
     else if (mode == 1) s += fabsf(a[idx] - b[idx]) * (m ? m[(int64_t)n * P + i / C] : 1.0f);
     else if (mode == 2) s += (a[idx] > 0.f && a[idx] < 1.f) ? 1.f : 0.f;
     else s += a[idx] * (1.0f - b[idx]);
   }
+  s = block_sum(s);
+  if (threadIdx.x == 0) partial[(int64_t)n * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(kB)
+sample_sum_final_kernel(const float* __restrict__ partial, int chunks, float* __restrict__ out) {
+  const int n = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < chunks; i += kB) s += partial[(int64_t)n * chunks + i];
   s = block_sum(s);
   if (threadIdx.x == 0) out[n] = s;
 }
@@ -606,10 +617,17 @@ int se3ds_head_bwd(const float* dy, const float* y, const void* x, int dtype, in
 }
 
 int se3ds_sample_sum(const float* a, const float* b, const float* m, int n, int64_t p, int c,
-                     int mode, float* out, void* stream) {
+                     int mode, float* out, float* workspace, void* stream) {
   if (n <= 0 || p <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
-  hipLaunchKernelGGL(sample_sum_kernel, dim3(n), dim3(kB), 0, as_stream(stream), a, b, m, p, c, mode,
-                     out);
+  if (!workspace) return SE3DS_E_WORKSPACE;   // n * 256 floats
+  constexpr int kChunks = 256;
+  int chunks = (int)ceil_div(p * c, (int64_t)kB * 8);
+  if (chunks > kChunks) chunks = kChunks;
+  if (chunks < 1) chunks = 1;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(sample_sum_kernel, dim3(chunks, n), dim3(kB), 0, s, a, b, m, p, c, mode,
+                     workspace);
+  hipLaunchKernelGGL(sample_sum_final_kernel, dim3(n), dim3(kB), 0, s, workspace, chunks, out);
   return check_launch("sample_sum");
 }
 

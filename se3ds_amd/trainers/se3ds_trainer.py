@@ -126,12 +126,14 @@ class GAN(gan_manager.GANManager):
     depth_out, generated = outs[3], outs[6]
 
     # ---- per-sample normalisers and loss sums
+    ssws = torch.empty(n * 256, **f32)  # scratch of the two-stage per-sample reductions
     npx = torch.empty(n, **f32)        # valid-depth pixel counts (:148-152)
     _lib.check(L.se3ds_sample_sum(depth_t.data_ptr(), None, None, n, p, 1, 2, npx.data_ptr(),
-                                  _lib.stream()), 'se3ds_sample_sum')
+                                  ssws.data_ptr(), _lib.stream()), 'se3ds_sample_sum')
     wcm = torch.empty(n, **f32)        # sum of proj_mask * (1 - blurred_mask) (:176-178)
     _lib.check(L.se3ds_sample_sum(inputs['proj_mask'].data_ptr(), inputs['blurred_mask'].data_ptr(),
-                                  None, n, p, 1, 3, wcm.data_ptr(), _lib.stream()),
+                                  None, n, p, 1, 3, wcm.data_ptr(), ssws.data_ptr(),
+                                  _lib.stream()),
                'se3ds_sample_sum')
     # gradient coefficients of the SUM over the (N,)-vector loss, already / replicas
     coef_depth = torch.empty(n, **f32)
@@ -156,14 +158,16 @@ class GAN(gan_manager.GANManager):
     _lib.check(L.se3ds_l1_grad(depth_t.data_ptr(), depth_t.data_ptr(), None, None, None, n, p, 1, 2,
                                tmask.data_ptr(), _lib.stream()), 'se3ds_l1_grad')
     _lib.check(L.se3ds_sample_sum(depth_out.data_ptr(), depth_t.data_ptr(), tmask.data_ptr(), n, p,
-                                  1, 1, depth_l1.data_ptr(), _lib.stream()), 'se3ds_sample_sum')
+                                  1, 1, depth_l1.data_ptr(), ssws.data_ptr(), _lib.stream()),
+               'se3ds_sample_sum')
     wc_l1 = torch.empty(n, **f32)
     wmask = torch.empty((n, p), **f32)
     _lib.check(L.se3ds_l1_grad(inputs['proj_mask'].data_ptr(), inputs['proj_mask'].data_ptr(),
                                inputs['proj_mask'].data_ptr(), inputs['blurred_mask'].data_ptr(),
                                None, n, p, 1, 3, wmask.data_ptr(), _lib.stream()), 'se3ds_l1_grad')
     _lib.check(L.se3ds_sample_sum(generated.data_ptr(), inputs['proj_image'].data_ptr(),
-                                  wmask.data_ptr(), n, p, 3, 1, wc_l1.data_ptr(), _lib.stream()),
+                                  wmask.data_ptr(), n, p, 3, 1, wc_l1.data_ptr(), ssws.data_ptr(),
+                                  _lib.stream()),
                'se3ds_sample_sum')
 
     # ---- discriminator forward on [fake; real]
