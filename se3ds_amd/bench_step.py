@@ -55,7 +55,7 @@ def build_gan(args, dev, world):
 
 def run(args, rank, world, dev, barrier, max_over_ranks):
   gan = build_gan(args, dev, world)
-  n = args.batch if args.batch > 0 else 4
+  n = args.batch if args.batch > 0 else 8
   h = args.image_size
   batch = synth_batch(n, h, 1234 + rank, dev)
   def step():
@@ -106,37 +106,51 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
       'hbm_gib_peak': torch.cuda.max_memory_allocated(dev) / 2**30,
   }
   if rank == 0 and not args.no_cpu_baseline:
-    out['cpu_baseline'] = cpu_baseline(args)
+    out['cpu_baseline'] = cpu_baseline(args, summ['flops'] / 1e12 / n)
   return out
 
 
-def cpu_baseline(args):
-  """The oracle (PyTorch-CPU fp32 restatement of the same step -- TF cannot run here) on a
-  bounded sample: ONE train_g_d sample at 128x256 with the full ResNet-101 / gen_dims-128
-  network, scaled to 512x1024 by the conv-FLOP ratio (16x)."""
+def cpu_baseline(args, tflop_per_sample):
+  """CPU baseline on a BOUNDED sample (~20 s): the PyTorch-CPU oracle's convolution
+  (oracle/nets_torch.tf_conv2d: the restatement of tf.nn.conv2d, fp32, oneDNN) forward +
+  backward on the three layer shapes that carry most of the step's FLOPs, at batch 1.  The
+  measured FLOP rate is converted to panoramas/s with the step's algorithmic conv FLOPs per
+  sample.  A port (TensorFlow cannot run here), not the reference; conv-only, so it flatters
+  the CPU (norms / optimiser are not charged)."""
   import torch as T
   from oracle import nets_torch as O
-  T.set_num_threads(os.cpu_count() or 1)
-  h = 128
-  gin_lite.clear_config()
-  G = image_models.ResNetGenerator(image_size=h, gen_dims=128, resnet_version='101', device='cpu',
-                                   seed=None)
-  D = image_models.SNMultiScaleDiscriminator(dis_dims=128, n_layers=6, n_dis=2, device='cpu',
-                                             seed=None)
-  gp = {k: v.detach() for k, v in G.store.views.items()}
-  dp = {k: v.detach() for k, v in D.store.views.items()}
-  batch = {k: v.cpu() for k, v in synth_batch(1, h, 1, 'cpu').items()}
-  cfg = dict(gen=dict(gen_dims=128, resnet_version='101', context_layer='convs', z_dim=128),
-             dis=dict(n_dis=2, n_layers=6, kernel_size=4), lambda_gan=1.0, lambda_kld=10.0,
-             lambda_wc=10.0, lambda_depth=100.0, mask_blurred=True,
-             g_train=lambda k: not k.endswith(('/u', '/moving_mean', '/moving_variance')),
-             d_train=lambda k: not k.endswith('/u'))
-  t0 = time.perf_counter()
-  O.train_g_d(gp, dp, batch, cfg)
-  dt = time.perf_counter() - t0
-  scale = (512 * 1024) / (h * 2 * h)
-  return {'value': 1.0 / (dt * scale), 'unit': 'panoramas/sec', 'cores': os.cpu_count(),
+  try:
+    cores = len(os.sched_getaffinity(0))
+  except AttributeError:
+    cores = os.cpu_count() or 1
+  threads = max(1, min(cores, 64))
+  T.set_num_threads(threads)
+  shapes = [  # (cin, cout, k, h, w, share of G forward FLOPs: SURVEY.md section 8d)
+      (1024, 1024, 3, 32, 64, 0.592), (128, 128, 3, 256, 512, 0.184), (512, 512, 3, 32, 64, 0.059)]
+  g = T.Generator().manual_seed(0)
+  inv_rate = 0.0
+  tot_share = sum(sh[-1] for sh in shapes)
+  desc = []
+  for cin, cout, k, h, w, share in shapes:
+    x = T.randn((1, h, w, cin), generator=g, requires_grad=True)
+    wgt = T.randn((k, k, cin, cout), generator=g, requires_grad=True)
+    flops = 3 * 2.0 * h * w * cin * cout * k * k   # fwd + dgrad + wgrad
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 1 or (time.perf_counter() - t0 < 6.0 and reps < 50):
+      y = O.tf_conv2d(O.pad_layer(x, 1), wgt, 1, 'VALID')
+      y.backward(T.ones_like(y))
+      x.grad = None
+      wgt.grad = None
+      reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    rate = flops / dt
+    inv_rate += (share / tot_share) / rate
+    desc.append(f'{k}x{k} {cin}->{cout}@{h}x{w}: {rate / 1e12:.3f} TFLOP/s')
+  rate = 1.0 / inv_rate
+  return {'value': rate / (tflop_per_sample * 1e12), 'unit': 'panoramas/sec', 'cores': threads,
           'kind': 'port',
-          'sample': f'1 train_g_d sample (fwd+bwd, no optimizer) at {h}x{2 * h}, full ResNet-101 '
-                    f'gen_dims=128 network, PyTorch-CPU fp32 oracle (not TF): {dt:.1f} s, scaled '
-                    f'x{scale:.0f} to 512x1024 by pixel count'}
+          'sample': 'PyTorch-CPU fp32 oracle conv fwd+bwd on 3 dominant layer shapes, batch 1, '
+                    '~6 s each (' + '; '.join(desc) + f'), FLOP-share-weighted rate '
+                    f'{rate / 1e12:.3f} TFLOP/s / {tflop_per_sample:.1f} TFLOP conv work per sample; '
+                    'conv-only (norms/optimiser not charged), not TF'}
