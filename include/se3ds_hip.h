@@ -187,6 +187,16 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
                        const float* row_scale, const float* out_scale, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight gradient of a THIN-Cout (cout <= 16), stride-1, same-size conv (the generator's
+ * 128->3 / 128->1 output convs, image_models.py:93-104) computed with the operand roles
+ * swapped: sum_l dy[l - tap, co] * x[l, ci] is the weight gradient of a conv whose INPUT is dy and
+ * whose output gradient is x, with the taps mirrored.  The thin operand then packs into one
+ * linear-K tile and x is streamed once instead of kh*kw times. */
+size_t se3ds_conv2d_wgrad_swapped_workspace_bytes(int n, int h, int w, int cin, int cout, int k);
+int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dtype, int n, int h,
+                               int w, int cin, int cout, int k, int pad, int accumulate,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* Partial-conv mask statistics -- models/layers.py:153-163: cnt = window sum of the mask
  * (n,h,w); ratio = kh*kw/(cnt+1e-6)*clip(cnt,0,1); um = clip(cnt,0,1); optionally
  * ru = ratio*um and bu = (1-ratio)*um (backward helpers).  All (n,ho,wo) fp32. */

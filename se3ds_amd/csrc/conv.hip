@@ -618,6 +618,7 @@ struct WgradParams {
   float* dw;                          // [split][kh*kw*Cin][Cout] fp32 partial sums
   int splits; int64_t l_per_split;    // pixels per split (multiple of 32)
   int ci_tiles;                       // ceil(Cin / 128)
+  int linear_k;                       // thin Cin: tile rows are the linear (tap, ci) index
 };
 
 constexpr int WG_BL = 32;               // reduction pixels per step
@@ -633,11 +634,15 @@ wgrad_kernel(const WgradParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tap = blockIdx.x / p.ci_tiles;
-  const int ci0 = (blockIdx.x - tap * p.ci_tiles) * 128;
+  // linear_k (thin Cin, e.g. the 5- and 4-channel input convs): the 128 tile rows are 128
+  // consecutive values of the linear index k = tap*Cin + ci, so ceil(K/128) tiles replace
+  // kh*kw tiles that would each use Cin of their 128 rows.
+  const int tap = p.linear_k ? 0 : blockIdx.x / p.ci_tiles;
+  const int ci0 = p.linear_k ? blockIdx.x * 128 : (blockIdx.x - tap * p.ci_tiles) * 128;
   const int co0 = blockIdx.y * 128;
   const int split = blockIdx.z;
   const int ky = tap / p.kw, kx = tap - ky * p.kw;
+  const int Ktot = p.kh * p.kw * p.Cin;
   const int64_t L = (int64_t)p.N * p.Ho * p.Wo;
   const int64_t l_begin = (int64_t)split * p.l_per_split;
   int64_t l_end = l_begin + p.l_per_split;
@@ -678,7 +683,25 @@ wgrad_kernel(const WgradParams p) {
       T xe[EPC], ye[EPC];
 #pragma unroll
       for (int e = 0; e < EPC; ++e) { xe[e] = tt::from_f(0.f); ye[e] = tt::from_f(0.f); }
-      if (l < l_end) {
+      if (l < l_end && p.linear_k) {
+        const int n = pn[q], oy = poy[q], ox = pox[q];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const int kk = ci0 + c + e;
+          if (kk < Ktot) {
+            const int t = kk / p.Cin, ci = kk - t * p.Cin;
+            const int tky = t / p.kw, tkx = t - tky * p.kw;
+            int sy = oy * p.stride - p.pad_t + tky, sx = ox * p.stride - p.pad_l + tkx;
+            if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
+            if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W) {
+              const int64_t pix = ((int64_t)n * p.H + sy) * p.W + sx;
+              float v = tt::to_f(x[pix * p.Cin + ci]);
+              if (p.src_mask) v *= p.src_mask[pix];
+              xe[e] = tt::from_f(v);
+            }
+          }
+        }
+      } else if (l < l_end) {
         const int n = pn[q], oy = poy[q], ox = pox[q];
         int sy = oy * p.stride - p.pad_t + ky, sx = ox * p.stride - p.pad_l + kx;
         if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
@@ -698,6 +721,8 @@ wgrad_kernel(const WgradParams p) {
             for (int e = 0; e < EPC; ++e) xe[e] = tt::from_f(tt::to_f(xe[e]) * mk);
           }
         }
+      }
+      if (l < l_end) {
         const T* ys = dy + l * p.Cout + co0 + c;
         if (vec_y && co0 + c + EPC <= p.Cout) {
           *reinterpret_cast<uint4*>(ye) = *reinterpret_cast<const uint4*>(ys);
@@ -814,8 +839,8 @@ wgrad_kernel(const WgradParams p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int ci = ci0 + wm * 64 + i * 32 + l32;
-    if (ci >= p.Cin) continue;
-    float* row = dw + ((int64_t)tap * p.Cin + ci) * p.Cout;
+    if (ci >= (p.linear_k ? Ktot : p.Cin)) continue;
+    float* row = dw + (p.linear_k ? (int64_t)ci : (int64_t)tap * p.Cin + ci) * p.Cout;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1031,6 +1056,22 @@ wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t n, int a
   }
 }
 
+// dW[(ky,kx),ci,co] = tmp[(k-1-ky, k-1-kx), co, ci]: finishes the role-swapped weight gradient
+// of thin-Cout stride-1 'same' convs (see se3ds_conv2d_wgrad_swapped in the header).
+__global__ void __launch_bounds__(256)
+wgrad_swap_fixup_kernel(const float* __restrict__ tmp, int k, int cin, int cout, int accumulate,
+                        float* __restrict__ out) {
+  const int total = k * k * cin * cout;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    int co = i % cout;
+    int ci = (i / cout) % cin;
+    int t = i / (cout * cin);
+    int ky = t / k, kx = t - ky * k;
+    float v = tmp[(((int64_t)(k - 1 - ky) * k + (k - 1 - kx)) * cout + co) * cin + ci];
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+
 // ------------------------------------------------------------------------ weight prep
 // fp32 master HWIO [K][Cout] -> compute-dtype copies: wt [Cout][K] (forward operand) and,
 // optionally, wn [K][Cout] (input-gradient operand).  32x32 LDS-tiled transpose.
@@ -1189,7 +1230,9 @@ static int wgrad_splits(int64_t L, int64_t tiles, int64_t nel) {
 size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int cout, int kh,
                                           int kw) {
   int64_t L = (int64_t)n * ho * wo;
-  int64_t tiles = (int64_t)kh * kw * ceil_div(cin, 128) * ceil_div(cout, 128);
+  int64_t row_tiles = cin <= 16 ? ceil_div((int64_t)kh * kw * cin, 128)
+                                : (int64_t)kh * kw * ceil_div(cin, 128);
+  int64_t tiles = row_tiles * ceil_div(cout, 128);
   int splits = wgrad_splits(L, tiles, (int64_t)kh * kw * cin * cout);
   return sizeof(float) * (size_t)splits * (size_t)kh * kw * cin * cout + 16;
 }
@@ -1211,14 +1254,17 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   p.wrap_w = wrap_w; p.src_mask = in_mask; p.mask_binary = in_mask_binary; p.row_scale = row_scale;
   p.dw = (float*)workspace;
   p.ci_tiles = (int)ceil_div(cin, 128);
+  p.linear_k = cin <= 16 ? 1 : 0;
   const int64_t L = (int64_t)n * ho * wo;
-  const int64_t tiles = (int64_t)kh * kw * p.ci_tiles * ceil_div(cout, 128);
+  const int64_t row_tiles = p.linear_k ? ceil_div((int64_t)kh * kw * cin, 128)
+                                       : (int64_t)kh * kw * p.ci_tiles;
+  const int64_t tiles = row_tiles * ceil_div(cout, 128);
   p.splits = wgrad_splits(L, tiles, (int64_t)kh * kw * cin * cout);
   p.l_per_split = ceil_div(ceil_div(L, p.splits), WG_BL) * WG_BL;
-  dim3 grid((unsigned)(kh * kw * p.ci_tiles), (unsigned)ceil_div(cout, 128), (unsigned)p.splits);
+  dim3 grid((unsigned)row_tiles, (unsigned)ceil_div(cout, 128), (unsigned)p.splits);
   hipStream_t s = as_stream(stream);
   const int epc = dtype == SE3DS_F32 ? 4 : 8;
-  const bool glds = !g_disable_glds && (in_mask == nullptr || in_mask_binary) &&
+  const bool glds = !g_disable_glds && !p.linear_k && (in_mask == nullptr || in_mask_binary) &&
                     row_scale == nullptr &&
                     (cin % epc) == 0 && (cout % epc) == 0;
   if (glds) {
@@ -1234,6 +1280,28 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nel, 256)), dim3(256), 0, s,
                      (const float*)workspace, p.splits, nel, accumulate, out_scale, dw);
   return check_launch("conv2d_wgrad");
+}
+
+size_t se3ds_conv2d_wgrad_swapped_workspace_bytes(int n, int h, int w, int cin, int cout, int k) {
+  return se3ds_conv2d_wgrad_workspace_bytes(n, h, w, cout, cin, k, k) +
+         sizeof(float) * (size_t)k * k * cin * cout + 64;
+}
+
+int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dtype, int n, int h,
+                               int w, int cin, int cout, int k, int pad, int accumulate,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (workspace_bytes < se3ds_conv2d_wgrad_swapped_workspace_bytes(n, h, w, cin, cout, k))
+    return SE3DS_E_WORKSPACE;
+  // tmp[(ky',kx'),co,ci] = wgrad of the conv with input dy (cout channels), output-grad x
+  float* tmp = (float*)workspace;
+  const size_t tmp_bytes = (sizeof(float) * (size_t)k * k * cin * cout + 63) / 64 * 64;
+  int rc = se3ds_conv2d_wgrad(dy, x, tmp, dtype, n, h, w, cout, h, w, cin, k, k, 1, k - 1 - pad,
+                              k - 1 - pad, 0, nullptr, 0, nullptr, nullptr, 0,
+                              (char*)workspace + tmp_bytes, workspace_bytes - tmp_bytes, stream);
+  if (rc != SE3DS_OK) return rc;
+  hipLaunchKernelGGL(wgrad_swap_fixup_kernel, dim3(grid_for((int64_t)k * k * cin * cout, 256)),
+                     dim3(256), 0, as_stream(stream), tmp, k, cin, cout, accumulate, dw);
+  return check_launch("conv2d_wgrad_swapped");
 }
 
 int se3ds_weight_prep(const float* w, int64_t k, int cout, int dtype, void* wt, void* wn,

@@ -237,16 +237,24 @@ class ConvProfiler:
     e.record()
     return e
 
-  def stop(self, kind, flops, e0):
+  def stop(self, kind, flops, e0, tag=None):
     e1 = torch.cuda.Event(enable_timing=True)
     e1.record()
-    self.records.append((kind, flops, e0, e1))
+    self.records.append((kind, flops, e0, e1, tag))
+
+  def by_shape(self):
+    torch.cuda.synchronize()
+    agg = {}
+    for kind, fl, e0, e1, tag in self.records:
+      a = agg.setdefault((kind, tag), [0.0, 0.0, 0])
+      a[0] += e0.elapsed_time(e1); a[1] += fl; a[2] += 1
+    return agg
 
   def summary(self):
     torch.cuda.synchronize()
     tot_ms = tot_fl = 0.0
     by = {}
-    for kind, fl, e0, e1 in self.records:
+    for kind, fl, e0, e1, _ in self.records:
       ms = e0.elapsed_time(e1)
       tot_ms += ms
       tot_fl += fl
@@ -269,15 +277,15 @@ def set_conv_profiler(p):
 class _Timed:
   """with _Timed(kind, flops): launch  -- no-op unless a profiler is installed."""
 
-  def __init__(self, kind, flops):
-    self.kind, self.flops = kind, flops
+  def __init__(self, kind, flops, tag=None):
+    self.kind, self.flops, self.tag = kind, flops, tag
 
   def __enter__(self):
     self.e0 = _PROF.start() if _PROF is not None else None
 
   def __exit__(self, *a):
     if _PROF is not None and self.e0 is not None:
-      _PROF.stop(self.kind, self.flops, self.e0)
+      _PROF.stop(self.kind, self.flops, self.e0, self.tag)
 
 
 def _global_ws(device, key, nbytes):
@@ -505,7 +513,8 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
   bias = layer.bias
   y = ctx.empty((n, ho, wo, layer.cout))
   flops = 2.0 * n * ho * wo * cin * layer.cout * k * k
-  with _Timed('fwd', flops):
+  tag = f'{k}x{k}s{s} {cin}->{layer.cout} @{ho}x{wo} n{n} {layer.kind}'
+  with _Timed('fwd', flops, tag):
     _chk(L.se3ds_conv2d_fwd(xd.data_ptr(), wt.data_ptr(), y.data_ptr(), ctx.code, n, h, w, cin,
                             ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
                             _lib.ptr(in_mask), 1 if ctx.binary_masks else 0, _lib.ptr(scale),
@@ -538,19 +547,31 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
         if bias is not None:
           _colsum(ctx, dy.data_ptr(), ctx.code, rows, layer.cout,
                   row_scale=bu if partial else None, out=st.grad_views[layer.name + '/bias'])
-        wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, layer.cout, k, k)
-        ws = _global_ws(ctx.device, 'wgrad', wsz)
         gk = st.grad_views[layer.name + '/kernel']
-        with _Timed('wgrad', flops):
-          _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dys.data_ptr(), gk.data_ptr(), ctx.code, n, h,
-                                    w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
-                                    1 if wrap else 0, _lib.ptr(in_mask),
-                                    1 if ctx.binary_masks else 0, _lib.ptr(row_scale),
-                                    None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
-               'se3ds_conv2d_wgrad')
+        thin_out = (layer.cout <= 16 and cin > 16 and s == 1 and ho == h and wo == w and
+                    pt == pl and not wrap and not partial)
+        if thin_out:
+          # 128->3 / 128->1 output convs: role-swapped weight gradient (x streamed once)
+          wsz = L.se3ds_conv2d_wgrad_swapped_workspace_bytes(n, h, w, cin, layer.cout, k)
+          ws = _global_ws(ctx.device, 'wgrad', wsz)
+          with _Timed('wgrad', flops, tag):
+            _chk(L.se3ds_conv2d_wgrad_swapped(xd.data_ptr(), dys.data_ptr(), gk.data_ptr(),
+                                              ctx.code, n, h, w, cin, layer.cout, k, pt, 0,
+                                              ws.data_ptr(), ws.numel(), _lib.stream()),
+                 'se3ds_conv2d_wgrad_swapped')
+        else:
+          wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, layer.cout, k, k)
+          ws = _global_ws(ctx.device, 'wgrad', wsz)
+          with _Timed('wgrad', flops, tag):
+            _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dys.data_ptr(), gk.data_ptr(), ctx.code, n, h,
+                                      w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
+                                      1 if wrap else 0, _lib.ptr(in_mask),
+                                      1 if ctx.binary_masks else 0, _lib.ptr(row_scale),
+                                      None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
+                 'se3ds_conv2d_wgrad')
       if x.requires_grad:
         dx = ctx.empty(xd.shape)
-        with _Timed('dgrad', flops):
+        with _Timed('dgrad', flops, tag):
           _chk(L.se3ds_conv2d_dgrad(dys.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h,
                                     w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
                                     1 if wrap else 0, _lib.ptr(row_scale), _lib.ptr(scale), None,

@@ -59,6 +59,8 @@ CONV_CASES = [
     ('plain', 4, 16, 4, 2, 'VALID', 2, False, True, False, 2, 32, 64),
     ('plain', 64, 1, 4, 1, 'SAME', 0, False, True, False, 2, 10, 18),
     ('plain', 8, 8, 3, 1, 'VALID', 1, False, False, False, 1, 12, 24),
+    ('spectral', 64, 3, 3, 1, 'VALID', 1, False, True, False, 2, 12, 20),   # thin Cout: swapped wgrad
+    ('plain', 32, 1, 3, 1, 'VALID', 1, False, True, False, 2, 20, 36),
 ]
 
 
