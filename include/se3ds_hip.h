@@ -312,6 +312,9 @@ int se3ds_multi_sqnorm(const float* grads, const int64_t* chunks, int64_t nchunk
 int se3ds_multi_clip_by_norm(float* grads, const int64_t* chunks, int64_t nchunks,
                              const float* sqnorm, int ntensors, float clip_norm,
                              float* mean_norm_out, void* stream);
+/* out[0] = mean over tensors of min-clipped norms (the grad_norm metrics, se3ds_trainer.py:239). */
+int se3ds_mean_clipped_norm(const float* sqnorm, int ntensors, float clip_norm, float* out,
+                            void* stream);
 /* Keras Adam (ResourceApplyAdam), `step` = iteration count t >= 1. */
 int se3ds_multi_adam_keras(float* params, const float* grads, float* m, float* v, int64_t n,
                            float lr, float beta1, float beta2, float eps, int64_t step,

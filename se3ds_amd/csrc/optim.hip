@@ -278,6 +278,14 @@ int se3ds_multi_clip_by_norm(float* grads, const int64_t* chunks, int64_t nchunk
   return check_launch("multi_clip_by_norm");
 }
 
+int se3ds_mean_clipped_norm(const float* sqnorm, int ntensors, float clip_norm, float* out,
+                            void* stream) {
+  if (ntensors <= 0) return SE3DS_OK;
+  hipLaunchKernelGGL(mean_clipped_norm_kernel, dim3(1), dim3(kB), 0, as_stream(stream), sqnorm,
+                     ntensors, clip_norm, out);
+  return check_launch("mean_clipped_norm");
+}
+
 int se3ds_multi_adam_keras(float* params, const float* grads, float* m, float* v, int64_t n,
                            float lr, float beta1, float beta2, float eps, int64_t step,
                            void* stream) {

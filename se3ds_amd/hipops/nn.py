@@ -108,6 +108,20 @@ class ParamStore:
   def to_dict(self):
     return {k: v.detach().cpu().numpy().copy() for k, v in self.views.items()}
 
+  def segments(self, prefixes):
+    """{prefix: (t0, t1, e0, e1)}: tensor-index and element ranges of the trainable tensors
+    whose name starts with `prefix + '/'` (modules are registered contiguously)."""
+    out = {}
+    for pre in prefixes:
+      idx = [i for i, n in enumerate(self.trainable_names) if n.startswith(pre + '/')]
+      if not idx:
+        continue
+      assert idx == list(range(idx[0], idx[-1] + 1)), f'{pre} is not contiguous'
+      o0 = self._off_tr[self.trainable_names[idx[0]]][0]
+      last = self._off_tr[self.trainable_names[idx[-1]]]
+      out[pre] = (idx[0], idx[-1] + 1, o0, last[0] + last[1])
+    return out
+
   def chunk_tables(self, chunk=65536):
     """(chunks int64 [nchunks,3], tensor_chunk_start int64 [T+1]) for the multi-tensor ops."""
     chunks, starts = [], [0]
@@ -193,6 +207,7 @@ class Ctx:
     # PartialConv masks hold only 0/1 (true for the reference's data pipeline and for every
     # update_mask derived from a binary mask).  Set False for fractional masks: exact, slower.
     self.binary_masks = True
+    self.on_segment = None    # callback(name): a top-level module's parameter gradients are final
     self.group = group
     self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) \
         else 1
@@ -216,6 +231,15 @@ class Ctx:
     tape, self.tape = self.tape, []
     for fn in reversed(tape):
       fn()
+
+  def mark_segment(self, name):
+    """Call BEFORE running a top-level module in the forward pass: in the backward pass the
+    marker fires after every op of that module, i.e. when its parameter gradients are final."""
+    if self.tape is not None:
+      def fire():
+        if self.on_segment is not None and self.param_grads:
+          self.on_segment(name)
+      self.tape.append(fire)
 
   def allreduce_sum(self, t):
     if self.world > 1:
@@ -451,12 +475,23 @@ class SpectralGroup:
                                           1 if training else 0, _lib.stream()),
            'se3ds_spectral_power_iter')
 
-  def backward_fixup(self):
+  def backward_fixup(self, prefix=None):
     """Only layers that convolve with W/sigma (SpectralConv); PartialSpectralConv computes
-    sigma but convolves with the raw kernel (layers.py:189-195)."""
-    if self.eff_table is not None:
-      _chk(_L().se3ds_spectral_bwd_fixup(self.eff_table.data_ptr(), self.eff_table.shape[0],
-                                         _lib.stream()), 'se3ds_spectral_bwd_fixup')
+    sigma but convolves with the raw kernel (layers.py:189-195).  `prefix` restricts the
+    fix-up to one top-level module (per-segment gradient synchronisation)."""
+    tab = self.eff_table
+    if tab is None:
+      return
+    if prefix is not None:
+      cache = self.__dict__.setdefault('_seg_tables', {})
+      if prefix not in cache:
+        rows = [j for j, i in enumerate(self._eff) if self.layers[i].name.startswith(prefix + '/')]
+        cache[prefix] = tab[rows].contiguous() if rows else None
+      tab = cache[prefix]
+      if tab is None:
+        return
+    _chk(_L().se3ds_spectral_bwd_fixup(tab.data_ptr(), tab.shape[0], _lib.stream()),
+         'se3ds_spectral_bwd_fixup')
 
 
 def mask_window(ctx, mask, n, h, w, ho, wo, k, stride, pad_t, pad_l, wrap, want_bwd):

@@ -214,6 +214,7 @@ class _Head:
 @gin.configurable
 class ResNetGenerator(_Model):
   """ResNet generator model with partial convs (reference :27-193)."""
+  SEGMENTS = ('encoder', 'decoder', 'depth_decoder', 'rgb_conv', 'depth_conv', 'context')
 
   def __init__(self, image_size: int = 256, gen_dims: int = 96, z_dim: int = 128,
                resnet_version: str = '50', context_layer: str = 'convs',
@@ -261,21 +262,27 @@ class ResNetGenerator(_Model):
     n, h, w, _ = x.shape
     mask = gm.to(torch.float32).reshape(n, h, w).contiguous()
     self.spectral.power_iteration(ctx.training)
+    ctx.mark_segment('encoder')
     hidden, skip = self.encoder(ctx, x, mask)
     taps = getattr(ctx, 'taps', None)
     if taps is not None:
       taps.update(b1=skip[0], s1=skip[1], s2=skip[2], s3=skip[3], enc=hidden)
     if self.context_layer == 'convs':
+      ctx.mark_segment('context')
       for i in range(4):
         hidden = self.ctx_bn[i](ctx, hidden)
         hidden = self.ctx_conv[i](ctx, hidden, pad=self.ctx_pad,
                                   act=ACT_LRELU if i < 3 else ACT_NONE, alpha=0.3)
     hh, hw = hidden.shape[1], hidden.shape[2]
+    ctx.mark_segment('decoder')
     out = self.decoder(ctx, hidden, skip)
+    ctx.mark_segment('depth_decoder')
     depth_out = self.depth_decoder(ctx, hidden, skip)
     if taps is not None:
       taps.update(ctx=hidden, dec=out, ddec=depth_out)
+    ctx.mark_segment('rgb_conv')
     rgb_pre = self.rgb_conv(ctx, out)
+    ctx.mark_segment('depth_conv')
     depth_pre = self.depth_conv(ctx, depth_out)
     rgb, push_rgb = nn.head(ctx, rgb_pre, 0)
     depth, push_depth = nn.head(ctx, depth_pre, 1)

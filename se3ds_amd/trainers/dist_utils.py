@@ -33,3 +33,32 @@ def shard_batch(batch: dict, rank: int, world: int) -> dict:
     b = n // world
     out[k] = v[rank * b:(rank + 1) * b]
   return out
+
+
+class GradSync:
+  """Overlaps the gradient all-reduce with the backward pass: as soon as a top-level module's
+  parameter gradients are final (and clipped, per replica and per tensor, as the reference does
+  before aggregation) its slice of the flat gradient arena is all-reduced on a side HIP stream
+  while the main stream keeps running backward kernels.  `finish()` joins the streams before
+  the optimiser reads the arena."""
+
+  def __init__(self, device, group=None, bucket_elems: int = GRAD_BUCKET_ELEMS):
+    self.device = torch.device(device)
+    self.group = group
+    self.bucket = bucket_elems
+    self.side = torch.cuda.Stream(device=self.device)
+    self.launched = []   # (e0, e1) ranges handed to the side stream this step (for tests)
+
+  def reduce_range(self, arena: torch.Tensor, e0: int, e1: int):
+    ready = torch.cuda.Event()
+    ready.record()   # on the main stream: the slice is clipped and final
+    with torch.cuda.stream(self.side):
+      self.side.wait_event(ready)
+      if world_size(self.group) > 1:
+        for o in range(e0, e1, self.bucket):
+          dist.all_reduce(arena[o:min(o + self.bucket, e1)], op=dist.ReduceOp.SUM, group=self.group)
+    self.launched.append((e0, e1))
+
+  def finish(self):
+    torch.cuda.current_stream(self.device).wait_stream(self.side)
+    self.launched = []

@@ -47,6 +47,7 @@ class AdamState:
     self.v = torch.zeros_like(model.store.theta)
     self.iterations = 0
     self.chunks, self.tensor_chunk_start = model.store.chunk_tables()
+    self._tcs_host = self.tensor_chunk_start.cpu().tolist()
     dev = model.store.theta.device
     self.partial = torch.empty(self.chunks.shape[0], dtype=torch.float32, device=dev)
     self.sqnorm = torch.empty(len(model.store.trainable_names), dtype=torch.float32, device=dev)
@@ -65,6 +66,33 @@ class AdamState:
                                           self.chunks.shape[0], self.sqnorm.data_ptr(), nt,
                                           float(clip_norm), self.mean_norm.data_ptr(),
                                           _lib.stream()), 'se3ds_multi_clip_by_norm')
+    return self.mean_norm
+
+  def clip_segment(self, t0, t1, clip_norm=5.0):
+    """clip_gradients restricted to tensors [t0, t1) (per-segment gradient synchronisation)."""
+    st = self.model.store
+    L = _lib.lib()
+    c0, c1 = self._tcs_host[t0], self._tcs_host[t1]
+    if c1 <= c0:
+      return
+    cache = self.__dict__.setdefault('_seg_tcs', {})
+    if (t0, t1) not in cache:   # chunk prefix of the segment, relative to its first chunk
+      cache[(t0, t1)] = (self.tensor_chunk_start[t0:t1 + 1] - c0).contiguous()
+    tcs = cache[(t0, t1)]
+    _lib.check(L.se3ds_multi_sqnorm(st.grad.data_ptr(), self.chunks.data_ptr() + 24 * c0, c1 - c0,
+                                    tcs.data_ptr(), t1 - t0, self.partial.data_ptr(),
+                                    self.sqnorm.data_ptr() + 4 * t0, _lib.stream()),
+               'se3ds_multi_sqnorm')
+    # chunk rows carry absolute tensor ids: sqnorm is passed from its base
+    _lib.check(L.se3ds_multi_clip_by_norm(st.grad.data_ptr(), self.chunks.data_ptr() + 24 * c0,
+                                          c1 - c0, self.sqnorm.data_ptr(), t1 - t0,
+                                          float(clip_norm), None, _lib.stream()),
+               'se3ds_multi_clip_by_norm')
+
+  def mean_clipped_norm(self, clip_norm=5.0):
+    _lib.check(_lib.lib().se3ds_mean_clipped_norm(
+        self.sqnorm.data_ptr(), len(self.model.store.trainable_names), float(clip_norm),
+        self.mean_norm.data_ptr(), _lib.stream()), 'se3ds_mean_clipped_norm')
     return self.mean_norm
 
   def apply_gradients(self, group=None, world=1):

@@ -12,6 +12,7 @@ Reference semantics kept on purpose:
   * `train_d` runs the generator in training mode outside any tape (BN moving statistics and
     spectral `u` advance on D-only steps too).
 """
+import os
 from typing import Dict
 
 import torch
@@ -21,6 +22,7 @@ from se3ds_amd import gin_lite as gin
 from se3ds_amd.hipops import nn
 from se3ds_amd.hipops.nn import Var
 from se3ds_amd.models import image_models  # noqa: F401  (gin references)
+from se3ds_amd.trainers import dist_utils
 from se3ds_amd.trainers import gan_manager
 from se3ds_amd.trainers.gan_manager import Mean
 
@@ -99,6 +101,28 @@ class GAN(gan_manager.GANManager):
       seeds_d.append(gd)
       seeds_g.append(gg)
     return sums, seeds_d, seeds_g
+
+  def _grad_sync(self):
+    """GradSync when gradients cross replicas (or SE3DS_FORCE_GRAD_SYNC=1, which exercises the
+    segment-wise clip / side-stream path on one GPU), else None."""
+    R = self.strategy.num_replicas_in_sync
+    if R == 1 and os.environ.get('SE3DS_FORCE_GRAD_SYNC') != '1':
+      return None
+    if getattr(self, '_sync', None) is None:
+      G = self.generator
+      self._sync = dist_utils.GradSync(G.store.theta.device, self.strategy.group)
+      self._g_segments = G.store.segments(G.SEGMENTS)
+      covered = sum(t1 - t0 for t0, t1, _, _ in self._g_segments.values())
+      assert covered == len(G.store.trainable_names), 'generator segments miss some tensors'
+    return self._sync
+
+  def _sync_discriminator(self, sync):
+    """Discriminator gradients are final after pass 1: clip, then all-reduce on the side
+    stream while the main stream runs pass 2 and the generator backward."""
+    D = self.discriminator
+    norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
+    sync.reduce_range(D.store.grad, 0, D.store.grad.numel())
+    return norm
 
   def _backward_tape(self, ctx, tape, seeds, logits):
     for sub, g in zip(logits, seeds):
@@ -187,6 +211,9 @@ class GAN(gan_manager.GANManager):
     self._set_input_grad(x_all, False)
     self._backward_tape(ctx_d, tape_d, seeds_d, logits)
     D.spectral.backward_fixup()
+    sync = self._grad_sync()
+    if sync is not None:
+      d_norm = self._sync_discriminator(sync)
     # ---- pass 2: gradient of the generator loss w.r.t. the fake images (gen_tape, :236)
     ctx_d.param_grads = False
     self._set_input_grad(x_all, True)
@@ -205,14 +232,31 @@ class GAN(gan_manager.GANManager):
     ctx_g.param_grads = True
     push_rgb(d_rgb)
     push_depth(d_depth)
-    ctx_g.backward()
-    G.spectral.backward_fixup()
-
     # ---- clip per tensor (per replica), aggregate, apply (:238-257)
-    g_norm = self.g_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
-    d_norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
-    self.g_optimizer.apply_gradients(group, R)
-    self.d_optimizer.apply_gradients(group, R)
+    if sync is None:
+      ctx_g.backward()
+      G.spectral.backward_fixup()
+      g_norm = self.g_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
+      d_norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
+      self.g_optimizer.apply_gradients(group, R)
+      self.d_optimizer.apply_gradients(group, R)
+    else:
+      # a module's gradients are fixed up, clipped and handed to the side stream as soon as
+      # the backward pass leaves it; the all-reduce overlaps the rest of the backward pass
+      def segment_done(name):
+        if name not in self._g_segments:
+          return
+        t0, t1, e0, e1 = self._g_segments[name]
+        G.spectral.backward_fixup(prefix=name)
+        self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM)
+        sync.reduce_range(G.store.grad, e0, e1)
+      ctx_g.on_segment = segment_done
+      ctx_g.backward()
+      ctx_g.on_segment = None
+      g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
+      sync.finish()
+      self.g_optimizer.apply_gradients(group, 1)
+      self.d_optimizer.apply_gradients(group, 1)
     if self.global_step == 0:
       # builds the EMA model's variables in the reference (:258-259): a throw-away forward
       self.ema_generator.forward(self.ema_generator.make_ctx(training=True, group=group), inputs)
@@ -268,5 +312,11 @@ class GAN(gan_manager.GANManager):
     self._set_input_grad(x_all, False)
     self._backward_tape(ctx_d, tape_d, seeds_d, logits)
     D.spectral.backward_fixup()
-    self.d_optimizer.clip_gradients(GRAD_CLIP_NORM)
-    self.d_optimizer.apply_gradients(group, R)
+    sync = self._grad_sync()
+    if sync is None:
+      self.d_optimizer.clip_gradients(GRAD_CLIP_NORM)
+      self.d_optimizer.apply_gradients(group, R)
+    else:
+      self._sync_discriminator(sync)
+      sync.finish()
+      self.d_optimizer.apply_gradients(group, 1)

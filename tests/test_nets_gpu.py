@@ -567,6 +567,36 @@ def test_bf16_step_runs_and_tracks_fp32():
     assert abs(a - b) <= 5e-2 * max(1.0, abs(a)), (key, a, b)
 
 
+def test_segment_grad_sync_matches_serial_path(monkeypatch):
+  """The overlapped path (per-module spectral fix-up -> per-tensor clip -> side-stream
+  all-reduce launched from inside the backward pass) must leave exactly the weights, Adam
+  slots and grad-norm metrics of the serial path."""
+  size = 64
+  batch = {k: v.to(DEV) for k, v in synth_batch(4, size, seed=81).items()}
+  res = {}
+  for mode in ('serial', 'overlap'):
+    if mode == 'overlap':
+      monkeypatch.setenv('SE3DS_FORCE_GRAD_SYNC', '1')
+    gan = _make_gan(size, 8, '50', 3)
+    gan.train_g_d(batch)
+    gan.global_step += 1
+    gan.train_d(batch)
+    gan.train_g_d(batch)
+    torch.cuda.synchronize()
+    if mode == 'overlap':
+      segs = gan._g_segments
+      assert set(segs) == {'encoder', 'decoder', 'depth_decoder', 'rgb_conv', 'depth_conv', 'context'}
+      assert sorted(v[2] for v in segs.values())[0] == 0
+    m = gan._save_metrics_to_dict()
+    res[mode] = (gan.generator.store.theta.clone(), gan.discriminator.store.theta.clone(),
+                 gan.g_optimizer.v.clone(), gan.d_optimizer.m.clone(),
+                 float(m['gen/grad_norm']), float(m['dis/grad_norm']))
+  for a, b in zip(res['serial'][:4], res['overlap'][:4]):
+    assert torch.equal(a, b)
+  assert res['serial'][4] == pytest.approx(res['overlap'][4], rel=1e-6)
+  assert res['serial'][5] == pytest.approx(res['overlap'][5], rel=1e-6)
+
+
 def test_split_input_dict_and_cluster():
   gan = _make_gan(64, 4, '50', 3)
   gan.d_step_per_g_step = 2
