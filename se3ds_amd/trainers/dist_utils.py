@@ -35,6 +35,13 @@ def shard_batch(batch: dict, rank: int, world: int) -> dict:
   return out
 
 
+def clone_group(group=None):
+  """A second process group (its own RCCL communicator and stream) over the same ranks.
+  Collective: every rank of `group` must call it at the same point."""
+  ranks = dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)
+  return dist.new_group(ranks=ranks)
+
+
 class GradSync:
   """Overlaps the gradient all-reduce with the backward pass: as soon as a top-level module's
   parameter gradients are final (and clipped, per replica and per tensor, as the reference does

@@ -110,7 +110,13 @@ class GAN(gan_manager.GANManager):
       return None
     if getattr(self, '_sync', None) is None:
       G = self.generator
-      self._sync = dist_utils.GradSync(G.store.theta.device, self.strategy.group)
+      group = self.strategy.group
+      if R > 1 and os.environ.get('SE3DS_GRAD_SYNC_SHARED_COMM') != '1':
+        # own communicator: the 4.5 GB of gradient traffic must not queue ahead of the small
+        # SyncBN statistics all-reduces the backward pass is waiting on (same issue order on
+        # every rank, so the two communicators cannot cross)
+        group = dist_utils.clone_group(group)
+      self._sync = dist_utils.GradSync(G.store.theta.device, group)
       self._g_segments = G.store.segments(G.SEGMENTS)
       covered = sum(t1 - t0 for t0, t1, _, _ in self._g_segments.values())
       assert covered == len(G.store.trainable_names), 'generator segments miss some tensors'

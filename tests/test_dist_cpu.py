@@ -63,6 +63,13 @@ def _worker(rank, world, port, mode, out):
       full = {'x': torch.arange(8).reshape(4, 2)}
       shard = dist_utils.shard_batch(full, rank, world)
       assert shard['x'].tolist() == [[4 * rank, 4 * rank + 1], [4 * rank + 2, 4 * rank + 3]]
+      # gradient traffic runs on its own communicator, interleaved with the default one
+      g2 = dist_utils.clone_group(None)
+      a = torch.full((300,), float(rank + 1))
+      b = torch.full((3,), float(rank + 1))
+      dist_utils.allreduce_arena_sum(a, g2, bucket_elems=128)
+      dist.all_reduce(b)
+      assert a.tolist() == [3.0] * 300 and b.tolist() == [3.0] * 3
     elif mode == 'replica_step':
       gp, dp = _toy_params()
       full = _batch(2, 64, 5)
