@@ -21,6 +21,8 @@
 // consecutive output channels of one pixel (8/16-byte stores).
 #include <stdlib.h>
 
+#include <cmath>
+#include <type_traits>
 #include "common.h"
 
 namespace se3ds {
@@ -122,18 +124,19 @@ struct RowInfo {
 };
 
 // Epilogue shared by the two implicit-GEMM kernels.
-// acc[i][j][r]: channel = n0 + wm*64 + i*32 + (r&3) + 8*(r>>2) + 4*half, pixel row = wn*64 + j*32 + l32
-template <typename T, int MODE>
-__device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)[2][2], int tile_m,
-                                           int n0, int64_t Mc, int cH, int cW, int py, int px,
-                                           int wm, int wn, int half, int l32) {
+// acc[i][j][r]: channel = co_base + i*32 + (r&3) + 8*(r>>2) + 4*half, pixel row = m_base + j*32 + l32
+// m_base / co_base: first pixel row / output channel of this wave's sub-tile.
+template <typename T, int MODE, int NI = 2>
+__device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)[NI][2],
+                                           int64_t m_base, int co_base, int64_t Mc, int cH, int cW,
+                                           int py, int px, int half, int l32) {
   using tt = TT<T>;
   const int s = p.stride;
   const float scale = p.scale ? *p.scale : 1.0f;
   T* __restrict__ out = (T*)p.out;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    int64_t m = (int64_t)tile_m * BM + wn * 64 + j * 32 + l32;
+    int64_t m = m_base + j * 32 + l32;
     if (m >= Mc) continue;
     int n = (int)(m / ((int64_t)cH * cW));
     int rem = (int)(m - (int64_t)n * cH * cW);
@@ -143,10 +146,10 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)
     const float ra = p.row_a ? p.row_a[opix] : 1.0f;
     const float rb = p.row_b ? p.row_b[opix] : 1.0f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int co = n0 + wm * 64 + i * 32 + g * 8 + half * 4;
+        const int co = co_base + i * 32 + g * 8 + half * 4;
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -397,7 +400,8 @@ igemm_kernel(const IgemmParams p) {
     __syncthreads();
   }
 
-  store_tile<T, MODE>(p, acc, tile_m, n0, Mc, cH, cW, py, px, wm, wn, half, l32);
+  store_tile<T, MODE>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py, px,
+                      half, l32);
 }
 
 // ------------------------------------------------------------------ LDS-DMA implicit GEMM
@@ -419,7 +423,11 @@ igemm_glds_kernel(const IgemmParams p) {
   using tt = TT<T>;
   constexpr int EPC = tt::EPC, BK2 = 2 * tt::BK;
   constexpr int ROW2 = 128, TILE2 = 128 * ROW2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE2];
+  // one LDS object per stage: the compiler's waitcnt pass tells LDS-DMA targets apart by the
+  // variable's alias scope; with a single array every fragment read waited (vmcnt(0)) for the
+  // DMA of the NEXT tile issued just before it, serialising fill and compute inside a wave
+  __shared__ __attribute__((aligned(16))) unsigned char stage0[2 * TILE2];
+  __shared__ __attribute__((aligned(16))) unsigned char stage1[2 * TILE2];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -469,22 +477,6 @@ igemm_glds_kernel(const IgemmParams p) {
   const T* __restrict__ wp = (const T*)p.w;
   const T* zero = reinterpret_cast<const T*>(g_zero_page);
 
-  auto src_pixel = [&](const RowInfo& r, int ky, int kx, int64_t& pix) -> bool {
-    int sy, sx;
-    if (MODE == MODE_FWD) {
-      sy = r.a * s - p.pad_t + ky;
-      sx = r.b * s - p.pad_l + kx;
-      if (p.wrap_w) { sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx); }
-    } else {
-      int ty = r.a + p.pad_t - ky, tx = r.b + p.pad_l - kx;
-      if (p.wrap_w) { tx = tx < 0 ? tx + p.sW : (tx >= p.sW ? tx - p.sW : tx); }
-      if (ty < 0 || tx < 0) return false;
-      sy = ty / s; sx = tx / s;
-    }
-    if (sy < 0 || sy >= p.sH || sx < 0 || sx >= p.sW) return false;
-    pix = ((int64_t)r.n * p.sH + sy) * p.sW + sx;
-    return true;
-  };
 
   const int ksteps_per_tap = Cr / BK2;
   const int nk = ntaps * ksteps_per_tap;
@@ -546,8 +538,7 @@ igemm_glds_kernel(const IgemmParams p) {
     }
     if (++tkx == nkx) { tkx = 0; ++tky; }
   };
-  auto issue = [&](int stage) {
-    unsigned char* wt = smem + stage * 2 * TILE2;
+  auto issue = [&](unsigned char* wt) {
     unsigned char* xt = wt + TILE2;
     const int c_off = cstep * BK2;
 #pragma unroll
@@ -574,15 +565,14 @@ igemm_glds_kernel(const IgemmParams p) {
 
   if (nk > 0) {
     setup_tap(0);
-    issue(0);
+    issue(stage0);
   }
   __syncthreads();   // drains the LDS-DMA of stage 0 (vmcnt(0)) before anyone reads it
   const int half = lane >> 5, l32 = lane & 31;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int stage = kt & 1;
-    if (kt + 1 < nk) issue(stage ^ 1);   // DMA for the next tile flies under the MFMAs below
-    const unsigned char* wt = smem + stage * 2 * TILE2;
-    const unsigned char* xt = wt + TILE2;
+  auto k_step = [&](unsigned char* cur, unsigned char* nxt, bool has_next) {
+    if (has_next) issue(nxt);   // DMA for the next tile flies under the MFMAs below
+    const unsigned char* wt = cur;
+    const unsigned char* xt = cur + TILE2;
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp) {
       uint4 wf[2][2], xf[2][2];
@@ -598,9 +588,241 @@ igemm_glds_kernel(const IgemmParams p) {
         }
       mfma_tile<T>(acc, wf, xf);
     }
-    __syncthreads();
+    __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done with `cur`
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    k_step(stage0, stage1, kt + 1 < nk);
+    if (kt + 1 < nk) k_step(stage1, stage0, kt + 2 < nk);
   }
-  store_tile<T, MODE>(p, acc, tile_m, n0, Mc, cH, cW, py, px, wm, wn, half, l32);
+  store_tile<T, MODE>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py, px,
+                      half, l32);
+}
+
+// ------------------------------------------------------------------ 256-pixel macro tiles
+// bf16 only.  256 pixels x CO (256 or 128) output channels per workgroup, 8 waves (2 channel
+// halves x 4 pixel quarters), K step 64, both operands by LDS-DMA into two stages (2 x 64 KiB
+// or 2 x 48 KiB of LDS): one workgroup per CU.  Measured on the 3x3 1024->1024 @32x64 layer the
+// LDS-DMA path delivers ~37 B/clk/CU, so the 128 x 128 tile (32 KiB per 2.1 MFLOP K step) is
+// fill-bound; this tile doubles (CO = 128: x1.33) the FLOPs per byte filled and, with a
+// 128 x 64 wave tile, needs 0.75 fragment reads per MFMA instead of 1.  Requires oC % CO == 0
+// and reduction channels % 64 == 0, and the same gather restrictions as igemm_glds_kernel.
+template <int MODE, int CO>
+__global__ void __launch_bounds__(512)
+igemm_big_kernel(const IgemmParams p) {
+  typedef uint16_t T;
+  constexpr int EPC = 8, BK2 = 64, ROW2 = 128, PIX = 256;
+  constexpr int WT = CO * ROW2, XT = PIX * ROW2, STAGE = WT + XT;
+  constexpr int NI = CO / 64;   // 32-channel MFMA blocks per wave
+  constexpr int WS = CO / 64;   // weight LDS-DMA instructions per wave and K step
+  // two separate LDS objects: the compiler's waitcnt pass tells LDS-DMA targets apart by the
+  // alias scope of the variable, so fragment reads of one stage do not wait (vmcnt(0)) for the
+  // DMA still filling the other
+  __shared__ __attribute__((aligned(16))) unsigned char stage0[STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char stage1[STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int cls = 0;
+  if (MODE == MODE_DGRAD) {
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+      if (c < p.n_classes && (int)blockIdx.x >= p.cls_tile_start[c]) cls = c;
+  }
+  const int tile_m = blockIdx.x - p.cls_tile_start[cls];
+  const int n0 = blockIdx.y * CO;
+  const int s = p.stride;
+  int py = 0, px = 0, cH = p.oH, cW = p.oW;
+  int ky0 = 0, kx0 = 0, kstep = 1, nky = p.kh, nkx = p.kw;
+  if (MODE == MODE_DGRAD) {
+    py = p.cls_py[cls]; px = p.cls_px[cls];
+    cH = (p.oH - py + s - 1) / s;
+    cW = (p.oW - px + s - 1) / s;
+    ky0 = (py + p.pad_t) % s; kx0 = (px + p.pad_l) % s; kstep = s;
+    nky = ky0 < p.kh ? (p.kh - ky0 + s - 1) / s : 0;
+    nkx = kx0 < p.kw ? (p.kw - kx0 + s - 1) / s : 0;
+  }
+  const int64_t Mc = (int64_t)p.N * cH * cW;
+  const int ntaps = nky * nkx;
+  const int Cr = p.sC;
+  const T* __restrict__ src = (const T*)p.src;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page);
+
+  // staging: instruction j of this wave fills rows (j*8 + wave)*8 .. +7 of an operand tile;
+  // the swizzled chunk a lane fetches is the same for every j ((row >> 1) & 7 has period 16 rows)
+  const int lrow = lane >> 3;
+  const int lch = (lane & 7) ^ (((wave * 8 + lrow) >> 1) & 7);
+  // per-slot gather constants (see igemm_glds_kernel); rows past the end of the pixel list get
+  // an a0 that fails every bounds test
+  int a0[4], b0[4], img0[4];
+  const int sshift = s == 2 ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = (j * 8 + wave) * 8 + lrow;
+    const int64_t m = (int64_t)tile_m * PIX + row;
+    const bool valid = m < Mc;
+    const int64_t mm = valid ? m : 0;
+    const int n = (int)(mm / ((int64_t)cH * cW));
+    const int rem = (int)(mm - (int64_t)n * cH * cW);
+    int a = rem / cW, b = rem - a * cW;
+    if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
+    a0[j] = MODE == MODE_FWD ? a * s - p.pad_t : a + p.pad_t;
+    b0[j] = MODE == MODE_FWD ? b * s - p.pad_l : b + p.pad_l;
+    if (!valid) a0[j] = MODE == MODE_FWD ? (1 << 28) : -(1 << 28);
+    img0[j] = n * p.sH * p.sW;
+  }
+  // weights: every channel row of the tile exists (oC % CO == 0)
+  const T* wbase = (const T*)p.w + (int64_t)(n0 + wave * 8 + lrow) * p.w_n + lch * EPC;
+  const int64_t wjs = 64 * p.w_n;
+
+  const int ksteps_per_tap = Cr / BK2;
+  const int nk = ntaps * ksteps_per_tap;
+  const T* xsrc[4];
+  int xm[4];
+  int64_t wtap = 0;
+  int tap_i = 0, cstep = 0, tky = 0, tkx = 0;
+  auto setup_tap = [&]() {
+    const int ky = ky0 + kstep * tky, kx = kx0 + kstep * tkx;
+    wtap = (int64_t)(ky * p.kw + kx) * p.w_tap;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int sy, sx;
+      bool ok = true;
+      if (MODE == MODE_FWD) {
+        sy = a0[j] + ky;
+        sx = b0[j] + kx;
+        if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+      } else {
+        int ty = a0[j] - ky, tx = b0[j] - kx;
+        if (p.wrap_w) tx = tx < 0 ? tx + p.sW : (tx >= p.sW ? tx - p.sW : tx);
+        ok = ty >= 0 && tx >= 0;
+        sy = ty >> sshift;
+        sx = tx >> sshift;
+      }
+      ok = ok && (unsigned)sy < (unsigned)p.sH && (unsigned)sx < (unsigned)p.sW;
+      const int pix = img0[j] + sy * p.sW + sx;
+      if (ok && p.src_mask) ok = p.src_mask[pix] != 0.0f;
+      if (ok) {
+        xsrc[j] = src + (int64_t)pix * Cr + lch * EPC;
+        xm[j] = -1;
+      } else {
+        xsrc[j] = zero + lch * EPC;
+        xm[j] = 0;
+      }
+    }
+    if (++tkx == nkx) { tkx = 0; ++tky; }
+  };
+  // One staging slot = one weight piece (if j < WS) + one pixel piece of the next tile.
+  auto issue_slot = [&](unsigned char* wt, int j) {
+    unsigned char* xt = wt + WT;
+    const int c_off = cstep * BK2;
+    const int slab = (j * 8 + wave) * 8 * ROW2;   // wave-uniform LDS byte offset
+    if (j < WS)
+      __builtin_amdgcn_global_load_lds((gas_ptr)(wbase + wtap + c_off + j * wjs),
+                                       (las_ptr)(wt + slab), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gas_ptr)(xsrc[j] + (c_off & xm[j])), (las_ptr)(xt + slab),
+                                     16, 0, 0);
+  };
+  auto issue_advance = [&]() {
+    if (++cstep == ksteps_per_tap) {
+      cstep = 0;
+      if (++tap_i < ntaps) setup_tap();
+    }
+  };
+
+  f32x16_t acc[NI][2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    setup_tap();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_slot(stage0, j);
+    issue_advance();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const int half = lane >> 5, l32 = lane & 31;
+  const int wrow0 = wm * (CO / 2) + l32, xrow0 = wn * 64 + l32;
+  // (row >> 1) & 7 is unchanged by adding multiples of 32 rows: one swizzle term per operand
+  const int wsw = (wrow0 >> 1) & 7, xsw = (xrow0 >> 1) & 7;
+
+  // Ping-pong schedule.  A K step is NP phases; a phase is a READ slot (fragment ds_reads for 8
+  // MFMAs, plus LDS-DMA issue for the next tile) and an MFMA slot (8 MFMAs = 256 pipe cycles),
+  // each closed by a workgroup barrier.  Channel half 1 (waves 4-7) starts one barrier late, so
+  // on every SIMD one wave is in its MFMA slot while the other reads / issues: the MFMA pipe is
+  // fed continuously although an LDS-DMA piece blocks its wave's issue for 60-180 cycles.
+  // (With all 8 waves in lock step the pipe idles ~800 cycles per K step during DMA issue and
+  // again while every wave waits for its fragments.)
+  //   stage hand-off: tile t+1 is DMA'd into the other stage during the first read slots of
+  //   K step t (that stage was last read in K step t-1; the lagging half's last reads are
+  //   retired by the lgkmcnt(0) in front of the barrier that ends its final read slot).  Every
+  //   wave waits for its own pieces (vmcnt(0)) in the last read slot of K step t, in front of a
+  //   barrier that all readers of tile t+1 pass before their first read of it.
+  constexpr int QP = 8 / (2 * NI);   // 16-deep MFMA steps per phase: 1 (CO 256) or 2 (CO 128)
+  constexpr int NP = 4 / QP;         // phases per K step
+  if (wm == 1) __builtin_amdgcn_s_barrier();
+  auto k_step = [&](unsigned char* cur, unsigned char* nxt, const bool has_next) {
+    const unsigned char* wt = cur + wrow0 * ROW2;
+    const unsigned char* xt = cur + WT + xrow0 * ROW2;
+#pragma unroll
+    for (int ph = 0; ph < NP; ++ph) {
+      // ---- read slot
+      uint4 wf[QP][NI], xf[QP][2];
+#pragma unroll
+      for (int qq = 0; qq < QP; ++qq) {
+        const int c = (ph * QP + qq) * 2 + half;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          wf[qq][i] = *reinterpret_cast<const uint4*>(wt + i * 32 * ROW2 + ((c ^ wsw) * 16));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          xf[qq][j] = *reinterpret_cast<const uint4*>(xt + j * 32 * ROW2 + ((c ^ xsw) * 16));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) {
+        if (NP == 4 && ph < 2) {
+          issue_slot(nxt, 2 * ph);
+          issue_slot(nxt, 2 * ph + 1);
+        }
+        if (NP == 2 && ph == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) issue_slot(nxt, j);
+        }
+        if (ph == NP / 2) issue_advance();
+      }
+      if (ph == NP - 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // ---- MFMA slot
+#pragma unroll
+      for (int qq = 0; qq < QP; ++qq)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8_t, wf[qq][i]), __builtin_bit_cast(bf16x8_t, xf[qq][j]),
+                acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    k_step(stage0, stage1, kt + 1 < nk);
+    if (kt + 1 < nk) k_step(stage1, stage0, kt + 2 < nk);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the late start of channel half 1
+  store_tile<T, MODE, NI>(p, acc, (int64_t)tile_m * PIX + wn * 64, n0 + wm * (CO / 2), Mc, cH, cW,
+                          py, px, half, l32);
 }
 
 // ------------------------------------------------------------------------------- wgrad
@@ -877,7 +1099,9 @@ wgrad_glds_kernel(const WgradParams p) {
   constexpr int RPI = 64 / CPR;                         // rows per wave instruction: 4 / 2
   constexpr int NI = BL / RPI / 4;                      // instructions per wave per operand: 4
   constexpr int TILE = BL * ROWBYTES;                   // 16 KiB
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+  // one LDS object per stage (see igemm_glds_kernel)
+  __shared__ __attribute__((aligned(16))) unsigned char stage0[2 * TILE];
+  __shared__ __attribute__((aligned(16))) unsigned char stage1[2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -919,8 +1143,7 @@ wgrad_glds_kernel(const WgradParams p) {
   const int dyoff = ky - p.pad_t, dxoff = kx - p.pad_l;
   const int st_ = p.stride;
   const int l_end_rel = (int)(l_end - l_begin);
-  auto issue = [&](int st, int stage) {
-    unsigned char* xt = smem + stage * 2 * TILE;
+  auto issue = [&](int st, unsigned char* xt) {
     unsigned char* yt = xt + TILE;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
@@ -956,13 +1179,12 @@ wgrad_glds_kernel(const WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nsteps > 0) issue(0, 0);
+  if (nsteps > 0) issue(0, stage0);
   __syncthreads();
   const int half = lane >> 5, l32 = lane & 31;
-  for (int st = 0; st < nsteps; ++st) {
-    const int stage = st & 1;
-    if (st + 1 < nsteps) issue(st + 1, stage ^ 1);
-    const unsigned char* xt = smem + stage * 2 * TILE;
+  auto l_step = [&](int st, unsigned char* cur, unsigned char* nxt) {
+    if (st + 1 < nsteps) issue(st + 1, nxt);
+    const unsigned char* xt = cur;
     const unsigned char* yt = xt + TILE;
     if (sizeof(T) == 2) {
       const int g16 = (lane >> 4) & 1, i16 = lane & 15;
@@ -1018,6 +1240,10 @@ wgrad_glds_kernel(const WgradParams p) {
       }
     }
     __syncthreads();
+  };
+  for (int st = 0; st < nsteps; st += 2) {
+    l_step(st, stage0, stage1);
+    if (st + 1 < nsteps) l_step(st + 1, stage1, stage0);
   }
   const int64_t K = (int64_t)p.kh * p.kw * p.Cin;
   float* __restrict__ dw = p.dw + (int64_t)split * K * p.Cout;
@@ -1098,14 +1324,14 @@ weight_prep_kernel(const float* __restrict__ w, int64_t K, int Cout, T* __restri
   }
 }
 
-int fill_classes(IgemmParams& p, int mode) {
+int fill_classes(IgemmParams& p, int mode, int bm = BM) {
   int total = 0;
   if (mode == MODE_FWD) {
     p.n_classes = 1;
     p.cls_py[0] = p.cls_px[0] = 0;
     p.cls_tile_start[0] = 0;
     int64_t m = (int64_t)p.N * p.oH * p.oW;
-    total = (int)ceil_div(m, BM);
+    total = (int)ceil_div(m, bm);
     p.cls_tile_start[1] = total;
     return total;
   }
@@ -1119,7 +1345,7 @@ int fill_classes(IgemmParams& p, int mode) {
       int cH = (p.oH - py + s - 1) / s, cW = (p.oW - px + s - 1) / s;
       if (cH < 0) cH = 0;
       if (cW < 0) cW = 0;
-      total += (int)ceil_div((int64_t)p.N * cH * cW, BM);
+      total += (int)ceil_div((int64_t)p.N * cH * cW, bm);
     }
   p.cls_tile_start[c] = total;
   return total;
@@ -1131,6 +1357,37 @@ int fill_classes(IgemmParams& p, int mode) {
 using namespace se3ds;
 
 static const bool g_disable_glds = getenv("SE3DS_NO_GLDS") != nullptr;
+
+// SE3DS_BIG_TILE: unset = cost model below, 0 = never, 1 = whenever the shape allows (read per
+// call so that tests can switch it).
+static int big_tile_mode() {
+  const char* e = getenv("SE3DS_BIG_TILE");
+  return e ? atoi(e) : -1;
+}
+
+// Output channels per 256-pixel macro tile (256 / 128) or 0 for the 128 x 128 kernel.  The macro
+// tile runs one workgroup per CU at about 1.5x the per-CU rate of two resident 128 x 128 tiles,
+// so it wins unless its coarser grid leaves CUs idle in the last round.
+static int big_tile_channels(const IgemmParams& p, int mode) {
+  const int g_big_tile = big_tile_mode();
+  if (g_big_tile == 0) return 0;
+  const int co = (p.oC % 256) == 0 ? 256 : ((p.oC % 128) == 0 ? 128 : 0);
+  if (!co) return 0;
+  if (g_big_tile == 1) return co;
+  int64_t m = 0;   // pixel rows over all parity classes
+  const int s = mode == MODE_FWD ? 1 : p.stride;
+  for (int py = 0; py < s; ++py)
+    for (int px = 0; px < s; ++px)
+      m += (int64_t)p.N * ((p.oH - py + s - 1) / s) * ((p.oW - px + s - 1) / s);
+  const double kCus = 256.0;
+  const double big_items = (double)ceil_div(m, (int64_t)256) * (p.oC / co);
+  const double small_items = (double)ceil_div(m, (int64_t)128) * ceil_div(p.oC, 128);
+  const double gain = co == 256 ? 1.5 : 1.2;
+  // time in units of one 128 x 128 tile on a CU that holds two of them
+  const double t_small = std::ceil(small_items / (2 * kCus)) * 2.0;
+  const double t_big = std::ceil(big_items / kCus) * (co == 256 ? 4.0 : 2.0) / gain;
+  return t_big < t_small ? co : 0;
+}
 
 extern "C" {
 
@@ -1162,12 +1419,28 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
     p.w_tap = (int64_t)cin * cout; p.w_n = cout;    // wn [K][Cout]
   }
   p.vec = (p.sC % bk) == 0;
-  int tiles = fill_classes(p, mode);
-  if (tiles <= 0) return SE3DS_OK;
-  dim3 grid((unsigned)tiles, (unsigned)ceil_div(p.oC, BN));
   hipStream_t s = as_stream(stream);
   const bool glds = (p.sC % (2 * bk)) == 0 && (src_mask == nullptr || mask_binary) &&
                     !g_disable_glds;
+  if (glds && dtype == SE3DS_BF16) {
+    const int co = big_tile_channels(p, mode);
+    if (co) {
+      const int tiles = fill_classes(p, mode, 256);
+      if (tiles <= 0) return SE3DS_OK;
+      dim3 grid((unsigned)tiles, (unsigned)(p.oC / co));
+      if (co == 256) {
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_big_kernel<MODE_FWD, 256>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 256>), grid, dim3(512), 0, s, p);
+      } else {
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_big_kernel<MODE_FWD, 128>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 128>), grid, dim3(512), 0, s, p);
+      }
+      return check_launch(mode == MODE_FWD ? "conv2d_fwd(big)" : "conv2d_dgrad(big)");
+    }
+  }
+  int tiles = fill_classes(p, mode);
+  if (tiles <= 0) return SE3DS_OK;
+  dim3 grid((unsigned)tiles, (unsigned)ceil_div(p.oC, BN));
   if (glds) {
     if (dtype == SE3DS_F32) {
       if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_glds_kernel<float, MODE_FWD>), grid, dim3(kThreads), 0, s, p);

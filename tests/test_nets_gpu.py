@@ -64,9 +64,39 @@ CONV_CASES = [
 ]
 
 
+# shapes the 256-pixel macro-tile kernels accept (bf16, Cout % 128 == 0 and/or Cin % 128 == 0 for
+# the data gradient, reduction channels % 64 == 0); run with SE3DS_BIG_TILE=1 so that the cost
+# model cannot route these small problems back to the 128 x 128 kernel
+BIG_TILE_CASES = [
+    ('spectral', 64, 256, 3, 1, 'VALID', 1, False, True, False, 2, 16, 32),
+    ('plain', 128, 128, 3, 1, 'VALID', 1, True, False, False, 1, 16, 32),      # circular width
+    ('spectral', 256, 256, 1, 1, 'SAME', 0, False, True, False, 2, 9, 17),     # ragged pixel tiles
+    ('spectral', 128, 256, 4, 2, 'VALID', 2, False, True, False, 2, 18, 34),   # parity classes
+    ('partial_spectral', 64, 128, 3, 2, 'VALID', 1, False, True, True, 2, 16, 32),
+    ('partial_spectral', 128, 128, 3, 1, 'VALID', 1, False, True, True, 2, 16, 32),
+    ('plain', 512, 256, 3, 1, 'VALID', 1, False, True, False, 3, 11, 23),      # several taps x K steps
+]
+
+
+@pytest.mark.parametrize('case', BIG_TILE_CASES)
+def test_conv_macro_tile_fwd_bwd(case, monkeypatch):
+  monkeypatch.setenv('SE3DS_BIG_TILE', '1')
+  _run_conv_case(case, torch.bfloat16)
+
+
+@pytest.mark.parametrize('k,cin,cout', [(3, 128, 128), (2, 64, 256)])
+def test_conv_transpose_macro_tile(k, cin, cout, monkeypatch):
+  monkeypatch.setenv('SE3DS_BIG_TILE', '1')
+  test_conv_transpose_fwd_bwd(k, cin, cout, True, torch.bfloat16)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_fwd_bwd(case, dtype):
+  _run_conv_case(case, dtype)
+
+
+def _run_conv_case(case, dtype):
   kind, cin, cout, k, stride, padding, pad, wrap, bias, use_mask, n, h, w = case
   store, layer, sg = _mk_layer(kind, cin, cout, k, stride, padding, bias, 7)
   gen = torch.Generator().manual_seed(11)

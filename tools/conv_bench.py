@@ -24,6 +24,8 @@ for name, cin, cout, k, s, h, w, pad in shapes:
   store.finalize(DEV, torch.Generator(device=DEV).manual_seed(1))
   ctx = nn.Ctx(DEV, dtype, training=True, record=True)
   x = nn.Var(torch.randn((N, h, w, cin), device=DEV).to(dtype))
+  if os.environ.get('ZERO'):
+    x.data.zero_(); store.theta.zero_()
   flops = None
   res = {}
   for it in range(3):
