@@ -74,6 +74,7 @@ struct IgemmParams {
   const float* row_b;     // (N*oH*oW) update_mask or null (only with bias)
   int act; float act_alpha;  // 0 none, 1 relu, 2 leaky relu
   int vec;                // reduction channels % BK == 0 -> vector gather
+  int halo_ty, halo_tx;   // igemm_halo_kernel: output tiles per image (rows of 8, columns of 32)
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
@@ -123,17 +124,61 @@ struct RowInfo {
   bool valid;
 };
 
-// Epilogue shared by the two implicit-GEMM kernels.
+// Epilogue shared by the implicit-GEMM kernels.
 // acc[i][j][r]: channel = co_base + i*32 + (r&3) + 8*(r>>2) + 4*half, pixel row = m_base + j*32 + l32
+// store_pixel writes the NI*16 channels this lane holds for pixel column j to output pixel opix.
+template <typename T, int NI>
+__device__ __forceinline__ void store_pixel(const IgemmParams& p, f32x16_t (&acc)[NI][2], int j,
+                                            int64_t opix, int co_base, int half, float scale) {
+  using tt = TT<T>;
+  T* __restrict__ out = (T*)p.out;
+  const float ra = p.row_a ? p.row_a[opix] : 1.0f;
+  const float rb = p.row_b ? p.row_b[opix] : 1.0f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int co = co_base + i * 32 + g * 8 + half * 4;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t = acc[i][j][g * 4 + e] * scale;
+        const float bv = (p.bias && co + e < p.oC) ? p.bias[co + e] : 0.0f;
+        if (p.row_a) {
+          if (p.bias) t = ((t - bv) * ra + bv) * rb;
+          else t = t * ra;
+        } else if (p.bias) {
+          t = t + bv;
+        }
+        if (p.act == 1) t = t > 0.f ? t : 0.f;
+        else if (p.act == 2) t = t > 0.f ? t : t * p.act_alpha;
+        v[e] = t;
+      }
+      T* o = out + opix * p.oC + co;
+      if (co + 3 < p.oC && (p.oC & 3) == 0) {
+        if (sizeof(T) == 4) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 pk;
+          pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+          pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+          *reinterpret_cast<uint2*>(o) = pk;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < p.oC) o[e] = tt::from_f(v[e]);
+      }
+    }
+}
+
 // m_base / co_base: first pixel row / output channel of this wave's sub-tile.
 template <typename T, int MODE, int NI = 2>
 __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)[NI][2],
                                            int64_t m_base, int co_base, int64_t Mc, int cH, int cW,
                                            int py, int px, int half, int l32) {
-  using tt = TT<T>;
   const int s = p.stride;
   const float scale = p.scale ? *p.scale : 1.0f;
-  T* __restrict__ out = (T*)p.out;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     int64_t m = m_base + j * 32 + l32;
@@ -143,44 +188,7 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)
     int a = rem / cW, b = rem - a * cW;
     if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
     const int64_t opix = ((int64_t)n * p.oH + a) * p.oW + b;
-    const float ra = p.row_a ? p.row_a[opix] : 1.0f;
-    const float rb = p.row_b ? p.row_b[opix] : 1.0f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = co_base + i * 32 + g * 8 + half * 4;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = acc[i][j][g * 4 + e] * scale;
-          const float bv = (p.bias && co + e < p.oC) ? p.bias[co + e] : 0.0f;
-          if (p.row_a) {
-            if (p.bias) t = ((t - bv) * ra + bv) * rb;
-            else t = t * ra;
-          } else if (p.bias) {
-            t = t + bv;
-          }
-          if (p.act == 1) t = t > 0.f ? t : 0.f;
-          else if (p.act == 2) t = t > 0.f ? t : t * p.act_alpha;
-          v[e] = t;
-        }
-        T* o = out + opix * p.oC + co;
-        if (co + 3 < p.oC && (p.oC & 3) == 0) {
-          if (sizeof(T) == 4) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2*>(o) = pk;
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (co + e < p.oC) o[e] = tt::from_f(v[e]);
-        }
-      }
+    store_pixel<T, NI>(p, acc, j, opix, co_base, half, scale);
   }
 }
 
@@ -825,6 +833,229 @@ igemm_big_kernel(const IgemmParams p) {
                           py, px, half, l32);
 }
 
+// ------------------------------------------------------------------ halo-resident 3x3 tiles
+// Stride-1 3x3 convolutions (forward and data gradient), bf16.  The 256 output pixels of a
+// workgroup are an 8 x 32 patch of one image, so the nine taps read nine shifted views of ONE
+// (8+2) x (32+2) source patch.  Per 64-channel slab the patch (340 pixels x 128 B = 43 KiB) is
+// DMA'd into LDS once and stays resident for the nine K steps of the slab; only the weight tile
+// (CO x 128 B) changes per K step.  Against the generic macro tile this cuts the LDS-DMA bytes
+// per slab from 9 x (32 + CO/8) KiB to 43 + 9 x CO/8 KiB (CO 256: 576 -> 331 KiB, CO 128:
+// 432 -> 187 KiB) and the DMA instructions per wave and K step from 8 (6) to about 5 (3), which
+// is what the ping-pong read slots have to hide.  LDS: two weight stages + two patch buffers
+// (CO 256: 150 KiB).  Same wave layout, MFMA order and epilogue as igemm_big_kernel.
+//   patch row r = pr * 34 + pc holds source pixel (oy0 + pr, ox0 + pc); tap (ky, kx) of output
+//   pixel (y0 + a, x0 + b) is patch pixel (a + dy, b + dx) with (dy, dx) = (ky, kx) forward and
+//   (2 - ky, 2 - kx) for the data gradient.  16-byte chunks are XOR-swizzled with (r >> 1) & 7;
+//   the 32 consecutive rows of a fragment read stay conflict-free for any start row.
+template <int MODE, int CO>
+__global__ void __launch_bounds__(512)
+igemm_halo_kernel(const IgemmParams p) {
+  typedef uint16_t T;
+  constexpr int EPC = 8, ROW2 = 128, TH = 8, TW = 32, PC = TW + 2, XROWS = (TH + 2) * PC;
+  constexpr int XPIECES = (XROWS + 7) / 8;          // 43 LDS-DMA pieces of 8 rows
+  constexpr int XS = (XPIECES + 7) / 8;             // patch pieces per wave: up to 6
+  constexpr int XBUF = XPIECES * 8 * ROW2;
+  constexpr int WT = CO * ROW2;
+  constexpr int NI = CO / 64, WS = CO / 64;
+  constexpr int QP = 8 / (2 * NI), NP = 4 / QP;
+  __shared__ __attribute__((aligned(16))) unsigned char wst0[WT];
+  __shared__ __attribute__((aligned(16))) unsigned char wst1[WT];
+  __shared__ __attribute__((aligned(16))) unsigned char xb0[XBUF];
+  __shared__ __attribute__((aligned(16))) unsigned char xb1[XBUF];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int half = lane >> 5, l32 = lane & 31;
+
+  int bt = blockIdx.x;
+  const int tx = bt % p.halo_tx; bt /= p.halo_tx;
+  const int ty = bt % p.halo_ty;
+  const int img = bt / p.halo_ty;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int n0 = blockIdx.y * CO;
+  const int oy0 = y0 - (MODE == MODE_FWD ? p.pad_t : 2 - p.pad_t);
+  const int ox0 = x0 - (MODE == MODE_FWD ? p.pad_l : 2 - p.pad_l);
+  const int Cr = p.sC;
+  const int nslabs = Cr / 64;
+  const T* __restrict__ src = (const T*)p.src;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page);
+
+  // ---- patch pieces of this wave: piece s*8 + wave, rows 8*piece + lane/8
+  const int lrow = lane >> 3;
+  const T* xptr[XS];
+  int xmk[XS];
+#pragma unroll
+  for (int sl = 0; sl < XS; ++sl) {
+    const int r = (sl * 8 + wave) * 8 + lrow;
+    const int ch = (lane & 7) ^ ((r >> 1) & 7);
+    const int pr = r / PC, pc = r - pr * PC;
+    const int sy = oy0 + pr;
+    int sx = ox0 + pc;
+    if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+    bool ok = r < XROWS && (unsigned)sy < (unsigned)p.sH && (unsigned)sx < (unsigned)p.sW;
+    const int pix = (img * p.sH + (ok ? sy : 0)) * p.sW + (ok ? sx : 0);
+    if (ok && p.src_mask) ok = p.src_mask[pix] != 0.0f;
+    xptr[sl] = ok ? src + (int64_t)pix * Cr + ch * EPC : zero + ch * EPC;
+    xmk[sl] = ok ? -1 : 0;
+  }
+  // ---- weight pieces: rows (j*8 + wave)*8 + lane/8 of the CO-row tile, every row exists
+  const int wch = (lane & 7) ^ (((wave * 8 + lrow) >> 1) & 7);
+  const T* wbase = (const T*)p.w + (int64_t)(n0 + wave * 8 + lrow) * p.w_n + wch * EPC;
+  const int64_t wjs = 64 * p.w_n;
+
+  auto issue_x = [&](unsigned char* xb, int sl, int slab) {
+    if (sl * 8 + wave < XPIECES)
+      __builtin_amdgcn_global_load_lds((gas_ptr)(xptr[sl] + ((slab * 64) & xmk[sl])),
+                                       (las_ptr)(xb + (sl * 8 + wave) * 8 * ROW2), 16, 0, 0);
+  };
+  auto issue_w = [&](unsigned char* wt, int j, int tap, int slab) {
+    // (wb is laundered so that the 18 x WS addresses of the unrolled K steps are recomputed
+    // from scalars instead of being hoisted and spilled)
+    const T* wb = wbase;
+    asm volatile("" : "+v"(wb));
+    const int64_t soff = (int64_t)tap * p.w_tap + slab * 64 + j * wjs;   // wave-uniform
+    __builtin_amdgcn_global_load_lds((gas_ptr)(wb + soff), (las_ptr)(wt + (j * 8 + wave) * 8 * ROW2),
+                                     16, 0, 0);
+  };
+
+  f32x16_t acc[NI][2];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+  for (int sl = 0; sl < XS; ++sl) issue_x(xb0, sl, 0);
+#pragma unroll
+  for (int j = 0; j < WS; ++j) issue_w(wst0, j, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int wrow0 = wm * (CO / 2) + l32;
+  const int wsw = (wrow0 >> 1) & 7;
+  int rb[2];   // patch row of this lane's pixel (tap offset 0) for the two 32-pixel fragments
+#pragma unroll
+  for (int j = 0; j < 2; ++j) rb[j] = (wn * 2 + j) * PC + l32;
+
+  if (wm == 1) __builtin_amdgcn_s_barrier();   // ping-pong: channel half 1 runs one slot behind
+  // One K step = one tap of one slab (see igemm_big_kernel for the slot / hand-off rules).
+  // Additional hand-off: the patch of slab+1 is DMA'd one piece per K step (taps 0..XS-1, in
+  // the read slot of the second-to-last phase, after this K step's weight pieces), so the
+  // closing wait may leave that one piece in flight: vmcnt(1); tap 8 drains everything.
+  auto k_step = [&](auto tap_c, unsigned char* wcur, unsigned char* wnxt, unsigned char* xcur,
+                    unsigned char* xnxt, int slab, bool next_slab) {
+    constexpr int tap = decltype(tap_c)::value;
+    constexpr int ky = tap / 3, kx = tap - ky * 3;
+    constexpr int toff = MODE == MODE_FWD ? ky * PC + kx : (2 - ky) * PC + (2 - kx);
+    constexpr int ntap = tap == 8 ? 0 : tap + 1;
+    const bool has_next = tap < 8 || next_slab;
+    const int nslab = tap == 8 ? slab + 1 : slab;
+    const bool x_piece = tap < XS && next_slab;
+    const unsigned char* wt = wcur + wrow0 * ROW2;
+    const unsigned char* xr[2];
+    int xsw[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      // opaque to the optimiser: otherwise the 72 per-tap fragment addresses are hoisted out of
+      // the slab loop and spilled
+      asm volatile("" : "+v"(rb[j]));
+      const int r = rb[j] + toff;
+      xr[j] = xcur + r * ROW2;
+      xsw[j] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int ph = 0; ph < NP; ++ph) {
+      // ---- read slot
+      uint4 wf[QP][NI], xf[QP][2];
+#pragma unroll
+      for (int qq = 0; qq < QP; ++qq) {
+        const int c = (ph * QP + qq) * 2 + half;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          wf[qq][i] = *reinterpret_cast<const uint4*>(wt + i * 32 * ROW2 + ((c ^ wsw) * 16));
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          xf[qq][j] = *reinterpret_cast<const uint4*>(xr[j] + ((c ^ xsw[j]) * 16));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) {
+        if (NP == 4 && ph < 2) {
+          issue_w(wnxt, 2 * ph, ntap, nslab);
+          issue_w(wnxt, 2 * ph + 1, ntap, nslab);
+        }
+        if (NP == 2 && ph == 0) {
+          issue_w(wnxt, 0, ntap, nslab);
+          issue_w(wnxt, 1, ntap, nslab);
+        }
+      }
+      if (ph == NP - 2 + (NP == 2) && x_piece) issue_x(xnxt, tap < XS ? tap : 0, slab + 1);
+      if (ph == NP - 1) {
+        if (x_piece) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // ---- MFMA slot
+#pragma unroll
+      for (int qq = 0; qq < QP; ++qq)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8_t, wf[qq][i]), __builtin_bit_cast(bf16x8_t, xf[qq][j]),
+                acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  // nine taps per slab: the weight stage parity flips from one slab to the next, so two slabs
+  // (18 K steps) are written out with compile-time stage / patch-buffer identities
+  auto slab_even = [&](int slab, bool next_slab) {
+    k_step(std::integral_constant<int, 0>(), wst0, wst1, xb0, xb1, slab, next_slab);
+    k_step(std::integral_constant<int, 1>(), wst1, wst0, xb0, xb1, slab, next_slab);
+    k_step(std::integral_constant<int, 2>(), wst0, wst1, xb0, xb1, slab, next_slab);
+    k_step(std::integral_constant<int, 3>(), wst1, wst0, xb0, xb1, slab, next_slab);
+    k_step(std::integral_constant<int, 4>(), wst0, wst1, xb0, xb1, slab, next_slab);
+    k_step(std::integral_constant<int, 5>(), wst1, wst0, xb0, xb1, slab, next_slab);
+    k_step(std::integral_constant<int, 6>(), wst0, wst1, xb0, xb1, slab, next_slab);
+    k_step(std::integral_constant<int, 7>(), wst1, wst0, xb0, xb1, slab, next_slab);
+    k_step(std::integral_constant<int, 8>(), wst0, wst1, xb0, xb1, slab, next_slab);
+  };
+  auto slab_odd = [&](int slab, bool next_slab) {
+    k_step(std::integral_constant<int, 0>(), wst1, wst0, xb1, xb0, slab, next_slab);
+    k_step(std::integral_constant<int, 1>(), wst0, wst1, xb1, xb0, slab, next_slab);
+    k_step(std::integral_constant<int, 2>(), wst1, wst0, xb1, xb0, slab, next_slab);
+    k_step(std::integral_constant<int, 3>(), wst0, wst1, xb1, xb0, slab, next_slab);
+    k_step(std::integral_constant<int, 4>(), wst1, wst0, xb1, xb0, slab, next_slab);
+    k_step(std::integral_constant<int, 5>(), wst0, wst1, xb1, xb0, slab, next_slab);
+    k_step(std::integral_constant<int, 6>(), wst1, wst0, xb1, xb0, slab, next_slab);
+    k_step(std::integral_constant<int, 7>(), wst0, wst1, xb1, xb0, slab, next_slab);
+    k_step(std::integral_constant<int, 8>(), wst1, wst0, xb1, xb0, slab, next_slab);
+  };
+  for (int slab = 0; slab < nslabs; slab += 2) {
+    slab_even(slab, slab + 1 < nslabs);
+    if (slab + 1 < nslabs) slab_odd(slab + 1, slab + 2 < nslabs);
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the late start of channel half 1
+
+  const float scale = p.scale ? *p.scale : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int y = y0 + wn * 2 + j, x = x0 + l32;
+    if (y < p.oH && x < p.oW) {
+      const int64_t opix = ((int64_t)img * p.oH + y) * p.oW + x;
+      store_pixel<T, NI>(p, acc, j, opix, n0 + wm * (CO / 2), half, scale);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------- wgrad
 // dW[(tap,ci), co] = sum_l xg[l,(tap,ci)] * dy[l, co].  Tile: 128 (ci of one tap) x 128 (co),
 // reduction over pixels l in steps of 32.  Both operands have the reduction dim as the SLOW
@@ -1365,9 +1596,29 @@ static int big_tile_mode() {
   return e ? atoi(e) : -1;
 }
 
-// Output channels per 256-pixel macro tile (256 / 128) or 0 for the 128 x 128 kernel.  The macro
-// tile runs one workgroup per CU at about 1.5x the per-CU rate of two resident 128 x 128 tiles,
-// so it wins unless its coarser grid leaves CUs idle in the last round.
+// Output channels per 256-pixel macro tile (256 / 128) or 0 for the 128 x 128 kernel.  Measured
+// (tools/conv_bench.py): the 256-channel macro tile runs one workgroup per CU at ~1.25x the
+// per-CU rate of two resident 128 x 128 tiles, so it wins unless its coarser grid leaves CUs
+// idle in the last round; the 128-channel variant does not beat the 128 x 128 kernel and is
+// only taken when forced (tests).
+// SE3DS_HALO_TILE: unset = heuristic, 0 = never, 1 = whenever the shape allows, 128 / 256 = force
+// that channel width.
+static int halo_tile_channels(const IgemmParams& p) {
+  const char* e = getenv("SE3DS_HALO_TILE");
+  const int mode = e ? atoi(e) : -1;
+  if (mode == 0) return 0;
+  if ((p.oC % 128) != 0) return 0;
+  if (mode == 128 || (p.oC % 256) != 0) return 128;
+  if (mode == 256) return 256;
+  // 256 channels per workgroup unless that leaves a large part of the chip without work
+  const int64_t tiles = (int64_t)p.N * ceil_div(p.oH, 8) * ceil_div(p.oW, 32);
+  const int64_t items256 = tiles * (p.oC / 256);
+  const double eff256 = (double)items256 / (double)(ceil_div(items256, (int64_t)256) * 256);
+  const int64_t items128 = items256 * 2;
+  const double eff128 = 0.85 * (double)items128 / (double)(ceil_div(items128, (int64_t)256) * 256);
+  return eff256 >= eff128 ? 256 : 128;
+}
+
 static int big_tile_channels(const IgemmParams& p, int mode) {
   const int g_big_tile = big_tile_mode();
   if (g_big_tile == 0) return 0;
@@ -1382,7 +1633,8 @@ static int big_tile_channels(const IgemmParams& p, int mode) {
   const double kCus = 256.0;
   const double big_items = (double)ceil_div(m, (int64_t)256) * (p.oC / co);
   const double small_items = (double)ceil_div(m, (int64_t)128) * ceil_div(p.oC, 128);
-  const double gain = co == 256 ? 1.5 : 1.2;
+  if (co != 256) return 0;
+  const double gain = 1.25;
   // time in units of one 128 x 128 tile on a CU that holds two of them
   const double t_small = std::ceil(small_items / (2 * kCus)) * 2.0;
   const double t_big = std::ceil(big_items / kCus) * (co == 256 ? 4.0 : 2.0) / gain;
@@ -1422,6 +1674,22 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   hipStream_t s = as_stream(stream);
   const bool glds = (p.sC % (2 * bk)) == 0 && (src_mask == nullptr || mask_binary) &&
                     !g_disable_glds;
+  if (glds && dtype == SE3DS_BF16 && stride == 1 && kh == 3 && kw == 3) {
+    const int co = halo_tile_channels(p);
+    if (co) {
+      p.halo_ty = ceil_div(p.oH, 8);
+      p.halo_tx = ceil_div(p.oW, 32);
+      dim3 grid((unsigned)(p.N * p.halo_ty * p.halo_tx), (unsigned)(p.oC / co));
+      if (co == 256) {
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256>), grid, dim3(512), 0, s, p);
+      } else {
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128>), grid, dim3(512), 0, s, p);
+      }
+      return check_launch(mode == MODE_FWD ? "conv2d_fwd(halo)" : "conv2d_dgrad(halo)");
+    }
+  }
   if (glds && dtype == SE3DS_BF16) {
     const int co = big_tile_channels(p, mode);
     if (co) {

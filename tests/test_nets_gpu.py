@@ -75,12 +75,17 @@ BIG_TILE_CASES = [
     ('partial_spectral', 64, 128, 3, 2, 'VALID', 1, False, True, True, 2, 16, 32),
     ('partial_spectral', 128, 128, 3, 1, 'VALID', 1, False, True, True, 2, 16, 32),
     ('plain', 512, 256, 3, 1, 'VALID', 1, False, True, False, 3, 11, 23),      # several taps x K steps
+    ('spectral', 192, 128, 3, 1, 'VALID', 1, False, True, False, 1, 20, 70),   # 3 slabs, ragged tiles
+    ('plain', 64, 128, 3, 1, 'SAME', 0, False, False, False, 2, 8, 32),        # one slab, SAME pad
 ]
 
 
+@pytest.mark.parametrize('halo', ['0', '1'])
 @pytest.mark.parametrize('case', BIG_TILE_CASES)
-def test_conv_macro_tile_fwd_bwd(case, monkeypatch):
+def test_conv_macro_tile_fwd_bwd(case, halo, monkeypatch):
+  """halo=1: stride-1 3x3 cases run the halo-resident kernel; halo=0: the generic macro tile."""
   monkeypatch.setenv('SE3DS_BIG_TILE', '1')
+  monkeypatch.setenv('SE3DS_HALO_TILE', halo)
   _run_conv_case(case, torch.bfloat16)
 
 
