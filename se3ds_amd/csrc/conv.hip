@@ -809,6 +809,7 @@ igemm_big_kernel(const IgemmParams p) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA slot
 #pragma unroll
       for (int qq = 0; qq < QP; ++qq)
@@ -1000,6 +1001,7 @@ igemm_halo_kernel(const IgemmParams p) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA slot
 #pragma unroll
       for (int qq = 0; qq < QP; ++qq)
@@ -1500,6 +1502,188 @@ wgrad_glds_kernel(const WgradParams p) {
   }
 }
 
+// ------------------------------------------------------------------- tap-fused 3x3 wgrad
+// Stride-1 3x3 weight gradients, bf16.  One workgroup owns a 64-channel slice of the input, a
+// 128-channel slice of the output gradient and ALL NINE taps: dW[tap][ci][co] for 9 x 64 x 128
+// outputs (8 waves x 9 accumulator tiles of 32 x 32).  The reduction runs over "steps" of 64
+// output pixels (2 rows x 32 columns of one image); a step needs the 64 x 128 dy tile and the
+// (2+2) x (32+2) x 64 halo of x, and the nine taps are nine shifted views of that one halo.
+// Per step a CU fills 33 KiB for 9.4 MFLOP (the per-tap 128 x 128 tile: 9 x 32 KiB for the same
+// work), so the kernel is MFMA-bound instead of fill-bound.  Schedule: as igemm_halo_kernel
+// (ping-pong read / MFMA slots of one 16-pixel step = 9 MFMAs, LDS-DMA of the next step in the
+// first two read slots, two LDS stages).  Both operands are [pixel][channel] in LDS and reach
+// the MFMA layout (8 consecutive pixels per lane) through ds_read_b64_tr_b16:
+//   dy  rows of 256 B, 16-byte chunk index ^= (row & 3) << 2   (as wgrad_glds_kernel)
+//   x   rows of 128 B, 16-byte chunk index ^= (row & 2) << 1 -- any four consecutive rows then
+//       cover the four 64-byte windows of the 256-byte bank line, for every tap shift.
+// Partial sums go to dw[split][(tap, ci)][co]; wgrad_reduce_kernel adds the splits in order.
+struct WgradTapsParams {
+  const uint16_t* x; int H, W, Cin;
+  const uint16_t* dy; int Ho, Wo, Cout;
+  int N, pad_t, pad_l, wrap_w;
+  const float* src_mask;     // binary (N,H,W) or null
+  float* dw;
+  int steps_y, steps_x;      // steps per image: ceil(Ho/2) x ceil(Wo/32)
+  int total_steps, steps_per_split;
+};
+
+__global__ void __launch_bounds__(512)
+wgrad_taps_kernel(const WgradTapsParams p) {
+  typedef uint16_t T;
+  constexpr int YROW = 256, XROW = 128, PC = 34;
+  constexpr int YT = 64 * YROW;              // 16 KiB
+  constexpr int XR = 4 * PC;                 // 136 halo rows
+  constexpr int XPIECES = (XR + 7) / 8;      // 17
+  constexpr int XT = XPIECES * 8 * XROW;     // 17 KiB
+  __shared__ __attribute__((aligned(16))) unsigned char stage0[YT + XT];
+  __shared__ __attribute__((aligned(16))) unsigned char stage1[YT + XT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int iw = wave >> 2, cw = wave & 3;   // 32-channel block of x / of dy owned by this wave
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 128;
+  const int split = blockIdx.z;
+  const int st_begin = split * p.steps_per_split;
+  int st_end = st_begin + p.steps_per_split;
+  if (st_end > p.total_steps) st_end = p.total_steps;
+  const int nsteps = st_end > st_begin ? st_end - st_begin : 0;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page_w);
+
+  // ---- LDS-DMA pieces of this wave
+  // dy: pieces 2*wave, 2*wave+1; piece = 4 rows x 256 B; lane -> row piece*4 + lane/16
+  int ya[2], yb[2], ych[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 4 + (lane >> 4);
+    ya[j] = r >> 5; yb[j] = r & 31;
+    ych[j] = (lane & 15) ^ ((r & 3) << 2);
+  }
+  // x: pieces wave, wave + 8 (and 16 on wave 0); piece = 8 rows x 128 B; lane -> row piece*8 + lane/8
+  int xa[3], xb[3], xch[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int r = (wave + 8 * j) * 8 + (lane >> 3);
+    xa[j] = r / PC; xb[j] = r - xa[j] * PC;
+    if (r >= XR) xa[j] = 1 << 20;   // rows past the halo: always out of bounds
+    xch[j] = (lane & 7) ^ ((r & 2) << 1);
+  }
+
+  auto issue = [&](int st, unsigned char* stg) {
+    // step -> (image, first row, first column); wave-uniform
+    int t = st_begin + st;
+    const int sx_i = t % p.steps_x; t /= p.steps_x;
+    const int sy_i = t % p.steps_y;
+    const int img = t / p.steps_y;
+    const int y0 = sy_i * 2, x0 = sx_i * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int oy = y0 + ya[j], ox = x0 + yb[j];
+      const T* src = zero + ych[j] * 8;
+      if (oy < p.Ho && ox < p.Wo)
+        src = p.dy + ((int64_t)(img * p.Ho + oy) * p.Wo + ox) * p.Cout + co0 + ych[j] * 8;
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(stg + (wave * 2 + j) * 4 * YROW), 16,
+                                       0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j == 2 && wave != 0) break;
+      const int sy = y0 - p.pad_t + xa[j];
+      int sx = x0 - p.pad_l + xb[j];
+      if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
+      const T* src = zero + xch[j] * 8;
+      if ((unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W) {
+        const int pix = (img * p.H + sy) * p.W + sx;
+        if (!(p.src_mask && p.src_mask[pix] == 0.0f))
+          src = p.x + (int64_t)pix * p.Cin + ci0 + xch[j] * 8;
+      }
+      __builtin_amdgcn_global_load_lds((gas_ptr)src,
+                                       (las_ptr)(stg + YT + (wave + 8 * j) * 8 * XROW), 16, 0, 0);
+    }
+  };
+
+  f32x16_t acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (nsteps > 0) issue(0, stage0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const int half = lane >> 5, l32 = lane & 31;
+  const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+  const int jrow = i16 >> 2, qcol = i16 & 3;
+  // per-lane constants of the transposing reads
+  const int ycol = cw * 32 + g16 * 16 + qcol * 4;                         // dy channel of the segment
+  const int yo = (((ycol >> 3) ^ ((jrow & 3) << 2)) << 4) + ((ycol & 4) << 1);
+  const int xcol = iw * 32 + g16 * 16 + qcol * 4;
+  const int xlo = (xcol & 4) << 1;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_seg;
+
+  if (iw == 1) __builtin_amdgcn_s_barrier();   // ping-pong: waves 4-7 run one slot behind
+  auto l_step = [&](unsigned char* cur, unsigned char* nxt, int st) {
+    const bool has_next = st + 1 < nsteps;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq) {
+      // ---- read slot: 16 pixels (row a, columns b0 .. b0+15); this lane: pixels lb .. lb+7
+      const int a = kq >> 1, lb = (kq & 1) * 16 + half * 8;
+      uint4 yf, xf[9];
+      {
+        const unsigned char* yp = cur + (a * 32 + lb + jrow) * YROW + yo;
+        uint2 v0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)yp));
+        uint2 v1 = __builtin_bit_cast(
+            uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(yp + 4 * YROW)));
+        yf = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t - ky * 3;
+        const int r = (a + ky) * PC + kx + lb + jrow;
+        const unsigned char* xp = cur + YT + r * XROW + ((((xcol >> 3) ^ ((r & 2) << 1)) << 4) + xlo);
+        uint2 v0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)xp));
+        uint2 v1 = __builtin_bit_cast(
+            uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(xp + 4 * XROW)));
+        xf[t] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kq == 0 && has_next) issue(st + 1, nxt);
+      if (kq == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- MFMA slot
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, yf),
+                                                         __builtin_bit_cast(bf16x8_t, xf[t]), acc[t],
+                                                         0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+  for (int st = 0; st < nsteps; st += 2) {
+    l_step(stage0, stage1, st);
+    if (st + 1 < nsteps) l_step(stage1, stage0, st + 1);
+  }
+  if (iw == 0) __builtin_amdgcn_s_barrier();
+
+  // acc[t][r]: ci = ci0 + iw*32 + l32, co = co0 + cw*32 + (r&3) + 8*(r>>2) + 4*half
+  const int64_t K = (int64_t)9 * p.Cin;
+  float* __restrict__ dw = p.dw + (int64_t)split * K * p.Cout;
+  const int ci = ci0 + iw * 32 + l32;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float* row = dw + ((int64_t)t * p.Cin + ci) * p.Cout + co0 + cw * 32 + half * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(row + g * 8) =
+          make_float4(acc[t][g * 4], acc[t][g * 4 + 1], acc[t][g * 4 + 2], acc[t][g * 4 + 3]);
+  }
+}
+
 // sum the split partials: out[i] (+)= sum_s part[s][i]
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t n, int accumulate,
@@ -1768,14 +1952,44 @@ static int wgrad_splits(int64_t L, int64_t tiles, int64_t nel) {
   return best;
 }
 
+// tap-fused 3x3 kernel: steps of 64 pixels, work items = (Cin/64) x (Cout/128) x splits on 256
+// single-workgroup CUs.  Returns the split count (0: shape not eligible).
+static int wgrad_taps_splits(int n, int ho, int wo, int cin, int cout, int kh, int kw, int* steps) {
+  if (kh != 3 || kw != 3 || (cin % 64) != 0 || (cout % 128) != 0) return 0;
+  const char* e = getenv("SE3DS_WGRAD_TAPS");
+  if (e && atoi(e) == 0) return 0;
+  const int64_t total = (int64_t)n * ceil_div(ho, 2) * ceil_div(wo, 32);
+  if (total > (1 << 30)) return 0;
+  *steps = (int)total;
+  const int64_t tiles = (int64_t)(cin / 64) * (cout / 128);
+  // rounds of 256 items x steps per item (~1.3 us each) + partial-slab traffic of the reduce
+  const double kStepUs = 1.3, kBytesPerUs = 3.0e6;
+  const int64_t nel = (int64_t)9 * cin * cout;
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 512 && s <= total; ++s) {
+    const double per = (double)ceil_div(total, (int64_t)s);
+    if (s > 1 && per < 8) break;
+    const double rounds = (double)ceil_div(tiles * s, (int64_t)256);
+    const double cost = rounds * (per * kStepUs + 4.0) +
+                        (double)s * (double)nel * 8.0 / kBytesPerUs * (s > 1 ? 1.0 : 0.5);
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
 size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int cout, int kh,
                                           int kw) {
+  int tsteps = 0;
+  const int tsplits = wgrad_taps_splits(n, ho, wo, cin, cout, kh, kw, &tsteps);
+  const size_t taps_bytes = sizeof(float) * (size_t)tsplits * (size_t)kh * kw * cin * cout + 16;
   int64_t L = (int64_t)n * ho * wo;
   int64_t row_tiles = cin <= 16 ? ceil_div((int64_t)kh * kw * cin, 128)
                                 : (int64_t)kh * kw * ceil_div(cin, 128);
   int64_t tiles = row_tiles * ceil_div(cout, 128);
   int splits = wgrad_splits(L, tiles, (int64_t)kh * kw * cin * cout);
-  return sizeof(float) * (size_t)splits * (size_t)kh * kw * cin * cout + 16;
+  const size_t bytes = sizeof(float) * (size_t)splits * (size_t)kh * kw * cin * cout + 16;
+  return bytes > taps_bytes ? bytes : taps_bytes;
 }
 
 int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int n, int h, int w,
@@ -1789,6 +2003,28 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   if (dtype != SE3DS_F32 && dtype != SE3DS_BF16) return SE3DS_E_BADDTYPE;
   if (workspace_bytes < se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, cout, kh, kw))
     return SE3DS_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  if (dtype == SE3DS_BF16 && stride == 1 && row_scale == nullptr &&
+      (in_mask == nullptr || in_mask_binary) && !g_disable_glds) {
+    int tsteps = 0;
+    const int tsplits = wgrad_taps_splits(n, ho, wo, cin, cout, kh, kw, &tsteps);
+    if (tsplits > 0) {
+      WgradTapsParams q;
+      q.x = (const uint16_t*)x; q.H = h; q.W = w; q.Cin = cin;
+      q.dy = (const uint16_t*)dy; q.Ho = ho; q.Wo = wo; q.Cout = cout;
+      q.N = n; q.pad_t = pad_t; q.pad_l = pad_l; q.wrap_w = wrap_w; q.src_mask = in_mask;
+      q.dw = (float*)workspace;
+      q.steps_y = ceil_div(ho, 2); q.steps_x = ceil_div(wo, 32);
+      q.total_steps = tsteps;
+      q.steps_per_split = ceil_div(tsteps, tsplits);
+      dim3 tgrid((unsigned)(cin / 64), (unsigned)(cout / 128), (unsigned)tsplits);
+      hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(512), 0, s, q);
+      const int64_t tnel = (int64_t)9 * cin * cout;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(tnel, 256)), dim3(256), 0, s,
+                         (const float*)workspace, tsplits, tnel, accumulate, out_scale, dw);
+      return check_launch("conv2d_wgrad(taps)");
+    }
+  }
   WgradParams p;
   p.x = x; p.H = h; p.W = w; p.Cin = cin; p.dy = dy; p.Ho = ho; p.Wo = wo; p.Cout = cout;
   p.N = n; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
@@ -1803,7 +2039,6 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   p.splits = wgrad_splits(L, tiles, (int64_t)kh * kw * cin * cout);
   p.l_per_split = ceil_div(ceil_div(L, p.splits), WG_BL) * WG_BL;
   dim3 grid((unsigned)row_tiles, (unsigned)ceil_div(cout, 128), (unsigned)p.splits);
-  hipStream_t s = as_stream(stream);
   const int epc = dtype == SE3DS_F32 ? 4 : 8;
   const bool glds = !g_disable_glds && !p.linear_k && (in_mask == nullptr || in_mask_binary) &&
                     row_scale == nullptr &&
