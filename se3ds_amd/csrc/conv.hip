@@ -75,6 +75,7 @@ struct IgemmParams {
   int act; float act_alpha;  // 0 none, 1 relu, 2 leaky relu
   int vec;                // reduction channels % BK == 0 -> vector gather
   int halo_ty, halo_tx;   // igemm_halo_kernel: output tiles per image (rows of 8, columns of 32)
+  int dbg;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
@@ -172,24 +173,99 @@ __device__ __forceinline__ void store_pixel(const IgemmParams& p, f32x16_t (&acc
     }
 }
 
+// bf16 epilogue through LDS.  In the MFMA layout a lane owns 4 consecutive channels of one
+// pixel, so direct stores are 8-byte pieces scattered over 32 pixel rows per instruction: the
+// 3x3 128->128 @512x1024 layer spent 36 % of its time in them (1.07 GB written at 1.5 TB/s).
+// Here the wave parks 32 pixels x NI*32 channels in its own LDS scratch ([pixel][channel], rows
+// padded by 16 B) and writes them back with 16-byte stores in which NI*4 consecutive lanes cover
+// one pixel's contiguous NI*64 bytes.  LDS instructions of one wave execute in order, so the
+// wave needs no barrier between its own ds_write and ds_read.
+// opix[j]: output pixel index of (fragment j, lane & 31), or -1.  scratch: kEpiScratch<NI> bytes.
+template <int NI> constexpr int kEpiScratch = 32 * (NI * 64 + 16) + 256;
+
+template <int NI>
+__device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&acc)[NI][2],
+                                               const int64_t (&opix)[2], int co_base, int lane,
+                                               unsigned char* scratch) {
+  constexpr int RB = NI * 64 + 16;   // padded row bytes
+  constexpr int LPP = NI * 4;        // lanes per pixel in the write-back
+  constexpr int PPI = 64 / LPP;      // pixels per store instruction
+  const int half = lane >> 5, l32 = lane & 31;
+  const float scale = p.scale ? *p.scale : 1.0f;
+  uint16_t* __restrict__ out = (uint16_t*)p.out;
+  int64_t* offs = reinterpret_cast<int64_t*>(scratch + 32 * RB);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t o = opix[j];
+    if (half == 0) offs[l32] = o;
+    const int64_t oc = o < 0 ? 0 : o;
+    const float ra = p.row_a ? p.row_a[oc] : 1.0f;
+    const float rb = p.row_b ? p.row_b[oc] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = i * 32 + g * 8 + half * 4;   // channel inside the wave tile
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[i][j][g * 4 + e] * scale;
+          const float bv = p.bias ? p.bias[co_base + cl + e] : 0.0f;
+          if (p.row_a) {
+            if (p.bias) t = ((t - bv) * ra + bv) * rb;
+            else t = t * ra;
+          } else if (p.bias) {
+            t = t + bv;
+          }
+          if (p.act == 1) t = t > 0.f ? t : 0.f;
+          else if (p.act == 2) t = t > 0.f ? t : t * p.act_alpha;
+          v[e] = t;
+        }
+        uint2 pk;
+        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(scratch + l32 * RB + cl * 2) = pk;
+      }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 32 / PPI; ++k) {
+      const int px = k * PPI + lane / LPP, c16 = lane % LPP;
+      const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * RB + c16 * 16);
+      const int64_t po = offs[px];
+      if (po >= 0) *reinterpret_cast<uint4*>(out + po * p.oC + co_base + c16 * 8) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // m_base / co_base: first pixel row / output channel of this wave's sub-tile.
+// scratch: this wave's kEpiScratch<NI> bytes of LDS (no longer read by anyone) or null.
 template <typename T, int MODE, int NI = 2>
 __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)[NI][2],
                                            int64_t m_base, int co_base, int64_t Mc, int cH, int cW,
-                                           int py, int px, int half, int l32) {
+                                           int py, int px, int half, int l32,
+                                           unsigned char* scratch = nullptr) {
   const int s = p.stride;
   const float scale = p.scale ? *p.scale : 1.0f;
+  int64_t opix[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     int64_t m = m_base + j * 32 + l32;
+    opix[j] = -1;
     if (m >= Mc) continue;
     int n = (int)(m / ((int64_t)cH * cW));
     int rem = (int)(m - (int64_t)n * cH * cW);
     int a = rem / cW, b = rem - a * cW;
     if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
-    const int64_t opix = ((int64_t)n * p.oH + a) * p.oW + b;
-    store_pixel<T, NI>(p, acc, j, opix, co_base, half, scale);
+    opix[j] = ((int64_t)n * p.oH + a) * p.oW + b;
   }
+  if (sizeof(T) == 2 && scratch != nullptr && (p.oC & 7) == 0 && co_base + NI * 32 <= p.oC) {
+    store_wave_lds<NI>(p, acc, opix, co_base, half * 32 + l32, scratch);
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    if (opix[j] >= 0) store_pixel<T, NI>(p, acc, j, opix[j], co_base, half, scale);
 }
 
 template <typename T, int MODE>
@@ -602,8 +678,9 @@ igemm_glds_kernel(const IgemmParams p) {
     k_step(stage0, stage1, kt + 1 < nk);
     if (kt + 1 < nk) k_step(stage1, stage0, kt + 2 < nk);
   }
+  // (the loop's closing __syncthreads leaves both stages idle: stage0 is the epilogue scratch)
   store_tile<T, MODE>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py, px,
-                      half, l32);
+                      half, l32, stage0 + wave * kEpiScratch<2>);
 }
 
 // ------------------------------------------------------------------ 256-pixel macro tiles
@@ -753,7 +830,7 @@ igemm_big_kernel(const IgemmParams p) {
     for (int j = 0; j < 4; ++j) issue_slot(stage0, j);
     issue_advance();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __builtin_amdgcn_s_barrier();
   const int half = lane >> 5, l32 = lane & 31;
   const int wrow0 = wm * (CO / 2) + l32, xrow0 = wn * 64 + l32;
@@ -804,11 +881,11 @@ igemm_big_kernel(const IgemmParams p) {
         }
         if (ph == NP / 2) issue_advance();
       }
-      if (ph == NP - 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (ph == NP - 1) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA slot
 #pragma unroll
@@ -830,8 +907,11 @@ igemm_big_kernel(const IgemmParams p) {
     if (kt + 1 < nk) k_step(stage1, stage0, kt + 2 < nk);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the late start of channel half 1
+  // every wave is past its last fragment read: the stages become the epilogue scratch
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   store_tile<T, MODE, NI>(p, acc, (int64_t)tile_m * PIX + wn * 64, n0 + wm * (CO / 2), Mc, cH, cW,
-                          py, px, half, l32);
+                          py, px, half, l32,
+                          (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>);
 }
 
 // ------------------------------------------------------------------ halo-resident 3x3 tiles
@@ -848,7 +928,7 @@ igemm_big_kernel(const IgemmParams p) {
 //   pixel (y0 + a, x0 + b) is patch pixel (a + dy, b + dx) with (dy, dx) = (ky, kx) forward and
 //   (2 - ky, 2 - kx) for the data gradient.  16-byte chunks are XOR-swizzled with (r >> 1) & 7;
 //   the 32 consecutive rows of a fragment read stay conflict-free for any start row.
-template <int MODE, int CO>
+template <int MODE, int CO, int WST>
 __global__ void __launch_bounds__(512)
 igemm_halo_kernel(const IgemmParams p) {
   typedef uint16_t T;
@@ -859,8 +939,15 @@ igemm_halo_kernel(const IgemmParams p) {
   constexpr int WT = CO * ROW2;
   constexpr int NI = CO / 64, WS = CO / 64;
   constexpr int QP = 8 / (2 * NI), NP = 4 / QP;
+  constexpr int DIST = WST - 1;   // weight tiles are fetched DIST K steps ahead
+  static_assert(WST == 2 || WST == 3, "weight stages");
   __shared__ __attribute__((aligned(16))) unsigned char wst0[WT];
   __shared__ __attribute__((aligned(16))) unsigned char wst1[WT];
+  __shared__ __attribute__((aligned(16))) unsigned char wst2[WST == 3 ? WT : 16];
+  // Every K step issues the same number of LDS-DMA instructions (idle ones copy the zero page
+  // into `sink`): with a path-dependent count the compiler's waitcnt pass falls back to
+  // vmcnt(0) in front of the fragment reads and the prefetch distance collapses.
+  __shared__ __attribute__((aligned(16))) unsigned char sink[1024];
   __shared__ __attribute__((aligned(16))) unsigned char xb0[XBUF];
   __shared__ __attribute__((aligned(16))) unsigned char xb1[XBUF];
   const int tid = threadIdx.x;
@@ -905,19 +992,26 @@ igemm_halo_kernel(const IgemmParams p) {
   const T* wbase = (const T*)p.w + (int64_t)(n0 + wave * 8 + lrow) * p.w_n + wch * EPC;
   const int64_t wjs = 64 * p.w_n;
 
-  auto issue_x = [&](unsigned char* xb, int sl, int slab) {
-    if (sl * 8 + wave < XPIECES)
-      __builtin_amdgcn_global_load_lds((gas_ptr)(xptr[sl] + ((slab * 64) & xmk[sl])),
-                                       (las_ptr)(xb + (sl * 8 + wave) * 8 * ROW2), 16, 0, 0);
+  const T* zlane = zero + (lane & 7) * EPC;
+  auto issue_x = [&](unsigned char* xb, int sl, int slab, bool real) {
+    const bool live = real && sl * 8 + wave < XPIECES;   // wave-uniform
+    const T* srcp = live ? xptr[sl] + ((slab * 64) & xmk[sl]) : zlane;
+    if (live)
+      __builtin_amdgcn_global_load_lds((gas_ptr)srcp, (las_ptr)(xb + (sl * 8 + wave) * 8 * ROW2), 16,
+                                       0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gas_ptr)srcp, (las_ptr)sink, 16, 0, 0);
   };
-  auto issue_w = [&](unsigned char* wt, int j, int tap, int slab) {
+  auto issue_w = [&](unsigned char* wt, int j, int tap, int slab, bool real) {
     // (wb is laundered so that the 18 x WS addresses of the unrolled K steps are recomputed
     // from scalars instead of being hoisted and spilled)
     const T* wb = wbase;
     asm volatile("" : "+v"(wb));
     const int64_t soff = (int64_t)tap * p.w_tap + slab * 64 + j * wjs;   // wave-uniform
-    __builtin_amdgcn_global_load_lds((gas_ptr)(wb + soff), (las_ptr)(wt + (j * 8 + wave) * 8 * ROW2),
-                                     16, 0, 0);
+    // an idle copy lands in a stage nobody reads again
+    const T* srcp = real ? wb + soff : zlane;
+    __builtin_amdgcn_global_load_lds((gas_ptr)srcp, (las_ptr)(wt + (j * 8 + wave) * 8 * ROW2), 16, 0,
+                                     0);
   };
 
   f32x16_t acc[NI][2];
@@ -929,10 +1023,14 @@ igemm_halo_kernel(const IgemmParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-  for (int sl = 0; sl < XS; ++sl) issue_x(xb0, sl, 0);
+  for (int sl = 0; sl < XS; ++sl) issue_x(xb0, sl, 0, true);
 #pragma unroll
-  for (int j = 0; j < WS; ++j) issue_w(wst0, j, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int j = 0; j < WS; ++j) issue_w(wst0, j, 0, 0, true);
+  if (WST == 3) {
+#pragma unroll
+    for (int j = 0; j < WS; ++j) issue_w(wst1, j, 1, 0, true);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __builtin_amdgcn_s_barrier();
 
   const int wrow0 = wm * (CO / 2) + l32;
@@ -948,12 +1046,13 @@ igemm_halo_kernel(const IgemmParams p) {
   // closing wait may leave that one piece in flight: vmcnt(1); tap 8 drains everything.
   auto k_step = [&](auto tap_c, unsigned char* wcur, unsigned char* wnxt, unsigned char* xcur,
                     unsigned char* xnxt, int slab, bool next_slab) {
+    // wnxt: the stage that receives the weight tile of K step (this + DIST)
     constexpr int tap = decltype(tap_c)::value;
     constexpr int ky = tap / 3, kx = tap - ky * 3;
     constexpr int toff = MODE == MODE_FWD ? ky * PC + kx : (2 - ky) * PC + (2 - kx);
-    constexpr int ntap = tap == 8 ? 0 : tap + 1;
-    const bool has_next = tap < 8 || next_slab;
-    const int nslab = tap == 8 ? slab + 1 : slab;
+    constexpr int ntap = (tap + DIST) % 9;
+    const bool has_next = tap + DIST < 9 || next_slab;
+    const int nslab = tap + DIST >= 9 ? slab + 1 : slab;
     const bool x_piece = tap < XS && next_slab;
     const unsigned char* wt = wcur + wrow0 * ROW2;
     const unsigned char* xr[2];
@@ -982,25 +1081,26 @@ igemm_halo_kernel(const IgemmParams p) {
           xf[qq][j] = *reinterpret_cast<const uint4*>(xr[j] + ((c ^ xsw[j]) * 16));
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (has_next) {
-        if (NP == 4 && ph < 2) {
-          issue_w(wnxt, 2 * ph, ntap, nslab);
-          issue_w(wnxt, 2 * ph + 1, ntap, nslab);
-        }
-        if (NP == 2 && ph == 0) {
-          issue_w(wnxt, 0, ntap, nslab);
-          issue_w(wnxt, 1, ntap, nslab);
-        }
+      if (NP == 4 && ph < 2) {
+        issue_w(wnxt, 2 * ph, ntap, nslab, has_next);
+        issue_w(wnxt, 2 * ph + 1, ntap, nslab, has_next);
       }
-      if (ph == NP - 2 + (NP == 2) && x_piece) issue_x(xnxt, tap < XS ? tap : 0, slab + 1);
+      if (NP == 2 && ph == 0) {
+        issue_w(wnxt, 0, ntap, nslab, has_next);
+        issue_w(wnxt, 1, ntap, nslab, has_next);
+      }
+      if (ph == NP - 2 + (NP == 2)) issue_x(xnxt, tap < XS ? tap : 0, slab + 1, x_piece);
       if (ph == NP - 1) {
-        if (x_piece) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // the weight tile of the NEXT K step must have landed; younger DMA stays in flight:
+        // this K step's patch piece and, with three weight stages, this K step's weight pieces
+        if (WST == 2) __builtin_amdgcn_s_waitcnt(0x0071);   // vmcnt(1) lgkmcnt(0)
+        else if (WS == 2) __builtin_amdgcn_s_waitcnt(0x0073);   // vmcnt(3) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0075);   // vmcnt(5) lgkmcnt(0)
       }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA slot
 #pragma unroll
@@ -1017,45 +1117,44 @@ igemm_halo_kernel(const IgemmParams p) {
       __builtin_amdgcn_s_barrier();
     }
   };
-  // nine taps per slab: the weight stage parity flips from one slab to the next, so two slabs
-  // (18 K steps) are written out with compile-time stage / patch-buffer identities
+  // nine taps per slab, written out with compile-time stage / patch-buffer identities.  Two
+  // weight stages: the stage parity flips from one slab to the next (two slab bodies); three
+  // stages: every slab starts on stage 0, only the patch buffers alternate.
+  auto wsel = [&](int i) -> unsigned char* { return i == 0 ? wst0 : (i == 1 ? wst1 : wst2); };
+  auto slab_body = [&](auto par_c, int slab, bool next_slab) {
+    constexpr int P = decltype(par_c)::value;
+    unsigned char* xc = P ? xb1 : xb0;
+    unsigned char* xn = P ? xb0 : xb1;
+#define SE3DS_TAP(T_)                                                                      \
+    k_step(std::integral_constant<int, T_>(),                                              \
+           wsel(WST == 2 ? ((T_ + P) & 1) : (T_ % 3)),                                     \
+           wsel(WST == 2 ? ((T_ + P + 1) & 1) : ((T_ + 2) % 3)), xc, xn, slab, next_slab)
+    SE3DS_TAP(0); SE3DS_TAP(1); SE3DS_TAP(2); SE3DS_TAP(3); SE3DS_TAP(4);
+    SE3DS_TAP(5); SE3DS_TAP(6); SE3DS_TAP(7); SE3DS_TAP(8);
+#undef SE3DS_TAP
+  };
   auto slab_even = [&](int slab, bool next_slab) {
-    k_step(std::integral_constant<int, 0>(), wst0, wst1, xb0, xb1, slab, next_slab);
-    k_step(std::integral_constant<int, 1>(), wst1, wst0, xb0, xb1, slab, next_slab);
-    k_step(std::integral_constant<int, 2>(), wst0, wst1, xb0, xb1, slab, next_slab);
-    k_step(std::integral_constant<int, 3>(), wst1, wst0, xb0, xb1, slab, next_slab);
-    k_step(std::integral_constant<int, 4>(), wst0, wst1, xb0, xb1, slab, next_slab);
-    k_step(std::integral_constant<int, 5>(), wst1, wst0, xb0, xb1, slab, next_slab);
-    k_step(std::integral_constant<int, 6>(), wst0, wst1, xb0, xb1, slab, next_slab);
-    k_step(std::integral_constant<int, 7>(), wst1, wst0, xb0, xb1, slab, next_slab);
-    k_step(std::integral_constant<int, 8>(), wst0, wst1, xb0, xb1, slab, next_slab);
+    slab_body(std::integral_constant<int, 0>(), slab, next_slab);
   };
   auto slab_odd = [&](int slab, bool next_slab) {
-    k_step(std::integral_constant<int, 0>(), wst1, wst0, xb1, xb0, slab, next_slab);
-    k_step(std::integral_constant<int, 1>(), wst0, wst1, xb1, xb0, slab, next_slab);
-    k_step(std::integral_constant<int, 2>(), wst1, wst0, xb1, xb0, slab, next_slab);
-    k_step(std::integral_constant<int, 3>(), wst0, wst1, xb1, xb0, slab, next_slab);
-    k_step(std::integral_constant<int, 4>(), wst1, wst0, xb1, xb0, slab, next_slab);
-    k_step(std::integral_constant<int, 5>(), wst0, wst1, xb1, xb0, slab, next_slab);
-    k_step(std::integral_constant<int, 6>(), wst1, wst0, xb1, xb0, slab, next_slab);
-    k_step(std::integral_constant<int, 7>(), wst0, wst1, xb1, xb0, slab, next_slab);
-    k_step(std::integral_constant<int, 8>(), wst1, wst0, xb1, xb0, slab, next_slab);
+    slab_body(std::integral_constant<int, 1>(), slab, next_slab);
   };
-  for (int slab = 0; slab < nslabs; slab += 2) {
+  for (int slab = 0; slab < ((p.dbg & 2) ? 0 : nslabs); slab += 2) {
     slab_even(slab, slab + 1 < nslabs);
     if (slab + 1 < nslabs) slab_odd(slab + 1, slab + 2 < nslabs);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the late start of channel half 1
 
-  const float scale = p.scale ? *p.scale : 1.0f;
+  int64_t opix[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int y = y0 + wn * 2 + j, x = x0 + l32;
-    if (y < p.oH && x < p.oW) {
-      const int64_t opix = ((int64_t)img * p.oH + y) * p.oW + x;
-      store_pixel<T, NI>(p, acc, j, opix, n0 + wm * (CO / 2), half, scale);
-    }
+    opix[j] = (y < p.oH && x < p.oW && !(p.dbg & 1)) ? ((int64_t)img * p.oH + y) * p.oW + x : -1;
   }
+  // every wave is past its last fragment read; the patch buffers become the epilogue scratch
+  // (idle copies of the last K steps only touch the weight stages and `sink`)
+  store_wave_lds<NI>(p, acc, opix, n0 + wm * (CO / 2), lane,
+                     (wave < 4 ? xb0 : xb1) + (wave & 3) * kEpiScratch<NI>);
 }
 
 // ------------------------------------------------------------------------------- wgrad
@@ -1607,7 +1706,7 @@ wgrad_taps_kernel(const WgradTapsParams p) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   if (nsteps > 0) issue(0, stage0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   __builtin_amdgcn_s_barrier();
 
   const int half = lane >> 5, l32 = lane & 31;
@@ -1647,11 +1746,11 @@ wgrad_taps_kernel(const WgradTapsParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if (kq == 0 && has_next) issue(st + 1, nxt);
-      if (kq == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (kq == 3) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA slot
 #pragma unroll
@@ -1861,15 +1960,16 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   if (glds && dtype == SE3DS_BF16 && stride == 1 && kh == 3 && kw == 3) {
     const int co = halo_tile_channels(p);
     if (co) {
+      p.dbg = getenv("SE3DS_DBG") ? atoi(getenv("SE3DS_DBG")) : 0;
       p.halo_ty = ceil_div(p.oH, 8);
       p.halo_tx = ceil_div(p.oW, 32);
       dim3 grid((unsigned)(p.N * p.halo_ty * p.halo_tx), (unsigned)(p.oC / co));
       if (co == 256) {
-        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256>), grid, dim3(512), 0, s, p);
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256, 2>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2>), grid, dim3(512), 0, s, p);
       } else {
-        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128>), grid, dim3(512), 0, s, p);
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3>), grid, dim3(512), 0, s, p);
       }
       return check_launch(mode == MODE_FWD ? "conv2d_fwd(halo)" : "conv2d_dgrad(halo)");
     }
