@@ -192,8 +192,21 @@ __device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&
   constexpr int PPI = 64 / LPP;      // pixels per store instruction
   const int half = lane >> 5, l32 = lane & 31;
   const float scale = p.scale ? *p.scale : 1.0f;
+  // activation as one select: none -> slope 1, relu -> slope 0, leaky relu -> alpha
+  const float slope = p.act == 0 ? 1.0f : (p.act == 1 ? 0.0f : p.act_alpha);
   uint16_t* __restrict__ out = (uint16_t*)p.out;
   int64_t* offs = reinterpret_cast<int64_t*>(scratch + 32 * RB);
+  // bias of the 4 consecutive channels this lane owns in every (i, g) group: vector loads up
+  // front (element-wise loads each paid a full vmcnt(0) round trip behind the prefetch DMA)
+  float4 bv[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      bv[i][g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + co_base + i * 32 + g * 8 + half * 4)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+  // epilogue form (wave-uniform): 0 plain, 1 + bias, 2 * ratio, 3 partial conv with bias
+  const int form = p.row_a ? (p.bias ? 3 : 2) : (p.bias ? 1 : 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int64_t o = opix[j];
@@ -201,31 +214,32 @@ __device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&
     const int64_t oc = o < 0 ? 0 : o;
     const float ra = p.row_a ? p.row_a[oc] : 1.0f;
     const float rb = p.row_b ? p.row_b[oc] : 1.0f;
+    auto emit = [&](auto form_c) {
+      constexpr int F = decltype(form_c)::value;
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cl = i * 32 + g * 8 + half * 4;   // channel inside the wave tile
-        float v[4];
+        for (int g = 0; g < 4; ++g) {
+          const float b4[4] = {bv[i][g].x, bv[i][g].y, bv[i][g].z, bv[i][g].w};
+          float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = acc[i][j][g * 4 + e] * scale;
-          const float bv = p.bias ? p.bias[co_base + cl + e] : 0.0f;
-          if (p.row_a) {
-            if (p.bias) t = ((t - bv) * ra + bv) * rb;
-            else t = t * ra;
-          } else if (p.bias) {
-            t = t + bv;
+          for (int e = 0; e < 4; ++e) {
+            float t = acc[i][j][g * 4 + e] * scale;
+            if (F == 1) t = t + b4[e];
+            else if (F == 2) t = t * ra;
+            else if (F == 3) t = ((t - b4[e]) * ra + b4[e]) * rb;
+            v[e] = t > 0.f ? t : t * slope;
           }
-          if (p.act == 1) t = t > 0.f ? t : 0.f;
-          else if (p.act == 2) t = t > 0.f ? t : t * p.act_alpha;
-          v[e] = t;
+          uint2 pk;
+          pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+          pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+          *reinterpret_cast<uint2*>(scratch + l32 * RB + (i * 32 + g * 8 + half * 4) * 2) = pk;
         }
-        uint2 pk;
-        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-        *reinterpret_cast<uint2*>(scratch + l32 * RB + cl * 2) = pk;
-      }
+    };
+    if (form == 0) emit(std::integral_constant<int, 0>());
+    else if (form == 1) emit(std::integral_constant<int, 1>());
+    else if (form == 2) emit(std::integral_constant<int, 2>());
+    else emit(std::integral_constant<int, 3>());
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 32 / PPI; ++k) {
@@ -928,7 +942,7 @@ igemm_big_kernel(const IgemmParams p) {
 //   pixel (y0 + a, x0 + b) is patch pixel (a + dy, b + dx) with (dy, dx) = (ky, kx) forward and
 //   (2 - ky, 2 - kx) for the data gradient.  16-byte chunks are XOR-swizzled with (r >> 1) & 7;
 //   the 32 consecutive rows of a fragment read stay conflict-free for any start row.
-template <int MODE, int CO, int WST>
+template <int MODE, int CO, int WST, bool STREAM>
 __global__ void __launch_bounds__(512)
 igemm_halo_kernel(const IgemmParams p) {
   typedef uint16_t T;
@@ -956,82 +970,92 @@ igemm_halo_kernel(const IgemmParams p) {
   const int wm = wave >> 2, wn = wave & 3;
   const int half = lane >> 5, l32 = lane & 31;
 
-  int bt = blockIdx.x;
-  const int tx = bt % p.halo_tx; bt /= p.halo_tx;
-  const int ty = bt % p.halo_ty;
-  const int img = bt / p.halo_ty;
-  const int y0 = ty * TH, x0 = tx * TW;
-  const int n0 = blockIdx.y * CO;
-  const int oy0 = y0 - (MODE == MODE_FWD ? p.pad_t : 2 - p.pad_t);
-  const int ox0 = x0 - (MODE == MODE_FWD ? p.pad_l : 2 - p.pad_l);
   const int Cr = p.sC;
   const int nslabs = Cr / 64;
   const T* __restrict__ src = (const T*)p.src;
   const T* zero = reinterpret_cast<const T*>(g_zero_page);
-
-  // ---- patch pieces of this wave: piece s*8 + wave, rows 8*piece + lane/8
   const int lrow = lane >> 3;
-  const T* xptr[XS];
-  int xmk[XS];
-#pragma unroll
-  for (int sl = 0; sl < XS; ++sl) {
-    const int r = (sl * 8 + wave) * 8 + lrow;
-    const int ch = (lane & 7) ^ ((r >> 1) & 7);
-    const int pr = r / PC, pc = r - pr * PC;
-    const int sy = oy0 + pr;
-    int sx = ox0 + pc;
-    if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
-    bool ok = r < XROWS && (unsigned)sy < (unsigned)p.sH && (unsigned)sx < (unsigned)p.sW;
-    const int pix = (img * p.sH + (ok ? sy : 0)) * p.sW + (ok ? sx : 0);
-    if (ok && p.src_mask) ok = p.src_mask[pix] != 0.0f;
-    xptr[sl] = ok ? src + (int64_t)pix * Cr + ch * EPC : zero + ch * EPC;
-    xmk[sl] = ok ? -1 : 0;
-  }
-  // ---- weight pieces: rows (j*8 + wave)*8 + lane/8 of the CO-row tile, every row exists
   const int wch = (lane & 7) ^ (((wave * 8 + lrow) >> 1) & 7);
-  const T* wbase = (const T*)p.w + (int64_t)(n0 + wave * 8 + lrow) * p.w_n + wch * EPC;
   const int64_t wjs = 64 * p.w_n;
+  const int nco = p.oC / CO;
+  const int nitems = p.N * p.halo_ty * p.halo_tx * nco;
+
+  // ---- per work item (output patch x channel tile) state
+  struct ItemPos { int img, y0, x0, n0; };
+  ItemPos cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};
+  const T* xptr[XS];    // patch pieces of this wave: piece s*8 + wave, rows 8*piece + lane/8
+  int xmk[XS];
+  const T* wbase = nullptr;   // weight pieces: rows (j*8 + wave)*8 + lane/8 of the CO-row tile
+  const T* nxptr[XS];   // the same for the NEXT item (STREAM: its first slab / first weight
+  int nxmk[XS];         // tiles are fetched while this item's last slab is computed)
+  const T* nwbase = nullptr;
+  auto setup_item = [&](int item, ItemPos& pos, const T* (&xp)[XS], int (&xm)[XS], const T*& wb) {
+    pos.n0 = (item % nco) * CO;
+    int bt = item / nco;
+    const int tx = bt % p.halo_tx; bt /= p.halo_tx;
+    const int ty = bt % p.halo_ty;
+    pos.img = bt / p.halo_ty;
+    pos.y0 = ty * TH; pos.x0 = tx * TW;
+    const int oy0 = pos.y0 - (MODE == MODE_FWD ? p.pad_t : 2 - p.pad_t);
+    const int ox0 = pos.x0 - (MODE == MODE_FWD ? p.pad_l : 2 - p.pad_l);
+#pragma unroll
+    for (int sl = 0; sl < XS; ++sl) {
+      const int r = (sl * 8 + wave) * 8 + lrow;
+      const int ch = (lane & 7) ^ ((r >> 1) & 7);
+      const int pr = r / PC, pc = r - pr * PC;
+      const int sy = oy0 + pr;
+      int sx = ox0 + pc;
+      if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+      bool ok = r < XROWS && (unsigned)sy < (unsigned)p.sH && (unsigned)sx < (unsigned)p.sW;
+      const int pix = (pos.img * p.sH + (ok ? sy : 0)) * p.sW + (ok ? sx : 0);
+      if (ok && p.src_mask) ok = p.src_mask[pix] != 0.0f;
+      xp[sl] = ok ? src + (int64_t)pix * Cr + ch * EPC : zero + ch * EPC;
+      xm[sl] = ok ? -1 : 0;
+    }
+    wb = (const T*)p.w + (int64_t)(pos.n0 + wave * 8 + lrow) * p.w_n + wch * EPC;
+  };
 
   const T* zlane = zero + (lane & 7) * EPC;
-  auto issue_x = [&](unsigned char* xb, int sl, int slab, bool real) {
+  // piece sl of the patch whose pointers are (xp, xm), channel slab `slab`
+  auto issue_x = [&](unsigned char* xb, int sl, const T* xp, int xm, int slab, bool real) {
     const bool live = real && sl * 8 + wave < XPIECES;   // wave-uniform
-    const T* srcp = live ? xptr[sl] + ((slab * 64) & xmk[sl]) : zlane;
     if (live)
-      __builtin_amdgcn_global_load_lds((gas_ptr)srcp, (las_ptr)(xb + (sl * 8 + wave) * 8 * ROW2), 16,
-                                       0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)(xp + ((slab * 64) & xm)),
+                                       (las_ptr)(xb + (sl * 8 + wave) * 8 * ROW2), 16, 0, 0);
     else
-      __builtin_amdgcn_global_load_lds((gas_ptr)srcp, (las_ptr)sink, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gas_ptr)zlane, (las_ptr)sink, 16, 0, 0);
   };
-  auto issue_w = [&](unsigned char* wt, int j, int tap, int slab, bool real) {
+  auto issue_w = [&](unsigned char* wt, int j, const T* wb0, int tap, int slab, bool real) {
     // (wb is laundered so that the 18 x WS addresses of the unrolled K steps are recomputed
     // from scalars instead of being hoisted and spilled)
-    const T* wb = wbase;
+    const T* wb = wb0;
     asm volatile("" : "+v"(wb));
     const int64_t soff = (int64_t)tap * p.w_tap + slab * 64 + j * wjs;   // wave-uniform
-    // an idle copy lands in a stage nobody reads again
-    const T* srcp = real ? wb + soff : zlane;
-    __builtin_amdgcn_global_load_lds((gas_ptr)srcp, (las_ptr)(wt + (j * 8 + wave) * 8 * ROW2), 16, 0,
-                                     0);
+    if (real)
+      __builtin_amdgcn_global_load_lds((gas_ptr)(wb + soff),
+                                       (las_ptr)(wt + (j * 8 + wave) * 8 * ROW2), 16, 0, 0);
+    else
+      __builtin_amdgcn_global_load_lds((gas_ptr)zlane, (las_ptr)sink, 16, 0, 0);
   };
 
   f32x16_t acc[NI][2];
+  // first patch slab and the first DIST weight tiles of the current item
+  auto issue_prologue = [&]() {
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+    for (int sl = 0; sl < XS; ++sl) issue_x(xb0, sl, xptr[sl], xmk[sl], 0, true);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WS; ++j) issue_w(wst0, j, wbase, 0, 0, true);
+    if (WST == 3) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#pragma unroll
-  for (int sl = 0; sl < XS; ++sl) issue_x(xb0, sl, 0, true);
-#pragma unroll
-  for (int j = 0; j < WS; ++j) issue_w(wst0, j, 0, 0, true);
-  if (WST == 3) {
-#pragma unroll
-    for (int j = 0; j < WS; ++j) issue_w(wst1, j, 1, 0, true);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-  __builtin_amdgcn_s_barrier();
+      for (int j = 0; j < WS; ++j) issue_w(wst1, j, wbase, 1, 0, true);
+    }
+  };
+  int item = blockIdx.x;
+  bool more = item + (int)gridDim.x < nitems;
+  setup_item(item, cur, xptr, xmk, wbase);
+  if (STREAM && more) setup_item(item + gridDim.x, nxt, nxptr, nxmk, nwbase);
+  issue_prologue();
+  if (STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
   const int wrow0 = wm * (CO / 2) + l32;
   const int wsw = (wrow0 >> 1) & 7;
@@ -1039,6 +1063,21 @@ igemm_halo_kernel(const IgemmParams p) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) rb[j] = (wn * 2 + j) * PC + l32;
 
+  // Persistent over work items (grid = one workgroup per CU): the next item's prologue DMA is
+  // issued before this item's epilogue, and the epilogue's stores drain under the next item's
+  // K loop (the 128-channel layers have only 18 K steps per item: prologue + epilogue were 40 %
+  // of their time as one workgroup per item).
+  for (;;) {
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // prologue landed (STREAM: only the first item has one; later items' first patch slab and
+  // weight tiles arrive through the normal K-step prefetch of the previous item)
+  if (!STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // ping-pong: channel half 1 runs one slot behind
   // One K step = one tap of one slab (see igemm_big_kernel for the slot / hand-off rules).
   // Additional hand-off: the patch of slab+1 is DMA'd one piece per K step (taps 0..XS-1, in
@@ -1051,9 +1090,18 @@ igemm_halo_kernel(const IgemmParams p) {
     constexpr int ky = tap / 3, kx = tap - ky * 3;
     constexpr int toff = MODE == MODE_FWD ? ky * PC + kx : (2 - ky) * PC + (2 - kx);
     constexpr int ntap = (tap + DIST) % 9;
-    const bool has_next = tap + DIST < 9 || next_slab;
-    const int nslab = tap + DIST >= 9 ? slab + 1 : slab;
-    const bool x_piece = tap < XS && next_slab;
+    // STREAM: past the last slab of this item the prefetch continues with the next item
+    const bool last_slab = !next_slab;
+    const bool cont = next_slab || (STREAM && more);
+    const bool has_next = tap + DIST < 9 || cont;
+    const bool wrap_item = STREAM && last_slab && tap + DIST >= 9;
+    const int nslab = tap + DIST >= 9 ? (last_slab ? 0 : slab + 1) : slab;
+    const T* wfar = wrap_item ? nwbase : wbase;
+    const bool x_piece = tap < XS && cont;
+    const int xsl = tap < XS ? tap : 0;
+    const T* xfar = (STREAM && last_slab) ? nxptr[xsl] : xptr[xsl];
+    const int xfm = (STREAM && last_slab) ? nxmk[xsl] : xmk[xsl];
+    const int xslab = last_slab ? 0 : slab + 1;
     const unsigned char* wt = wcur + wrow0 * ROW2;
     const unsigned char* xr[2];
     int xsw[2];
@@ -1082,14 +1130,14 @@ igemm_halo_kernel(const IgemmParams p) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if (NP == 4 && ph < 2) {
-        issue_w(wnxt, 2 * ph, ntap, nslab, has_next);
-        issue_w(wnxt, 2 * ph + 1, ntap, nslab, has_next);
+        issue_w(wnxt, 2 * ph, wfar, ntap, nslab, has_next);
+        issue_w(wnxt, 2 * ph + 1, wfar, ntap, nslab, has_next);
       }
       if (NP == 2 && ph == 0) {
-        issue_w(wnxt, 0, ntap, nslab, has_next);
-        issue_w(wnxt, 1, ntap, nslab, has_next);
+        issue_w(wnxt, 0, wfar, ntap, nslab, has_next);
+        issue_w(wnxt, 1, wfar, ntap, nslab, has_next);
       }
-      if (ph == NP - 2 + (NP == 2)) issue_x(xnxt, tap < XS ? tap : 0, slab + 1, x_piece);
+      if (ph == NP - 2 + (NP == 2)) issue_x(xnxt, xsl, xfar, xfm, xslab, x_piece);
       if (ph == NP - 1) {
         // the weight tile of the NEXT K step must have landed; younger DMA stays in flight:
         // this K step's patch piece and, with three weight stages, this K step's weight pieces
@@ -1148,13 +1196,39 @@ igemm_halo_kernel(const IgemmParams p) {
   int64_t opix[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int y = y0 + wn * 2 + j, x = x0 + l32;
-    opix[j] = (y < p.oH && x < p.oW && !(p.dbg & 1)) ? ((int64_t)img * p.oH + y) * p.oW + x : -1;
+    const int y = cur.y0 + wn * 2 + j, x = cur.x0 + l32;
+    opix[j] = (y < p.oH && x < p.oW && !(p.dbg & 1)) ? ((int64_t)cur.img * p.oH + y) * p.oW + x : -1;
   }
-  // every wave is past its last fragment read; the patch buffers become the epilogue scratch
-  // (idle copies of the last K steps only touch the weight stages and `sink`)
-  store_wave_lds<NI>(p, acc, opix, n0 + wm * (CO / 2), lane,
-                     (wave < 4 ? xb0 : xb1) + (wave & 3) * kEpiScratch<NI>);
+  const int co_base = cur.n0 + wm * (CO / 2);
+  // Every wave is past its last fragment read.  xb1 is the epilogue scratch (the last K steps'
+  // idle copies only touch `sink`); xb0 and the first weight stages hold / take the next item's
+  // first slab and weight tiles.
+  item += gridDim.x;
+  const bool have = item < nitems;
+  if (have) {
+    if (STREAM) {
+      cur = nxt; wbase = nwbase;
+#pragma unroll
+      for (int sl = 0; sl < XS; ++sl) { xptr[sl] = nxptr[sl]; xmk[sl] = nxmk[sl]; }
+      more = item + (int)gridDim.x < nitems;
+    }
+  }
+  if (have && !STREAM) {
+    setup_item(item, cur, xptr, xmk, wbase);
+    issue_prologue();
+  }
+  unsigned char* scratch = xb1 + wave * kEpiScratch<2>;
+  if (p.dbg & 4) {
+  } else if (NI == 2) {
+    store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane, scratch);
+  } else {
+    store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane, scratch);
+    store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64, lane,
+                      scratch);
+  }
+  if (!have) break;
+  if (STREAM && more) setup_item(item + gridDim.x, nxt, nxptr, nxmk, nwbase);
+  }
 }
 
 // ------------------------------------------------------------------------------- wgrad
@@ -1963,13 +2037,21 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       p.dbg = getenv("SE3DS_DBG") ? atoi(getenv("SE3DS_DBG")) : 0;
       p.halo_ty = ceil_div(p.oH, 8);
       p.halo_tx = ceil_div(p.oW, 32);
-      dim3 grid((unsigned)(p.N * p.halo_ty * p.halo_tx), (unsigned)(p.oC / co));
+      const int64_t items = (int64_t)p.N * p.halo_ty * p.halo_tx * (p.oC / co);
+      dim3 grid((unsigned)(items < 256 ? items : 256));   // persistent: one workgroup per CU
       if (co == 256) {
-        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256, 2>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2>), grid, dim3(512), 0, s, p);
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256, 2, false>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2, false>), grid, dim3(512), 0, s, p);
       } else {
-        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3>), grid, dim3(512), 0, s, p);
+        // streaming across work items needs the patch-buffer parity to repeat per item
+        const bool stream = ((p.sC / 64) % 2) == 0 && !(getenv("SE3DS_HALO_STREAM") && atoi(getenv("SE3DS_HALO_STREAM")) == 0);
+        if (stream) {
+          if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3, true>), grid, dim3(512), 0, s, p);
+          else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3, true>), grid, dim3(512), 0, s, p);
+        } else {
+          if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3, false>), grid, dim3(512), 0, s, p);
+          else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3, false>), grid, dim3(512), 0, s, p);
+        }
       }
       return check_launch(mode == MODE_FWD ? "conv2d_fwd(halo)" : "conv2d_dgrad(halo)");
     }
