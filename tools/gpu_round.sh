@@ -1,6 +1,7 @@
 # full verification pass: GPU tests, smoke, default bench (timed), forced-overlap bench
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+ulimit -c 0
 mkdir -p gpurun_out
 SECONDS=0
 timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
