@@ -75,7 +75,6 @@ struct IgemmParams {
   int act; float act_alpha;  // 0 none, 1 relu, 2 leaky relu
   int vec;                // reduction channels % BK == 0 -> vector gather
   int halo_ty, halo_tx;   // igemm_halo_kernel: output tiles per image (rows of 8, columns of 32)
-  int dbg;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
@@ -181,75 +180,95 @@ __device__ __forceinline__ void store_pixel(const IgemmParams& p, f32x16_t (&acc
 // one pixel's contiguous NI*64 bytes.  LDS instructions of one wave execute in order, so the
 // wave needs no barrier between its own ds_write and ds_read.
 // opix[j]: output pixel index of (fragment j, lane & 31), or -1.  scratch: kEpiScratch<NI> bytes.
-template <int NI> constexpr int kEpiScratch = 32 * (NI * 64 + 16) + 256;
+template <int NI, int PXC = 32> constexpr int kEpiScratch = PXC * (NI * 64 + 16) + 256;
 
-template <int NI>
-__device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&acc)[NI][2],
-                                               const int64_t (&opix)[2], int co_base, int lane,
-                                               unsigned char* scratch) {
+// PXC: pixels parked per pass (32, or 16 to halve the scratch).  bias4(cl) returns the bias of
+// channels co_base + cl .. + 3 (zeros without bias); `scale` is the spectral 1/(sigma+eps).
+template <int NI, int PXC, typename BiasFn>
+__device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16_t (&acc)[NI][2],
+                                                    const int64_t (&opix)[2], int co_base, int lane,
+                                                    unsigned char* scratch, float scale,
+                                                    BiasFn bias4) {
   constexpr int RB = NI * 64 + 16;   // padded row bytes
   constexpr int LPP = NI * 4;        // lanes per pixel in the write-back
   constexpr int PPI = 64 / LPP;      // pixels per store instruction
+  constexpr int NPASS = 32 / PXC;
   const int half = lane >> 5, l32 = lane & 31;
-  const float scale = p.scale ? *p.scale : 1.0f;
   // activation as one select: none -> slope 1, relu -> slope 0, leaky relu -> alpha
   const float slope = p.act == 0 ? 1.0f : (p.act == 1 ? 0.0f : p.act_alpha);
   uint16_t* __restrict__ out = (uint16_t*)p.out;
-  int64_t* offs = reinterpret_cast<int64_t*>(scratch + 32 * RB);
-  // bias of the 4 consecutive channels this lane owns in every (i, g) group: vector loads up
-  // front (element-wise loads each paid a full vmcnt(0) round trip behind the prefetch DMA)
+  int64_t* offs = reinterpret_cast<int64_t*>(scratch + PXC * RB);
   float4 bv[NI][4];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      bv[i][g] = p.bias ? *reinterpret_cast<const float4*>(p.bias + co_base + i * 32 + g * 8 + half * 4)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 4; ++g) bv[i][g] = bias4(i * 32 + g * 8 + half * 4);
   // epilogue form (wave-uniform): 0 plain, 1 + bias, 2 * ratio, 3 partial conv with bias
   const int form = p.row_a ? (p.bias ? 3 : 2) : (p.bias ? 1 : 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int64_t o = opix[j];
-    if (half == 0) offs[l32] = o;
     const int64_t oc = o < 0 ? 0 : o;
     const float ra = p.row_a ? p.row_a[oc] : 1.0f;
     const float rb = p.row_b ? p.row_b[oc] : 1.0f;
-    auto emit = [&](auto form_c) {
-      constexpr int F = decltype(form_c)::value;
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+    for (int ps = 0; ps < NPASS; ++ps) {
+      // this pass parks pixels ps*PXC .. +PXC-1 of fragment j (lanes owning other pixels idle)
+      const bool mine = NPASS == 1 || (l32 / PXC) == ps;
+      const int lp = l32 % PXC;
+      if (mine && half == 0) offs[lp] = o;
+      auto emit = [&](auto form_c) {
+        constexpr int F = decltype(form_c)::value;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float b4[4] = {bv[i][g].x, bv[i][g].y, bv[i][g].z, bv[i][g].w};
-          float v[4];
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t = acc[i][j][g * 4 + e] * scale;
-            if (F == 1) t = t + b4[e];
-            else if (F == 2) t = t * ra;
-            else if (F == 3) t = ((t - b4[e]) * ra + b4[e]) * rb;
-            v[e] = t > 0.f ? t : t * slope;
+          for (int g = 0; g < 4; ++g) {
+            const float b4[4] = {bv[i][g].x, bv[i][g].y, bv[i][g].z, bv[i][g].w};
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t = acc[i][j][g * 4 + e] * scale;
+              if (F == 1) t = t + b4[e];
+              else if (F == 2) t = t * ra;
+              else if (F == 3) t = ((t - b4[e]) * ra + b4[e]) * rb;
+              v[e] = t > 0.f ? t : t * slope;
+            }
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            if (mine)
+              *reinterpret_cast<uint2*>(scratch + lp * RB + (i * 32 + g * 8 + half * 4) * 2) = pk;
           }
-          uint2 pk;
-          pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-          pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-          *reinterpret_cast<uint2*>(scratch + l32 * RB + (i * 32 + g * 8 + half * 4) * 2) = pk;
-        }
-    };
-    if (form == 0) emit(std::integral_constant<int, 0>());
-    else if (form == 1) emit(std::integral_constant<int, 1>());
-    else if (form == 2) emit(std::integral_constant<int, 2>());
-    else emit(std::integral_constant<int, 3>());
-    __builtin_amdgcn_wave_barrier();
+      };
+      if (form == 0) emit(std::integral_constant<int, 0>());
+      else if (form == 1) emit(std::integral_constant<int, 1>());
+      else if (form == 2) emit(std::integral_constant<int, 2>());
+      else emit(std::integral_constant<int, 3>());
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int k = 0; k < 32 / PPI; ++k) {
-      const int px = k * PPI + lane / LPP, c16 = lane % LPP;
-      const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * RB + c16 * 16);
-      const int64_t po = offs[px];
-      if (po >= 0) *reinterpret_cast<uint4*>(out + po * p.oC + co_base + c16 * 8) = v;
+      for (int k = 0; k < PXC / PPI; ++k) {
+        const int px = k * PPI + lane / LPP, c16 = lane % LPP;
+        const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * RB + c16 * 16);
+        const int64_t po = offs[px];
+        if (po >= 0) *reinterpret_cast<uint4*>(out + po * p.oC + co_base + c16 * 8) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
   }
+}
+
+template <int NI>
+__device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&acc)[NI][2],
+                                               const int64_t (&opix)[2], int co_base, int lane,
+                                               unsigned char* scratch) {
+  const float scale = p.scale ? *p.scale : 1.0f;
+  // vector loads up front (element-wise loads each paid a full vmcnt(0) round trip behind the
+  // prefetch DMA)
+  auto bias4 = [&](int cl) {
+    return p.bias ? *reinterpret_cast<const float4*>(p.bias + co_base + cl)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  store_wave_lds_impl<NI, 32>(p, acc, opix, co_base, lane, scratch, scale, bias4);
 }
 
 // m_base / co_base: first pixel row / output channel of this wave's sub-tile.
@@ -942,7 +961,7 @@ igemm_big_kernel(const IgemmParams p) {
 //   pixel (y0 + a, x0 + b) is patch pixel (a + dy, b + dx) with (dy, dx) = (ky, kx) forward and
 //   (2 - ky, 2 - kx) for the data gradient.  16-byte chunks are XOR-swizzled with (r >> 1) & 7;
 //   the 32 consecutive rows of a fragment read stay conflict-free for any start row.
-template <int MODE, int CO, int WST, bool STREAM>
+template <int MODE, int CO, int WST>
 __global__ void __launch_bounds__(512)
 igemm_halo_kernel(const IgemmParams p) {
   typedef uint16_t T;
@@ -982,13 +1001,10 @@ igemm_halo_kernel(const IgemmParams p) {
 
   // ---- per work item (output patch x channel tile) state
   struct ItemPos { int img, y0, x0, n0; };
-  ItemPos cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};
+  ItemPos cur = {0, 0, 0, 0};
   const T* xptr[XS];    // patch pieces of this wave: piece s*8 + wave, rows 8*piece + lane/8
   int xmk[XS];
   const T* wbase = nullptr;   // weight pieces: rows (j*8 + wave)*8 + lane/8 of the CO-row tile
-  const T* nxptr[XS];   // the same for the NEXT item (STREAM: its first slab / first weight
-  int nxmk[XS];         // tiles are fetched while this item's last slab is computed)
-  const T* nwbase = nullptr;
   auto setup_item = [&](int item, ItemPos& pos, const T* (&xp)[XS], int (&xm)[XS], const T*& wb) {
     pos.n0 = (item % nco) * CO;
     int bt = item / nco;
@@ -1051,11 +1067,8 @@ igemm_halo_kernel(const IgemmParams p) {
     }
   };
   int item = blockIdx.x;
-  bool more = item + (int)gridDim.x < nitems;
   setup_item(item, cur, xptr, xmk, wbase);
-  if (STREAM && more) setup_item(item + gridDim.x, nxt, nxptr, nxmk, nwbase);
   issue_prologue();
-  if (STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 
   const int wrow0 = wm * (CO / 2) + l32;
   const int wsw = (wrow0 >> 1) & 7;
@@ -1066,7 +1079,9 @@ igemm_halo_kernel(const IgemmParams p) {
   // Persistent over work items (grid = one workgroup per CU): the next item's prologue DMA is
   // issued before this item's epilogue, and the epilogue's stores drain under the next item's
   // K loop (the 128-channel layers have only 18 K steps per item: prologue + epilogue were 40 %
-  // of their time as one workgroup per item).
+  // of their time as one workgroup per item).  Streaming the next item's first slab through the
+  // regular K-step prefetch instead was measured slower (1.63 vs 1.43 ms on 3x3 128->128
+  // @512x1024) and was dropped.
   for (;;) {
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -1074,9 +1089,7 @@ igemm_halo_kernel(const IgemmParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // prologue landed (STREAM: only the first item has one; later items' first patch slab and
-  // weight tiles arrive through the normal K-step prefetch of the previous item)
-  if (!STREAM) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): prologue landed, older stores retired
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // ping-pong: channel half 1 runs one slot behind
   // One K step = one tap of one slab (see igemm_big_kernel for the slot / hand-off rules).
@@ -1090,18 +1103,14 @@ igemm_halo_kernel(const IgemmParams p) {
     constexpr int ky = tap / 3, kx = tap - ky * 3;
     constexpr int toff = MODE == MODE_FWD ? ky * PC + kx : (2 - ky) * PC + (2 - kx);
     constexpr int ntap = (tap + DIST) % 9;
-    // STREAM: past the last slab of this item the prefetch continues with the next item
-    const bool last_slab = !next_slab;
-    const bool cont = next_slab || (STREAM && more);
-    const bool has_next = tap + DIST < 9 || cont;
-    const bool wrap_item = STREAM && last_slab && tap + DIST >= 9;
-    const int nslab = tap + DIST >= 9 ? (last_slab ? 0 : slab + 1) : slab;
-    const T* wfar = wrap_item ? nwbase : wbase;
-    const bool x_piece = tap < XS && cont;
+    const bool has_next = tap + DIST < 9 || next_slab;
+    const int nslab = tap + DIST >= 9 ? slab + 1 : slab;
+    const T* wfar = wbase;
+    const bool x_piece = tap < XS && next_slab;
     const int xsl = tap < XS ? tap : 0;
-    const T* xfar = (STREAM && last_slab) ? nxptr[xsl] : xptr[xsl];
-    const int xfm = (STREAM && last_slab) ? nxmk[xsl] : xmk[xsl];
-    const int xslab = last_slab ? 0 : slab + 1;
+    const T* xfar = xptr[xsl];
+    const int xfm = xmk[xsl];
+    const int xslab = slab + 1;
     const unsigned char* wt = wcur + wrow0 * ROW2;
     const unsigned char* xr[2];
     int xsw[2];
@@ -1187,7 +1196,7 @@ igemm_halo_kernel(const IgemmParams p) {
   auto slab_odd = [&](int slab, bool next_slab) {
     slab_body(std::integral_constant<int, 1>(), slab, next_slab);
   };
-  for (int slab = 0; slab < ((p.dbg & 2) ? 0 : nslabs); slab += 2) {
+  for (int slab = 0; slab < nslabs; slab += 2) {
     slab_even(slab, slab + 1 < nslabs);
     if (slab + 1 < nslabs) slab_odd(slab + 1, slab + 2 < nslabs);
   }
@@ -1197,7 +1206,7 @@ igemm_halo_kernel(const IgemmParams p) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int y = cur.y0 + wn * 2 + j, x = cur.x0 + l32;
-    opix[j] = (y < p.oH && x < p.oW && !(p.dbg & 1)) ? ((int64_t)cur.img * p.oH + y) * p.oW + x : -1;
+    opix[j] = (y < p.oH && x < p.oW) ? ((int64_t)cur.img * p.oH + y) * p.oW + x : -1;
   }
   const int co_base = cur.n0 + wm * (CO / 2);
   // Every wave is past its last fragment read.  xb1 is the epilogue scratch (the last K steps'
@@ -1206,28 +1215,18 @@ igemm_halo_kernel(const IgemmParams p) {
   item += gridDim.x;
   const bool have = item < nitems;
   if (have) {
-    if (STREAM) {
-      cur = nxt; wbase = nwbase;
-#pragma unroll
-      for (int sl = 0; sl < XS; ++sl) { xptr[sl] = nxptr[sl]; xmk[sl] = nxmk[sl]; }
-      more = item + (int)gridDim.x < nitems;
-    }
-  }
-  if (have && !STREAM) {
     setup_item(item, cur, xptr, xmk, wbase);
     issue_prologue();
   }
+  // (an epilogue scratch of its own that is not an LDS-DMA target, with the bias staged in LDS
+  // so that the epilogue issues no global load, was measured slower: 1.62 vs 1.44 ms on the
+  // 3x3 128->128 @512x1024 layer)
   unsigned char* scratch = xb1 + wave * kEpiScratch<2>;
-  if (p.dbg & 4) {
-  } else if (NI == 2) {
-    store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane, scratch);
-  } else {
-    store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane, scratch);
-    store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64, lane,
-                      scratch);
-  }
+  store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane, scratch);
+  if (NI == 4)
+    store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64,
+                      lane, scratch);
   if (!have) break;
-  if (STREAM && more) setup_item(item + gridDim.x, nxt, nxptr, nxmk, nwbase);
   }
 }
 
@@ -2096,24 +2095,16 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   if (glds && dtype == SE3DS_BF16 && stride == 1 && kh == 3 && kw == 3) {
     const int co = halo_tile_channels(p);
     if (co) {
-      p.dbg = getenv("SE3DS_DBG") ? atoi(getenv("SE3DS_DBG")) : 0;
       p.halo_ty = ceil_div(p.oH, 8);
       p.halo_tx = ceil_div(p.oW, 32);
       const int64_t items = (int64_t)p.N * p.halo_ty * p.halo_tx * (p.oC / co);
       dim3 grid((unsigned)(items < 256 ? items : 256));   // persistent: one workgroup per CU
       if (co == 256) {
-        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256, 2, false>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2, false>), grid, dim3(512), 0, s, p);
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256, 2>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2>), grid, dim3(512), 0, s, p);
       } else {
-        // streaming across work items needs the patch-buffer parity to repeat per item
-        const bool stream = ((p.sC / 64) % 2) == 0 && !(getenv("SE3DS_HALO_STREAM") && atoi(getenv("SE3DS_HALO_STREAM")) == 0);
-        if (stream) {
-          if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3, true>), grid, dim3(512), 0, s, p);
-          else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3, true>), grid, dim3(512), 0, s, p);
-        } else {
-          if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3, false>), grid, dim3(512), 0, s, p);
-          else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3, false>), grid, dim3(512), 0, s, p);
-        }
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3>), grid, dim3(512), 0, s, p);
       }
       return check_launch(mode == MODE_FWD ? "conv2d_fwd(halo)" : "conv2d_dgrad(halo)");
     }
