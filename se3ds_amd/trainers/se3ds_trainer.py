@@ -116,6 +116,11 @@ class GAN(gan_manager.GANManager):
         # SyncBN statistics all-reduces the backward pass is waiting on (same issue order on
         # every rank, so the two communicators cannot cross)
         group = dist_utils.clone_group(group)
+        # build the communicator now, at a point every rank reaches together, instead of
+        # lazily at the first bucket in the middle of the backward pass
+        warm = torch.zeros(1, dtype=torch.float32, device=G.store.theta.device)
+        torch.distributed.all_reduce(warm, group=group)
+        torch.cuda.synchronize(G.store.theta.device)
       self._sync = dist_utils.GradSync(G.store.theta.device, group)
       self._g_segments = G.store.segments(G.SEGMENTS)
       covered = sum(t1 - t0 for t0, t1, _, _ in self._g_segments.values())
@@ -149,6 +154,7 @@ class GAN(gan_manager.GANManager):
     L = _L()
     dev = image.device
     f32 = dict(dtype=torch.float32, device=dev)
+    sync = self._grad_sync()   # (first call builds the gradient communicator: do it up front)
 
     # ---- generator forward (both "tapes" of the reference share this forward)
     ctx_g = G.make_ctx(training=True, record=True, group=group)
@@ -217,7 +223,6 @@ class GAN(gan_manager.GANManager):
     self._set_input_grad(x_all, False)
     self._backward_tape(ctx_d, tape_d, seeds_d, logits)
     D.spectral.backward_fixup()
-    sync = self._grad_sync()
     if sync is not None:
       d_norm = self._sync_discriminator(sync)
     # ---- pass 2: gradient of the generator loss w.r.t. the fake images (gen_tape, :236)

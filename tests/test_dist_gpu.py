@@ -1,0 +1,28 @@
+"""Two replicas on one MI355X (gloo between them): the multi-replica trainer path end to end."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(('127.0.0.1', 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def test_two_replicas_share_one_gpu_over_gloo():
+  env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+         os.path.join(ROOT, 'tests', '_dist_gpu_worker.py')]
+  r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+  assert 'DIST_GPU_OK' in r.stdout
