@@ -366,11 +366,402 @@ splat_debug_copy_kernel(SplatWs ws, int64_t total, int32_t* idx_out, float* z_ou
   }
 }
 
+// ------------------------------------------------------------------ binned splat (owner computes)
+// The scatter version above pays 4 agent-scope atomics per point on memory that eight
+// non-coherent L2s share (executed memory-side, ~28 G/s: 350 us at 4 M points).  Here the points
+// are first binned by TARGET tile (16 x 128 pixels): per-block LDS histograms -> one global add
+// per (block, tile) -> scan -> scatter of (pixel-in-tile, z, features) records; then one
+// workgroup per tile resolves z-min and the per-channel max in LDS and writes depth, features
+// and mask directly.  min / max do not depend on the record order, so the result is bit-identical
+// to the scatter version.  Used for <= 7 channels and <= 4096 tiles per image.
+constexpr int kTileY = 16, kTileX = 128, kTilePx = kTileY * kTileX;
+constexpr int kMaxTiles = 4096;      // per image (LDS histogram)
+constexpr int kMaxBinChannels = 7;
+
+struct BinWs {
+  uint32_t* tile_count;   // [nb]
+  uint32_t* tile_off;     // [nb + 1]
+  uint32_t* cursor;       // [nb]
+  uint32_t* fpart2;       // [nb][C] sink partials of the occluded points, per tile
+  int32_t* rec_idx;       // [N*M] pixel inside the tile
+  float* rec_z;           // [N*M]
+  float* rec_feat;        // [N*M][C]
+};
+__host__ __device__ inline size_t align16(size_t v) { return (v + 15) / 16 * 16; }
+__host__ __device__ inline size_t bin_ws_bytes(int n, int64_t m, int height, int width, int channels) {
+  const size_t nb = (size_t)n * ceil_div(height, kTileY) * ceil_div(width, kTileX);
+  const size_t pts = (size_t)n * (size_t)(m > 0 ? m : 0);
+  return align16(4 * nb) + align16(4 * (nb + 1)) + align16(4 * nb) + align16(4 * nb * channels) +
+         align16(4 * pts) + align16(4 * pts) + align16(4 * pts * channels);
+}
+__host__ __device__ inline BinWs carve_bin_ws(void* base, int n, int64_t m, int height, int width,
+                                             int channels) {
+  const size_t nb = (size_t)n * ceil_div(height, kTileY) * ceil_div(width, kTileX);
+  const size_t pts = (size_t)n * (size_t)(m > 0 ? m : 0);
+  char* p = (char*)base;
+  BinWs w;
+  w.tile_count = (uint32_t*)p; p += align16(4 * nb);
+  w.tile_off = (uint32_t*)p; p += align16(4 * (nb + 1));
+  w.cursor = (uint32_t*)p; p += align16(4 * nb);
+  w.fpart2 = (uint32_t*)p; p += align16(4 * nb * channels);
+  w.rec_idx = (int32_t*)p; p += align16(4 * pts);
+  w.rec_z = (float*)p; p += align16(4 * pts);
+  w.rec_feat = (float*)p;
+  return w;
+}
+
+__device__ __forceinline__ void tile_of(int32_t idx, int width, int tiles_x, int* tile, int* local) {
+  const int y = idx / width, x = idx - y * width;
+  const int ty = y / kTileY, tx = x / kTileX;
+  *tile = ty * tiles_x + tx;
+  *local = (y - ty * kTileY) * kTileX + (x - tx * kTileX);
+}
+
+// A: per point -> (idx, z) as splat_zmin_kernel, no z-buffer atomics; per-block tile histogram.
+template <typename T, bool EQUIRECT>
+__global__ void __launch_bounds__(kBlock)
+splat_bin_count_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
+                       const T* __restrict__ feats, int64_t m, int channels, int height, int width,
+                       float input_void, int ntiles, int tiles_x, SplatWs ws, BinWs bw) {
+  extern __shared__ uint32_t s_hist[];   // [ntiles]
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < ntiles; t += kBlock) s_hist[t] = 0u;
+  __syncthreads();
+  const float* X = coords + (int64_t)b * 4 * m;
+  float ox = 0.f, oy = 0.f, oz = 0.f;
+  if (EQUIRECT && offset) {
+    ox = offset[b * 3 + 0];
+    oy = offset[b * 3 + 1];
+    oz = offset[b * 3 + 2];
+  }
+  uint32_t sink = 0xffffffffu;
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < m; i0 += (int64_t)gridDim.x * kBlock) {
+    int64_t i = i0 + threadIdx.x;
+    if (i < m) {
+      float x = X[i], y = X[m + i], z = X[2 * m + i];
+      float px, py, pz;
+      if (EQUIRECT) {
+        if (offset) {
+          x = x - ox;
+          y = y - oy;
+          z = z - oz;
+        }
+        se3ds_equirect_project(x, y, z, &px, &py, &pz);
+      } else {
+        px = x;
+        py = y;
+        pz = z;
+      }
+      const T* f = feats + ((int64_t)b * m + i) * channels;
+      int fv = 1;
+      for (int k = 0; k < channels; ++k) fv &= (FeatIO<T>::load(f + k) != input_void);
+      int32_t idx = se3ds_splat_index(px, py, pz, width, height, fv);
+      ws.idx[(int64_t)b * m + i] = idx;
+      ws.z[(int64_t)b * m + i] = pz;
+      if (idx >= 0) {
+        int tile, local;
+        tile_of(idx, width, tiles_x, &tile, &local);
+        atomicAdd(&s_hist[tile], 1u);
+      } else if (pz == pz) {
+        uint32_t o = se3ds_f32_to_ordered(pz);
+        sink = o < sink ? o : sink;
+      }
+    }
+  }
+  __shared__ uint32_t s_sink[kBlock / 64];
+  sink = wave_min_u32(sink);
+  if ((threadIdx.x & 63) == 0) s_sink[threadIdx.x >> 6] = sink;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t v = s_sink[0];
+    for (int i = 1; i < kBlock / 64; ++i) v = s_sink[i] < v ? s_sink[i] : v;
+    ws.zpart[blockIdx.y * gridDim.x + blockIdx.x] = v;
+  }
+  for (int t = threadIdx.x; t < ntiles; t += kBlock)
+    if (s_hist[t]) atomicAdd(&bw.tile_count[(int64_t)b * ntiles + t], s_hist[t]);
+}
+
+// B: exclusive scan of the tile counts (one block), cursors := offsets; the same block reduces
+// the per-block sink-z partials (saves a launch).
+__global__ void __launch_bounds__(1024)
+splat_bin_scan_kernel(BinWs bw, int nb, SplatWs ws, int nparts) {
+  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_sinkz[1024 / 64];
+  {
+    uint32_t v = 0xffffffffu;
+    for (int i = threadIdx.x; i < nparts; i += 1024) v = ws.zpart[i] < v ? ws.zpart[i] : v;
+    v = wave_min_u32(v);
+    if ((threadIdx.x & 63) == 0) s_sinkz[threadIdx.x >> 6] = v;
+  }
+  const int per = ceil_div(nb, 1024);
+  const int lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+  uint32_t sum = 0;
+  for (int i = lo; i < hi; ++i) sum += bw.tile_count[i];
+  s_part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 1024; ++i) {
+      uint32_t t = s_part[i];
+      s_part[i] = run;
+      run += t;
+    }
+    bw.tile_off[nb] = run;
+    uint32_t v = s_sinkz[0];
+    for (int i = 1; i < 1024 / 64; ++i) v = s_sinkz[i] < v ? s_sinkz[i] : v;
+    *ws.sink_z = v;
+  }
+  __syncthreads();
+  uint32_t run = s_part[threadIdx.x];
+  for (int i = lo; i < hi; ++i) {
+    bw.tile_off[i] = run;
+    bw.cursor[i] = run;
+    run += bw.tile_count[i];
+  }
+}
+
+// C: scatter the valid points into their tile's record range; invalid points feed the sink.
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int channels, int width, int ntiles,
+                         int tiles_x, SplatWs ws, BinWs bw) {
+  extern __shared__ uint32_t s_mem[];   // [ntiles] counts -> bases, [ntiles] ranks
+  uint32_t* s_base = s_mem;
+  uint32_t* s_rank = s_mem + ntiles;
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < 2 * ntiles; t += kBlock) s_mem[t] = 0u;
+  __syncthreads();
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < m; i0 += (int64_t)gridDim.x * kBlock) {
+    int64_t i = i0 + threadIdx.x;
+    if (i < m) {
+      const int32_t idx = ws.idx[(int64_t)b * m + i];
+      if (idx >= 0) {
+        int tile, local;
+        tile_of(idx, width, tiles_x, &tile, &local);
+        atomicAdd(&s_base[tile], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntiles; t += kBlock) {
+    const uint32_t c = s_base[t];
+    s_base[t] = c ? atomicAdd(&bw.cursor[(int64_t)b * ntiles + t], c) : 0u;
+  }
+  __syncthreads();
+  constexpr int kMaxC = kMaxBinChannels;
+  uint32_t smax[kMaxC];
+#pragma unroll
+  for (int k = 0; k < kMaxC; ++k) smax[k] = 0u;
+  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < m; i0 += (int64_t)gridDim.x * kBlock) {
+    int64_t i = i0 + threadIdx.x;
+    if (i < m) {
+      const int32_t idx = ws.idx[(int64_t)b * m + i];
+      const T* f = feats + ((int64_t)b * m + i) * channels;
+      if (idx >= 0) {
+        int tile, local;
+        tile_of(idx, width, tiles_x, &tile, &local);
+        const uint32_t pos = s_base[tile] + atomicAdd(&s_rank[tile], 1u);
+        bw.rec_idx[pos] = local;
+        bw.rec_z[pos] = ws.z[(int64_t)b * m + i];
+#pragma unroll
+        for (int k = 0; k < kMaxC; ++k)
+          if (k < channels) bw.rec_feat[(int64_t)pos * channels + k] = FeatIO<T>::load(f + k);
+      } else {
+#pragma unroll
+        for (int k = 0; k < kMaxC; ++k)
+          if (k < channels) {
+            const float v = FeatIO<T>::load(f + k);
+            if (v == v) {
+              const uint32_t o = se3ds_f32_to_ordered(v);
+              smax[k] = o > smax[k] ? o : smax[k];
+            }
+          }
+      }
+    }
+  }
+  __shared__ uint32_t s_f[kMaxC][kBlock / 64];
+#pragma unroll
+  for (int k = 0; k < kMaxC; ++k) {
+    uint32_t v = wave_max_u32(smax[k]);
+    if ((threadIdx.x & 63) == 0) s_f[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < channels) {
+    uint32_t v = 0u;
+    for (int i = 0; i < kBlock / 64; ++i) v = s_f[threadIdx.x][i] > v ? s_f[threadIdx.x][i] : v;
+    ws.fpart[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * channels + threadIdx.x] = v;
+  }
+}
+
+// D: one workgroup per target tile: z-min, tolerance test, per-channel max, finalize.
+template <bool ORDERED>
+__global__ void __launch_bounds__(kBlock)
+splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int tiles_x,
+                          float depth_scale, float output_void, float mask_void,
+                          float* __restrict__ depth, float* __restrict__ feat,
+                          float* __restrict__ mask, SplatWs ws, BinWs bw) {
+  extern __shared__ uint32_t s_tile[];   // z[kTilePx], feat[channels][kTilePx]
+  uint32_t* s_z = s_tile;
+  uint32_t* s_fe = s_tile + kTilePx;
+  const int bt = blockIdx.x;
+  const int b = bt / ntiles, t = bt - b * ntiles;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const uint32_t fvoid = se3ds_f32_to_ordered(output_void);
+  for (int p = threadIdx.x; p < kTilePx; p += kBlock) s_z[p] = __float_as_uint(depth_scale);
+  for (int p = threadIdx.x; p < kTilePx * channels; p += kBlock) s_fe[p] = fvoid;
+  __syncthreads();
+  const uint32_t r0 = bw.tile_off[bt], r1 = bw.tile_off[bt + 1];
+  for (uint32_t r = r0 + threadIdx.x; r < r1; r += kBlock)
+    atomicMin(&s_z[bw.rec_idx[r]], __float_as_uint(bw.rec_z[r]));   // valid => z > 0
+  __syncthreads();
+  const bool have_sink_z = (*ws.sink_z != 0xffffffffu);
+  const float sink_z = se3ds_ordered_to_f32(*ws.sink_z);
+  const bool first = bt == 0;   // holds flat pixel 0, which also receives the sink
+  constexpr int kMaxC = kMaxBinChannels;
+  uint32_t smax[kMaxC];
+#pragma unroll
+  for (int k = 0; k < kMaxC; ++k) smax[k] = 0u;
+  for (uint32_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
+    const int li = bw.rec_idx[r];
+    const float z = bw.rec_z[r];
+    float zm = __uint_as_float(s_z[li]);
+    if (first && li == 0 && have_sink_z) zm = sink_z < zm ? sink_z : zm;
+    const bool keep = z < zm + 0.1f;
+#pragma unroll
+    for (int k = 0; k < kMaxC; ++k)
+      if (k < channels) {
+        const float v = bw.rec_feat[(int64_t)r * channels + k];
+        if (keep) {
+          if (ORDERED || v > 0.0f) atomicMax(&s_fe[k * kTilePx + li], se3ds_f32_to_ordered(v));
+        } else if (v == v) {
+          const uint32_t o = se3ds_f32_to_ordered(v);
+          smax[k] = o > smax[k] ? o : smax[k];
+        }
+      }
+  }
+  __shared__ uint32_t s_f[kMaxC][kBlock / 64];
+#pragma unroll
+  for (int k = 0; k < kMaxC; ++k) {
+    uint32_t v = wave_max_u32(smax[k]);
+    if ((threadIdx.x & 63) == 0) s_f[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < channels) {
+    uint32_t v = 0u;
+    for (int i = 0; i < kBlock / 64; ++i) v = s_f[threadIdx.x][i] > v ? s_f[threadIdx.x][i] : v;
+    bw.fpart2[(int64_t)bt * channels + threadIdx.x] = v;
+  }
+  // finalize (pixel 0's feature / mask fold of the sink happens in splat_pixel0_kernel)
+  const int64_t hw = (int64_t)height * width;
+  for (int p = threadIdx.x; p < kTilePx; p += kBlock) {
+    const int y = ty * kTileY + p / kTileX, x = tx * kTileX + (p % kTileX);
+    if (y >= height || x >= width) continue;
+    const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
+    float z = __uint_as_float(s_z[p]);
+    if (i == 0 && have_sink_z) z = sink_z < z ? sink_z : z;
+    float d = z < 0.0f ? 0.0f : (z > depth_scale ? depth_scale : z);
+    d = d / depth_scale;
+    depth[i] = d;
+    bool all_ok = true;
+    for (int k = 0; k < channels; ++k) {
+      const float v = se3ds_ordered_to_f32(s_fe[k * kTilePx + p]);
+      feat[i * channels + k] = v;
+      all_ok = all_ok && (v != mask_void);
+    }
+    if (mask) mask[i] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+  }
+}
+
+// sink_feat[c] = max over the per-block (invalid points) and per-tile (occluded points) partials
+// ... and flat pixel 0 then folds the sink features in and redoes its mask
+// (point_cloud_utils.py:151-152)
+__global__ void __launch_bounds__(kBlock)
+splat_sink_feat2_kernel(SplatWs ws, BinWs bw, int nparts, int nb, int channels, float* depth,
+                        float* feat, float* mask, float mask_void) {
+  __shared__ uint32_t s_red[kBlock / 64];
+  for (int c = 0; c < channels; ++c) {
+    uint32_t v = 0u;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) {
+      uint32_t t = ws.fpart[(int64_t)i * channels + c];
+      v = t > v ? t : v;
+    }
+    for (int i = threadIdx.x; i < nb; i += kBlock) {
+      uint32_t t = bw.fpart2[(int64_t)i * channels + c];
+      v = t > v ? t : v;
+    }
+    v = wave_max_u32(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < kBlock / 64; ++i) v = s_red[i] > v ? s_red[i] : v;
+      ws.sink_feat[c] = v;
+    }
+  }
+  if (threadIdx.x == 0) {   // (same thread wrote sink_feat above)
+    const float d = depth[0];
+    bool all_ok = true;
+    for (int k = 0; k < channels; ++k) {
+      float v = feat[k];
+      if (ws.sink_feat[k] != 0u) {
+        const float sv = se3ds_ordered_to_f32(ws.sink_feat[k]);
+        v = sv > v ? sv : v;
+      }
+      feat[k] = v;
+      all_ok = all_ok && (v != mask_void);
+    }
+    if (mask) mask[0] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+  }
+}
+
+template <typename T, bool EQUIRECT>
+int launch_splat_binned(const float* coords, const float* offset, const T* feats, int n, int64_t m,
+                        int channels, int height, int width, float depth_scale, float input_void,
+                        float output_void, float* depth, float* feat, float* mask, float mask_void,
+                        void* workspace, hipStream_t stream) {
+  SplatWs ws = carve_ws(workspace, n, m);
+  const size_t base = splat_hdr_bytes() + (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)m;
+  BinWs bw = carve_bin_ws((char*)workspace + align16(base), n, m, height, width, channels);
+  const int tiles_x = ceil_div(width, kTileX), tiles_y = ceil_div(height, kTileY);
+  const int ntiles = tiles_x * tiles_y, nb = n * ntiles;
+  const bool ordered = !(output_void >= 0.0f);
+  (void)hipMemsetAsync(bw.tile_count, 0, 4 * (size_t)nb, stream);
+  dim3 g_pt = point_grid(m, n, kBlock);
+  const int nparts = (int)(g_pt.x * g_pt.y);
+  hipLaunchKernelGGL((splat_bin_count_kernel<T, EQUIRECT>), g_pt, dim3(kBlock), 4 * ntiles, stream,
+                     coords, offset, feats, m, channels, height, width, input_void, ntiles, tiles_x,
+                     ws, bw);
+  hipLaunchKernelGGL(splat_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, bw, nb, ws, nparts);
+  hipLaunchKernelGGL((splat_bin_scatter_kernel<T>), g_pt, dim3(kBlock), 8 * ntiles, stream, feats, m,
+                     channels, width, ntiles, tiles_x, ws, bw);
+  const size_t tile_lds = 4 * (size_t)kTilePx * (1 + channels);
+  if (ordered)
+    hipLaunchKernelGGL(splat_tile_resolve_kernel<true>, dim3(nb), dim3(kBlock), tile_lds, stream,
+                       channels, height, width, ntiles, tiles_x, depth_scale, output_void, mask_void,
+                       depth, feat, mask, ws, bw);
+  else
+    hipLaunchKernelGGL(splat_tile_resolve_kernel<false>, dim3(nb), dim3(kBlock), tile_lds, stream,
+                       channels, height, width, ntiles, tiles_x, depth_scale, output_void, mask_void,
+                       depth, feat, mask, ws, bw);
+  hipLaunchKernelGGL(splat_sink_feat2_kernel, dim3(1), dim3(kBlock), 0, stream, ws, bw, nparts, nb,
+                     channels, depth, feat, mask, mask_void);
+  return check_launch("splat(binned)");
+}
+
 template <typename T, bool EQUIRECT>
 int launch_splat(const float* coords, const float* offset, const T* feats, int n, int64_t m,
                  int channels, int height, int width, float depth_scale, float input_void,
                  float output_void, float* depth, float* feat, float* mask, float mask_void,
                  void* workspace, hipStream_t stream) {
+  {
+    static const bool no_bin = getenv("SE3DS_SPLAT_SCATTER") != nullptr;
+    const int64_t ntiles = (int64_t)ceil_div(height, kTileY) * ceil_div(width, kTileX);
+    if (!no_bin && m > 0 && channels <= kMaxBinChannels && ntiles <= kMaxTiles &&
+        (int64_t)n * m < ((int64_t)1 << 31))
+      return launch_splat_binned<T, EQUIRECT>(coords, offset, feats, n, m, channels, height, width,
+                                              depth_scale, input_void, output_void, depth, feat,
+                                              mask, mask_void, workspace, stream);
+  }
   SplatWs ws = carve_ws(workspace, n, m);
   const int64_t npx = (int64_t)n * height * width;
   const bool ordered = !(output_void >= 0.0f);
@@ -726,10 +1117,9 @@ int se3ds_unproject_equirect(const void* feats, int feat_dtype, const float* dep
 }
 
 size_t se3ds_splat_workspace_bytes(int n, int64_t m, int height, int width, int channels) {
-  (void)height; (void)width;
-  (void)channels;
-  return splat_hdr_bytes() +
-         (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)(m > 0 ? m : 0) + 16;
+  const size_t base = splat_hdr_bytes() +
+                      (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)(m > 0 ? m : 0);
+  return align16(base) + bin_ws_bytes(n, m, height, width, channels > 0 ? channels : 1) + 16;
 }
 
 int se3ds_project_equirect(const float* xyz1, const float* offset, const void* feats,

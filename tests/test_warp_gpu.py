@@ -140,6 +140,20 @@ def test_roundtrip_property_full_size():
   assert torch.all(prgb2[torch.from_numpy(m).to(prgb2.device)] == prgb[torch.from_numpy(m).to(prgb.device)])
 
 
+def test_project_wide_features_take_the_scatter_path():
+  """More than 7 channels do not fit the binned splat's LDS tile: the global-atomic scatter
+  version must stay bit-exact too."""
+  rng = np.random.default_rng(29)
+  n, h, w, m, c = 2, 32, 64, 6000, 9
+  xyz = rng.standard_normal((n, 4, m)).astype(F32) * 3.0
+  feats = rng.integers(0, 200, (n, m, c)).astype(np.int32)
+  feats[rng.uniform(size=(n, m)) < 0.05] = -1   # void points go to the sink
+  d_o, f_o = warp_c.project_feats_to_equirectangular(feats, xyz, h, w, -1, DEPTH_SCALE)
+  d_g, f_g = pano_utils.project_feats_to_equirectangular(t(feats), t(xyz), h, w, -1, DEPTH_SCALE)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+
+
 def test_project_edge_cases():
   d = dev()
   h, w = 8, 16
