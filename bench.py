@@ -124,12 +124,12 @@ def bench_warp(args, rank, world, dev):
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
       'data': 'synthetic',
       'config': {'workload': f'warp cfg5 {h}x{w} V={views} (replicas only)'},
-      'roofline': {'bound': 'hbm', 'kernel': 'project+splat (init,zmin,resolve,finalize)',
+      'roofline': {'bound': 'hbm', 'kernel': 'project+splat (bin count, scan, scatter, per-tile resolve)',
                    'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                    'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                    'ms_per_launch': proj_ms, 'algorithmic_bytes': algo_bytes},
   }
-  if rank == 0 and not args.no_cpu_baseline:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline_warp(panos, target, h, w)
   return out
 

@@ -99,8 +99,9 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
                              f'depth+wc losses, clip, Adam, EMA), ResNet-101 gen_dims 128, '
                              f'per-GPU batch {n}, d_step_per_g_step 1',
                  'per_gpu_batch': n, 'global_batch': n * world, 'parallelism': f'dp{world}'},
-      'roofline': {'bound': 'mfma', 'kernel': 'igemm_kernel/wgrad_kernel (all conv fwd+dgrad+wgrad '
-                   'launches of one step)', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+      'roofline': {'bound': 'mfma', 'kernel': 'implicit-GEMM convolutions: igemm_halo / igemm_big / '
+                   'igemm_glds + wgrad_taps / wgrad_glds (every conv fwd, dgrad and wgrad call of '
+                   'one step)', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                    'frac': achieved / peak, 'traffic': None, 'launches': summ['launches'],
                    'avg_launch_ms': summ['ms'] / max(summ['launches'], 1),
                    'conv_ms_per_step': summ['ms'], 'conv_tflop_per_step': summ['flops'] / 1e12,
@@ -109,7 +110,7 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
           'gen/gen_gan_loss', 'dis/disc_loss', 'gen/depth_loss', 'gen/wc_loss')},
       'hbm_gib_peak': torch.cuda.max_memory_allocated(dev) / 2**30,
   }
-  if rank == 0 and not args.no_cpu_baseline:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline(args, summ['flops'] / 1e12 / n)
   return out
 
