@@ -223,24 +223,28 @@ int se3ds_norm_finalize(const float* sums, float count, int g, int c, const floa
                         const float* beta, float eps, float momentum, float* moving_mean,
                         float* moving_var, int use_moving, float* scale, float* shift, float* mean,
                         float* rstd, void* stream);
-/* y = act(x*scale + shift [+ res]) [+ post]  (scale/shift are [g][c]). */
+/* y = act(x*scale + shift [+ res]) [+ post]  (scale/shift are [g][c]).
+ * act_mask (bf16, c % 8 == 0; may be NULL): g*r*c/8 bytes, bit e of byte i = (y[8*i + e] > 0).
+ * The backward entry points below take the same buffer and then do not read y (16x less
+ * traffic for the activation derivative); with act_mask == NULL they read y. */
 int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const float* scale,
                      const float* shift, const void* res, const void* post, int act, float alpha,
-                     void* y, void* stream);
+                     void* y, void* act_mask, void* stream);
 /* sums[g][0][c] = sum dpre, sums[g][1][c] = sum dpre*xhat with dpre = dy*act'(y).  For g == 1
  * dbeta_out / dgamma_out (c floats, may be NULL) receive the two rows directly. */
 int se3ds_norm_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
                          int c, const float* mean, const float* rstd, int act, float alpha,
-                         float* sums, float* dbeta_out, float* dgamma_out, void* workspace,
-                         size_t workspace_bytes, void* stream);
+                         float* sums, float* dbeta_out, float* dgamma_out, const void* act_mask,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* dx = gamma*rstd*(dpre - S0/count - xhat*S1/count); dres = dpre when non-NULL. */
 int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
                          int c, const float* mean, const float* rstd, const float* gamma,
                          const float* sums, float count, int act, float alpha, void* dx,
-                         void* dres, void* stream);
+                         void* dres, const void* act_mask, void* stream);
 /* inference-mode backward: dx = dpre*scale; dres = dpre. */
 int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r, int c,
-                     const float* scale, int act, float alpha, void* dx, void* dres, void* stream);
+                     const float* scale, int act, float alpha, void* dx, void* dres,
+                     const void* act_mask, void* stream);
 
 /* ======================================================================================
  * Pointwise / pooling

@@ -114,5 +114,11 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act, float alpha
   if (act == 2) return y > 0.f ? 1.f : alpha;
   return 1.f;
 }
+// the same from a stored "output > 0" bit
+__device__ __forceinline__ float act_grad_from_bit(unsigned bit, int act, float alpha) {
+  if (act == 1) return bit ? 1.f : 0.f;
+  if (act == 2) return bit ? 1.f : alpha;
+  return 1.f;
+}
 
 }  // namespace se3ds

@@ -35,7 +35,8 @@ __global__ void __launch_bounds__(256)
 norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ rstd,
                     const float* __restrict__ row_scale, int64_t R, int C, int cx, int ry, int act,
-                    float alpha, int rblocks, float* __restrict__ partial) {
+                    float alpha, int rblocks, float* __restrict__ partial,
+                    const uint8_t* __restrict__ amask) {
   // grid: (rblocks, ctiles, G)
   __shared__ float red[2][256 * (VEC > 1 ? VEC : 1)];
   const int g = blockIdx.z;
@@ -71,8 +72,13 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
         }
       } else {
         float yv[VEC], xv[VEC];
+        const bool use_mask = VEC == 8 && amask != nullptr;
+        unsigned mbits = 0;
         if constexpr (VEC > 1) {
-          if (act) VT<T>::load(y + off, reinterpret_cast<float(&)[VT<T>::V]>(yv));
+          if (act) {
+            if (use_mask) mbits = amask[off >> 3];
+            else VT<T>::load(y + off, reinterpret_cast<float(&)[VT<T>::V]>(yv));
+          }
           VT<T>::load(x + off, reinterpret_cast<float(&)[VT<T>::V]>(xv));
         } else {
           if (act) yv[0] = VT<T>::ld1(y + off);
@@ -80,7 +86,10 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          float d = av[e] * rsc * (act ? act_grad_from_out(yv[e], act, alpha) : 1.f);
+          const float ag = !act ? 1.f
+                           : (use_mask ? act_grad_from_bit((mbits >> e) & 1u, act, alpha)
+                                       : act_grad_from_out(yv[e], act, alpha));
+          float d = av[e] * rsc * ag;
           s0[e] += d;
           s1[e] += d * ((xv[e] - mu[e]) * rs[e]);
         }
@@ -196,7 +205,7 @@ __global__ void __launch_bounds__(256)
 norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                   const float* __restrict__ shift, const T* __restrict__ res,
                   const T* __restrict__ post, int64_t R, int C, int cx, int ry, int act,
-                  float alpha, T* __restrict__ y) {
+                  float alpha, T* __restrict__ y, uint8_t* __restrict__ amask) {
   const int g = blockIdx.z;
   const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
   const int c0 = (blockIdx.y * cx + tx) * VEC;
@@ -229,6 +238,19 @@ norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
     }
     if constexpr (VEC > 1) VT<T>::store(y + off, reinterpret_cast<float(&)[VT<T>::V]>(o));
     else VT<T>::st1(y + off, o[0]);
+    if constexpr (VEC == 8 && sizeof(T) == 2) {
+      // one bit per element: the stored (rounded) output is > 0.  The backward kernels read
+      // this byte instead of the 16 bytes of y.
+      if (amask) {
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const uint16_t hb = f32_to_bf16(o[e]);
+          bits |= ((hb & 0x7fffu) != 0 && (hb & 0x8000u) == 0) ? (1u << e) : 0u;
+        }
+        amask[off >> 3] = (uint8_t)bits;
+      }
+    }
   }
 }
 
@@ -239,7 +261,7 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
                       const float* __restrict__ mean, const float* __restrict__ rstd,
                       const float* __restrict__ gamma, const float* __restrict__ sums, float count,
                       int64_t R, int C, int cx, int ry, int act, float alpha, T* __restrict__ dx,
-                      T* __restrict__ dres) {
+                      T* __restrict__ dres, const uint8_t* __restrict__ amask) {
   const int g = blockIdx.z;
   const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
   const int c0 = (blockIdx.y * cx + tx) * VEC;
@@ -257,9 +279,14 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
   for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
     const int64_t off = ((int64_t)g * R + r) * C + c0;
     float dv[VEC], yv[VEC], xv[VEC], o[VEC], dr[VEC];
+    const bool use_mask = VEC == 8 && amask != nullptr;
+    unsigned mbits = 0;
     if constexpr (VEC > 1) {
       VT<T>::load(dy + off, reinterpret_cast<float(&)[VT<T>::V]>(dv));
-      if (act) VT<T>::load(y + off, reinterpret_cast<float(&)[VT<T>::V]>(yv));
+      if (act) {
+        if (use_mask) mbits = amask[off >> 3];
+        else VT<T>::load(y + off, reinterpret_cast<float(&)[VT<T>::V]>(yv));
+      }
       VT<T>::load(x + off, reinterpret_cast<float(&)[VT<T>::V]>(xv));
     } else {
       dv[0] = VT<T>::ld1(dy + off);
@@ -268,7 +295,10 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float d = dv[e] * (act ? act_grad_from_out(yv[e], act, alpha) : 1.f);
+      const float ag = !act ? 1.f
+                       : (use_mask ? act_grad_from_bit((mbits >> e) & 1u, act, alpha)
+                                   : act_grad_from_out(yv[e], act, alpha));
+      float d = dv[e] * ag;
       dr[e] = d;
       float xh = (xv[e] - mu[e]) * rs[e];
       o[e] = gr[e] * (d - s0[e] - xh * s1[e]);
@@ -288,7 +318,8 @@ template <typename T, int VEC>
 __global__ void __launch_bounds__(256)
 affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                   const float* __restrict__ scale, int64_t R, int C, int cx, int ry, int act,
-                  float alpha, T* __restrict__ dx, T* __restrict__ dres) {
+                  float alpha, T* __restrict__ dx, T* __restrict__ dres,
+                  const uint8_t* __restrict__ amask) {
   const int g = blockIdx.z;
   const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
   const int c0 = (blockIdx.y * cx + tx) * VEC;
@@ -299,16 +330,24 @@ affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
   for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
     const int64_t off = ((int64_t)g * R + r) * C + c0;
     float dv[VEC], yv[VEC], o[VEC], dr[VEC];
+    const bool use_mask = VEC == 8 && amask != nullptr;
+    unsigned mbits = 0;
     if constexpr (VEC > 1) {
       VT<T>::load(dy + off, reinterpret_cast<float(&)[VT<T>::V]>(dv));
-      if (act) VT<T>::load(y + off, reinterpret_cast<float(&)[VT<T>::V]>(yv));
+      if (act) {
+        if (use_mask) mbits = amask[off >> 3];
+        else VT<T>::load(y + off, reinterpret_cast<float(&)[VT<T>::V]>(yv));
+      }
     } else {
       dv[0] = VT<T>::ld1(dy + off);
       if (act) yv[0] = VT<T>::ld1(y + off);
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float d = dv[e] * (act ? act_grad_from_out(yv[e], act, alpha) : 1.f);
+      const float ag = !act ? 1.f
+                       : (use_mask ? act_grad_from_bit((mbits >> e) & 1u, act, alpha)
+                                   : act_grad_from_out(yv[e], act, alpha));
+      float d = dv[e] * ag;
       dr[e] = d;
       o[e] = d * sc[e];
     }
@@ -347,17 +386,17 @@ template <typename T, int MODE>
 int launch_partial(const T* a, const T* y, const T* x, const float* mean, const float* rstd,
                    const float* row_scale, int G, int64_t R, int C, int act, float alpha,
                    float* sums, float* dst0, float* dst1, float* ws, size_t ws_bytes,
-                   hipStream_t s) {
+                   hipStream_t s, const uint8_t* amask = nullptr) {
   Layout2D l = make_layout(C, VT<T>::V);
   int rb = pick_rblocks(R, l.ry, l.ctiles, G);
   if (ws_bytes < sizeof(float) * (size_t)G * rb * 2 * C) return SE3DS_E_WORKSPACE;
   dim3 grid((unsigned)rb, (unsigned)l.ctiles, (unsigned)G);
   if (l.vec > 1)
     hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE>), grid, dim3(256), 0, s, a, y, x,
-                       mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws);
+                       mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
   else
     hipLaunchKernelGGL((norm_partial_kernel<T, 1, MODE>), grid, dim3(256), 0, s, a, y, x, mean,
-                       rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws);
+                       rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
   hipLaunchKernelGGL(norm_final_reduce_kernel, dim3((unsigned)ceil_div(2 * C, 32), (unsigned)G),
                      dim3(256), 0, s, ws, rb, C, G, sums, dst0, dst1);
   return check_launch("norm_partial");
@@ -403,13 +442,13 @@ int se3ds_norm_finalize(const float* sums, float count, int g, int c, const floa
 
 int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const float* scale,
                      const float* shift, const void* res, const void* post, int act, float alpha,
-                     void* y, void* stream) {
+                     void* y, void* act_mask, void* stream) {
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
 #define LAUNCH_APPLY(T, V)                                                                        \
   hipLaunchKernelGGL((norm_apply_kernel<T, V>), ew_grid(l, r, g), dim3(256), 0, s, (const T*)x,   \
                      scale, shift, (const T*)res, (const T*)post, r, c, l.cx, l.ry, act, alpha,   \
-                     (T*)y)
+                     (T*)y, (uint8_t*)act_mask)
   if (dtype == SE3DS_F32) {
     Layout2D l = make_layout(c, 4);
     if (l.vec > 1) LAUNCH_APPLY(float, 4); else LAUNCH_APPLY(float, 1);
@@ -425,8 +464,8 @@ int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const fl
 
 int se3ds_norm_bwd_stats(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
                          int c, const float* mean, const float* rstd, int act, float alpha,
-                         float* sums, float* dbeta_out, float* dgamma_out, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+                         float* sums, float* dbeta_out, float* dgamma_out, const void* act_mask,
+                         void* workspace, size_t workspace_bytes, void* stream) {
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
   if (dtype == SE3DS_F32)
@@ -436,20 +475,21 @@ int se3ds_norm_bwd_stats(const void* dy, const void* y, const void* x, int dtype
   if (dtype == SE3DS_BF16)
     return launch_partial<uint16_t, 1>((const uint16_t*)dy, (const uint16_t*)y, (const uint16_t*)x,
                                        mean, rstd, nullptr, g, r, c, act, alpha, sums, dbeta_out,
-                                       dgamma_out, (float*)workspace, workspace_bytes, s);
+                                       dgamma_out, (float*)workspace, workspace_bytes, s,
+                                       (const uint8_t*)act_mask);
   return SE3DS_E_BADDTYPE;
 }
 
 int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
                          int c, const float* mean, const float* rstd, const float* gamma,
                          const float* sums, float count, int act, float alpha, void* dx,
-                         void* dres, void* stream) {
+                         void* dres, const void* act_mask, void* stream) {
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
 #define LAUNCH_BWD(T, V)                                                                         \
   hipLaunchKernelGGL((norm_bwd_apply_kernel<T, V>), ew_grid(l, r, g), dim3(256), 0, s,           \
                      (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, sums, count, r,  \
-                     c, l.cx, l.ry, act, alpha, (T*)dx, (T*)dres)
+                     c, l.cx, l.ry, act, alpha, (T*)dx, (T*)dres, (const uint8_t*)act_mask)
   if (dtype == SE3DS_F32) {
     Layout2D l = make_layout(c, 4);
     if (l.vec > 1) LAUNCH_BWD(float, 4); else LAUNCH_BWD(float, 1);
@@ -465,13 +505,13 @@ int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype
 
 int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r, int c,
                      const float* scale, int act, float alpha, void* dx, void* dres,
-                     void* stream) {
+                     const void* act_mask, void* stream) {
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
 #define LAUNCH_AFF(T, V)                                                                      \
   hipLaunchKernelGGL((affine_bwd_kernel<T, V>), ew_grid(l, r, g), dim3(256), 0, s,            \
                      (const T*)dy, (const T*)y, scale, r, c, l.cx, l.ry, act, alpha, (T*)dx,  \
-                     (T*)dres)
+                     (T*)dres, (const uint8_t*)act_mask)
   if (dtype == SE3DS_F32) {
     Layout2D l = make_layout(c, 4);
     if (l.vec > 1) LAUNCH_AFF(float, 4); else LAUNCH_AFF(float, 1);

@@ -719,10 +719,15 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
                                shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _lib.stream()),
          'se3ds_norm_finalize')
   y = ctx.empty(xd.shape)
+  # one "output > 0" bit per element for the backward pass (instead of re-reading y twice)
+  amask = None
+  if (ctx.tape is not None and act != ACT_NONE and post is None and c % 8 == 0 and
+      xd.dtype == torch.bfloat16):
+    amask = torch.empty(xd.numel() // 8, dtype=torch.uint8, device=ctx.device)
   _chk(L.se3ds_norm_apply(xd.data_ptr(), ctx.code, g, r, c, scale.data_ptr(), shift.data_ptr(),
                           _lib.ptr(res.data if res is not None else None),
                           _lib.ptr(post.data if post is not None else None), act, float(alpha),
-                          y.data_ptr(), _lib.stream()), 'se3ds_norm_apply')
+                          y.data_ptr(), _lib.ptr(amask), _lib.stream()), 'se3ds_norm_apply')
   out = Var(y)
   if ctx.tape is not None:
     def bwd():
@@ -744,11 +749,11 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
                                       c, mean.data_ptr(), rstd.data_ptr(), act, float(alpha),
                                       bs.data_ptr(), st.grad_views[layer.name + '/beta'].data_ptr(),
                                       st.grad_views[layer.name + '/gamma'].data_ptr(),
-                                      ws.data_ptr(), ws.numel(), _lib.stream()),
+                                      _lib.ptr(amask), ws.data_ptr(), ws.numel(), _lib.stream()),
                'se3ds_norm_bwd_stats')
         _chk(L.se3ds_affine_bwd(dy.data_ptr(), y.data_ptr(), ctx.code, g, r, c, scale.data_ptr(),
-                                act, float(alpha), dx.data_ptr(), _lib.ptr(dres), _lib.stream()),
-             'se3ds_affine_bwd')
+                                act, float(alpha), dx.data_ptr(), _lib.ptr(dres), _lib.ptr(amask),
+                                _lib.stream()), 'se3ds_affine_bwd')
       else:
         bs = torch.empty((g, 2, c), dtype=torch.float32, device=ctx.device)
         direct = ctx.param_grads and g == 1
@@ -759,7 +764,7 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
             rstd.data_ptr(), act, float(alpha), bs.data_ptr(),
             st.grad_views[layer.name + '/beta'].data_ptr() if direct else None,
             st.grad_views[layer.name + '/gamma'].data_ptr() if direct else None,
-            ws.data_ptr(), ws.numel(), _lib.stream()), 'se3ds_norm_bwd_stats')
+            _lib.ptr(amask), ws.data_ptr(), ws.numel(), _lib.stream()), 'se3ds_norm_bwd_stats')
         if not ctx.param_grads or direct:
           pass
         else:
@@ -771,7 +776,8 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
         _chk(L.se3ds_norm_bwd_apply(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c,
                                     mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                     bs.data_ptr(), count, act, float(alpha), dx.data_ptr(),
-                                    _lib.ptr(dres), _lib.stream()), 'se3ds_norm_bwd_apply')
+                                    _lib.ptr(dres), _lib.ptr(amask), _lib.stream()),
+             'se3ds_norm_bwd_apply')
       accumulate(x, dx)
       if want_res:
         accumulate(res, dres)
