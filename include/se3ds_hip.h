@@ -165,6 +165,20 @@ int se3ds_conv2d_fwd(const void* x, const void* wt, void* y, int dtype, int n, i
                      const float* scale, const float* bias, const float* row_a,
                      const float* row_b, int act, float act_alpha, void* stream);
 
+/* Forward conv that also emits the batch-norm statistics of its (rounded) output, so that
+ * SyncBatchNormalization (models/layers.py BN after conv) needs no separate pass over y:
+ * stats[row][2][cout] = per-row-block (sum, sum of squares) over the stored outputs, with
+ * rows = se3ds_conv2d_fwd_stats_rows(...) (0: this shape has no fused path, use
+ * se3ds_conv2d_fwd + se3ds_norm_stats).  Reduce with se3ds_norm_reduce_rows. */
+int64_t se3ds_conv2d_fwd_stats_rows(int dtype, int n, int cin, int ho, int wo, int cout, int kh,
+                                    int kw, int stride, int has_in_mask, int in_mask_binary);
+int se3ds_conv2d_fwd_stats(const void* x, const void* wt, void* y, int dtype, int n, int h, int w,
+                           int cin, int ho, int wo, int cout, int kh, int kw, int stride,
+                           int pad_t, int pad_l, int wrap_w, const float* in_mask,
+                           int in_mask_binary, const float* scale, const float* bias,
+                           const float* row_a, const float* row_b, int act, float act_alpha,
+                           float* stats, void* stream);
+
 /* dx = epilogue(conv_transpose(dy, W)): the input-gradient of the conv above AND the forward
  * of Keras Conv2DTranspose (models/layers.py:417-423,475-480; image_models.py:440-441), whose
  * kernel (kh,kw,Cout_T,Cin_T) is the HWIO kernel of the associated forward conv.  wn is the
@@ -216,6 +230,10 @@ size_t se3ds_norm_workspace_bytes(int g, int c);
 int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const float* row_scale,
                      float* sums, float* colsum_out, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* sums[2][c] = sum over rows of partial[rows][2][c] (deterministic; workspace of
+ * se3ds_norm_workspace_bytes(ceil(rows/512), c) bytes for rows > 2048). */
+int se3ds_norm_reduce_rows(const float* partial, int64_t rows, int c, float* sums, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* mean = S0/count, var = S1/count - mean^2 (biased); scale = gamma*rsqrt(var+eps),
  * shift = beta - mean*scale; moving stats (c) updated in place unless NULL;
  * use_moving != 0: inference (statistics from moving_mean / moving_var). */

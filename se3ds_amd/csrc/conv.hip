@@ -75,6 +75,9 @@ struct IgemmParams {
   int act; float act_alpha;  // 0 none, 1 relu, 2 leaky relu
   int vec;                // reduction channels % BK == 0 -> vector gather
   int halo_ty, halo_tx;   // igemm_halo_kernel: output tiles per image (rows of 8, columns of 32)
+  // igemm_halo_kernel, forward: per (pixel tile, pixel quarter) column sums of the stored
+  // outputs, stats[row][2][oC] (sum, sum of squares), row = tile * 4 + quarter; or NULL
+  float* stats;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
@@ -188,7 +191,7 @@ template <int NI, int PXC, typename BiasFn>
 __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16_t (&acc)[NI][2],
                                                     const int64_t (&opix)[2], int co_base, int lane,
                                                     unsigned char* scratch, float scale,
-                                                    BiasFn bias4) {
+                                                    BiasFn bias4, float* stats_row = nullptr) {
   constexpr int RB = NI * 64 + 16;   // padded row bytes
   constexpr int LPP = NI * 4;        // lanes per pixel in the write-back
   constexpr int PPI = 64 / LPP;      // pixels per store instruction
@@ -205,6 +208,7 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
     for (int g = 0; g < 4; ++g) bv[i][g] = bias4(i * 32 + g * 8 + half * 4);
   // epilogue form (wave-uniform): 0 plain, 1 + bias, 2 * ratio, 3 partial conv with bias
   const int form = p.row_a ? (p.bias ? 3 : 2) : (p.bias ? 1 : 0);
+  float cs1 = 0.f, cs2 = 0.f;   // column sums of channel co_base + lane (NI == 2 only)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int64_t o = opix[j];
@@ -236,6 +240,7 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
             uint2 pk;
             pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
             pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            if (o < 0) pk = make_uint2(0u, 0u);   // (keeps the column sums clean)
             if (mine)
               *reinterpret_cast<uint2*>(scratch + lp * RB + (i * 32 + g * 8 + half * 4) * 2) = pk;
           }
@@ -245,6 +250,15 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
       else if (form == 2) emit(std::integral_constant<int, 2>());
       else emit(std::integral_constant<int, 3>());
       __builtin_amdgcn_wave_barrier();
+      if (NI == 2 && NPASS == 1 && stats_row != nullptr) {
+        // batch-norm statistics of the stored (rounded) outputs: lane = channel
+#pragma unroll 8
+        for (int px = 0; px < PXC; ++px) {
+          const float v = bf16_to_f32(*reinterpret_cast<const uint16_t*>(scratch + px * RB + lane * 2));
+          cs1 += v;
+          cs2 += v * v;
+        }
+      }
 #pragma unroll
       for (int k = 0; k < PXC / PPI; ++k) {
         const int px = k * PPI + lane / LPP, c16 = lane % LPP;
@@ -255,12 +269,16 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
       __builtin_amdgcn_wave_barrier();
     }
   }
+  if (NI == 2 && stats_row != nullptr) {
+    stats_row[co_base + lane] = cs1;
+    stats_row[p.oC + co_base + lane] = cs2;
+  }
 }
 
 template <int NI>
 __device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&acc)[NI][2],
                                                const int64_t (&opix)[2], int co_base, int lane,
-                                               unsigned char* scratch) {
+                                               unsigned char* scratch, float* stats_row = nullptr) {
   const float scale = p.scale ? *p.scale : 1.0f;
   // vector loads up front (element-wise loads each paid a full vmcnt(0) round trip behind the
   // prefetch DMA)
@@ -268,7 +286,7 @@ __device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&
     return p.bias ? *reinterpret_cast<const float4*>(p.bias + co_base + cl)
                   : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  store_wave_lds_impl<NI, 32>(p, acc, opix, co_base, lane, scratch, scale, bias4);
+  store_wave_lds_impl<NI, 32>(p, acc, opix, co_base, lane, scratch, scale, bias4, stats_row);
 }
 
 // m_base / co_base: first pixel row / output channel of this wave's sub-tile.
@@ -1000,14 +1018,15 @@ igemm_halo_kernel(const IgemmParams p) {
   const int nitems = p.N * p.halo_ty * p.halo_tx * nco;
 
   // ---- per work item (output patch x channel tile) state
-  struct ItemPos { int img, y0, x0, n0; };
-  ItemPos cur = {0, 0, 0, 0};
+  struct ItemPos { int img, y0, x0, n0, tile; };
+  ItemPos cur = {0, 0, 0, 0, 0};
   const T* xptr[XS];    // patch pieces of this wave: piece s*8 + wave, rows 8*piece + lane/8
   int xmk[XS];
   const T* wbase = nullptr;   // weight pieces: rows (j*8 + wave)*8 + lane/8 of the CO-row tile
   auto setup_item = [&](int item, ItemPos& pos, const T* (&xp)[XS], int (&xm)[XS], const T*& wb) {
     pos.n0 = (item % nco) * CO;
     int bt = item / nco;
+    pos.tile = bt;
     const int tx = bt % p.halo_tx; bt /= p.halo_tx;
     const int ty = bt % p.halo_ty;
     pos.img = bt / p.halo_ty;
@@ -1212,6 +1231,8 @@ igemm_halo_kernel(const IgemmParams p) {
   // Every wave is past its last fragment read.  xb1 is the epilogue scratch (the last K steps'
   // idle copies only touch `sink`); xb0 and the first weight stages hold / take the next item's
   // first slab and weight tiles.
+  float* stats_row = (MODE == MODE_FWD && p.stats)
+                         ? p.stats + ((int64_t)(cur.tile * 4 + wn) * 2) * p.oC : nullptr;
   item += gridDim.x;
   const bool have = item < nitems;
   if (have) {
@@ -1222,10 +1243,11 @@ igemm_halo_kernel(const IgemmParams p) {
   // so that the epilogue issues no global load, was measured slower: 1.62 vs 1.44 ms on the
   // 3x3 128->128 @512x1024 layer)
   unsigned char* scratch = xb1 + wave * kEpiScratch<2>;
-  store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane, scratch);
+  store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane, scratch,
+                    stats_row);
   if (NI == 4)
     store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64,
-                      lane, scratch);
+                      lane, scratch, stats_row);
   if (!have) break;
   }
 }
@@ -2065,7 +2087,8 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
                        int h, int wdt, int cin, int ho, int wo, int cout, int kh, int kw,
                        int stride, int pad_t, int pad_l, int wrap_w, const float* src_mask,
                        int mask_binary, const float* scale, const float* bias, const float* row_a,
-                       const float* row_b, int act, float act_alpha, void* stream) {
+                       const float* row_b, int act, float act_alpha, void* stream,
+                       float* stats = nullptr) {
   if (n <= 0 || h <= 0 || wdt <= 0 || cin <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || kh <= 0 ||
       kw <= 0 || stride <= 0 || stride > 2)
     return SE3DS_E_BADSHAPE;
@@ -2089,12 +2112,17 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
     p.w_tap = (int64_t)cin * cout; p.w_n = cout;    // wn [K][Cout]
   }
   p.vec = (p.sC % bk) == 0;
+  p.stats = nullptr;
   hipStream_t s = as_stream(stream);
   const bool glds = (p.sC % (2 * bk)) == 0 && (src_mask == nullptr || mask_binary) &&
                     !g_disable_glds;
+  if (stats != nullptr && !(glds && dtype == SE3DS_BF16 && stride == 1 && kh == 3 && kw == 3 &&
+                            mode == MODE_FWD && halo_tile_channels(p)))
+    return SE3DS_E_UNSUPPORTED;   // callers ask se3ds_conv2d_fwd_stats_rows first
   if (glds && dtype == SE3DS_BF16 && stride == 1 && kh == 3 && kw == 3) {
     const int co = halo_tile_channels(p);
     if (co) {
+      p.stats = mode == MODE_FWD ? stats : nullptr;
       p.halo_ty = ceil_div(p.oH, 8);
       p.halo_tx = ceil_div(p.oW, 32);
       const int64_t items = (int64_t)p.N * p.halo_ty * p.halo_tx * (p.oC / co);
@@ -2156,6 +2184,29 @@ int se3ds_conv2d_fwd(const void* x, const void* wt, void* y, int dtype, int n, i
   return conv_common(MODE_FWD, x, wt, y, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride, pad_t,
                      pad_l, wrap_w, in_mask, in_mask_binary, scale, bias, row_a, row_b, act,
                      act_alpha, stream);
+}
+
+int64_t se3ds_conv2d_fwd_stats_rows(int dtype, int n, int cin, int ho, int wo, int cout, int kh,
+                                    int kw, int stride, int has_in_mask, int in_mask_binary) {
+  if (dtype != SE3DS_BF16 || stride != 1 || kh != 3 || kw != 3 || (cin % 64) != 0 ||
+      (has_in_mask && !in_mask_binary) || g_disable_glds)
+    return 0;
+  if (getenv("SE3DS_FUSED_BN_STATS") && atoi(getenv("SE3DS_FUSED_BN_STATS")) == 0) return 0;
+  IgemmParams p;
+  p.N = n; p.oH = ho; p.oW = wo; p.oC = cout;
+  if (!halo_tile_channels(p)) return 0;
+  return (int64_t)n * ceil_div(ho, 8) * ceil_div(wo, 32) * 4;
+}
+
+int se3ds_conv2d_fwd_stats(const void* x, const void* wt, void* y, int dtype, int n, int h, int w,
+                           int cin, int ho, int wo, int cout, int kh, int kw, int stride,
+                           int pad_t, int pad_l, int wrap_w, const float* in_mask,
+                           int in_mask_binary, const float* scale, const float* bias,
+                           const float* row_a, const float* row_b, int act, float act_alpha,
+                           float* stats, void* stream) {
+  return conv_common(MODE_FWD, x, wt, y, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride, pad_t,
+                     pad_l, wrap_w, in_mask, in_mask_binary, scale, bias, row_a, row_b, act,
+                     act_alpha, stream, stats);
 }
 
 int se3ds_conv2d_dgrad(const void* dy, const void* wn, void* dx, int dtype, int n, int h, int w,

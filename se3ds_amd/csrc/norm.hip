@@ -429,6 +429,35 @@ int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const fl
   return SE3DS_E_BADDTYPE;
 }
 
+int se3ds_norm_reduce_rows(const float* partial, int64_t rows, int c, float* sums, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (rows <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+  const dim3 cols((unsigned)ceil_div(2 * c, 32));
+  if (rows <= 2048) {
+    hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(cols.x, 1), dim3(256), 0, s, partial,
+                       (int)rows, c, 1, sums, (float*)nullptr, (float*)nullptr);
+    return check_launch("norm_reduce_rows");
+  }
+  // two levels: groups of kChunk rows -> workspace[groups][2][c] -> sums
+  constexpr int kChunk = 512;
+  const int64_t full = rows / kChunk, tail = rows - full * kChunk;
+  const int64_t groups = full + (tail ? 1 : 0);
+  if (groups > 1024 * 64 || workspace_bytes < sizeof(float) * (size_t)groups * 2 * c)
+    return SE3DS_E_WORKSPACE;
+  float* mid = (float*)workspace;
+  if (full)
+    hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(cols.x, (unsigned)full), dim3(256), 0, s,
+                       partial, kChunk, c, (int)full, mid, (float*)nullptr, (float*)nullptr);
+  if (tail)
+    hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(cols.x, 1), dim3(256), 0, s,
+                       partial + full * kChunk * 2 * c, (int)tail, c, 1, mid + full * 2 * c,
+                       (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(cols.x, 1), dim3(256), 0, s, mid, (int)groups, c,
+                     1, sums, (float*)nullptr, (float*)nullptr);
+  return check_launch("norm_reduce_rows");
+}
+
 int se3ds_norm_finalize(const float* sums, float count, int g, int c, const float* gamma,
                         const float* beta, float eps, float momentum, float* moving_mean,
                         float* moving_var, int use_moving, float* scale, float* shift, float* mean,

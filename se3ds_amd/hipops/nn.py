@@ -181,12 +181,13 @@ def truncated_normal_init(shape, gen, std=0.05):
 # --------------------------------------------------------------------------------- context
 class Var:
   """Activation handle: NHWC tensor in the compute dtype plus its (lazy) gradient."""
-  __slots__ = ('data', 'grad', 'requires_grad')
+  __slots__ = ('data', 'grad', 'requires_grad', 'col_stats')
 
   def __init__(self, data, requires_grad=True):
     self.data = data
     self.grad = None
     self.requires_grad = requires_grad
+    self.col_stats = None   # conv outputs: partial column sums for a following batch norm
 
   @property
   def shape(self):
@@ -549,14 +550,34 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
   y = ctx.empty((n, ho, wo, layer.cout))
   flops = 2.0 * n * ho * wo * cin * layer.cout * k * k
   tag = f'{k}x{k}s{s} {cin}->{layer.cout} @{ho}x{wo} n{n} {layer.kind}'
+  # Training forward: convs that can also emit the column sums of their output (the statistics
+  # a following SyncBatchNormalization needs) do so; norm_act picks them up from the Var.
+  stats_rows = 0
+  if ctx.training and recording and act == ACT_NONE and not getattr(ctx, 'bn_use_moving', False):
+    stats_rows = int(L.se3ds_conv2d_fwd_stats_rows(ctx.code, n, cin, ho, wo, layer.cout, k, k, s,
+                                                   1 if in_mask is not None else 0,
+                                                   1 if ctx.binary_masks else 0))
+  stats = None
   with _Timed('fwd', flops, tag):
-    _chk(L.se3ds_conv2d_fwd(xd.data_ptr(), wt.data_ptr(), y.data_ptr(), ctx.code, n, h, w, cin,
-                            ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
-                            _lib.ptr(in_mask), 1 if ctx.binary_masks else 0, _lib.ptr(scale),
-                            _lib.ptr(bias), _lib.ptr(ratio),
-                            _lib.ptr(um if (partial and bias is not None) else None), act,
-                            float(alpha), _lib.stream()), 'se3ds_conv2d_fwd')
+    if stats_rows > 0:
+      stats = torch.empty((stats_rows, 2, layer.cout), dtype=torch.float32, device=ctx.device)
+      _chk(L.se3ds_conv2d_fwd_stats(xd.data_ptr(), wt.data_ptr(), y.data_ptr(), ctx.code, n, h, w,
+                                    cin, ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
+                                    _lib.ptr(in_mask), 1 if ctx.binary_masks else 0,
+                                    _lib.ptr(scale), _lib.ptr(bias), _lib.ptr(ratio),
+                                    _lib.ptr(um if (partial and bias is not None) else None), act,
+                                    float(alpha), stats.data_ptr(), _lib.stream()),
+           'se3ds_conv2d_fwd_stats')
+    else:
+      _chk(L.se3ds_conv2d_fwd(xd.data_ptr(), wt.data_ptr(), y.data_ptr(), ctx.code, n, h, w, cin,
+                              ho, wo, layer.cout, k, k, s, pt, pl, 1 if wrap else 0,
+                              _lib.ptr(in_mask), 1 if ctx.binary_masks else 0, _lib.ptr(scale),
+                              _lib.ptr(bias), _lib.ptr(ratio),
+                              _lib.ptr(um if (partial and bias is not None) else None), act,
+                              float(alpha), _lib.stream()), 'se3ds_conv2d_fwd')
   out = Var(y)
+  if stats is not None:
+    out.col_stats = stats   # [rows][2][cout] partial (sum, sum of squares) of y
   if recording:
     def bwd():
       dy = out.grad
@@ -708,7 +729,17 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
                                scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                                rstd.data_ptr(), _lib.stream()), 'se3ds_norm_finalize')
   else:
-    sums = _colsum(ctx, xd.data_ptr(), ctx.code, r, c, groups=g)
+    fused = getattr(x, 'col_stats', None)
+    if fused is not None and not inst and fused.shape[2] == c:
+      # statistics came out of the producing convolution's epilogue
+      sums = torch.empty((1, 2, c), dtype=torch.float32, device=ctx.device)
+      ws = ctx.ws('norm', L.se3ds_norm_workspace_bytes(max(1, (fused.shape[0] + 511) // 512), c))
+      _chk(L.se3ds_norm_reduce_rows(fused.data_ptr(), fused.shape[0], c, sums.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), _lib.stream()),
+           'se3ds_norm_reduce_rows')
+      x.col_stats = None
+    else:
+      sums = _colsum(ctx, xd.data_ptr(), ctx.code, r, c, groups=g)
     if not inst and ctx.world > 1:
       ctx.allreduce_sum(sums)
       count = float(r * ctx.world)

@@ -632,6 +632,32 @@ def test_segment_grad_sync_matches_serial_path(monkeypatch):
   assert res['serial'][5] == pytest.approx(res['overlap'][5], rel=1e-6)
 
 
+@pytest.mark.parametrize('cin,cout,n,h,w', [(64, 128, 2, 16, 32), (128, 256, 3, 11, 70)])
+def test_fused_bn_statistics_match_separate_pass(cin, cout, n, h, w, monkeypatch):
+  """conv -> SyncBatchNormalization: the column sums emitted by the conv epilogue must give the
+  same normalised output / moving statistics as the separate statistics pass."""
+  res = {}
+  for mode in ('0', '1'):
+    monkeypatch.setenv('SE3DS_FUSED_BN_STATS', mode)
+    store = nn.ParamStore()
+    conv = nn.ConvLayer(store, 'c', cin, cout, 3, 1, 'VALID', True, 'plain')
+    bn = nn.NormLayer(store, 'n', cout, 'batch')
+    store.finalize(DEV, torch.Generator().manual_seed(3))
+    ctx = nn.Ctx(DEV, torch.bfloat16, training=True, record=True)
+    x = nn.Var(torch.randn((n, h, w, cin), generator=torch.Generator().manual_seed(4)).to(DEV).bfloat16())
+    y = nn.conv2d(ctx, x, conv, pad=1)
+    assert (y.col_stats is not None) == (mode == '1')
+    z = nn.norm_act(ctx, y, bn, act=2, alpha=0.2)
+    z.grad = torch.ones_like(z.data)
+    ctx.backward()
+    res[mode] = (z.data.float().cpu().numpy(), store['n/moving_mean'].cpu().numpy().copy(),
+                 store['n/moving_variance'].cpu().numpy().copy(), x.grad.float().cpu().numpy())
+  # fp32 statistics agree to summation-order noise; bf16 tensors to a rounding step
+  assert rel_err(res['0'][1], res['1'][1]) < 1e-4 and rel_err(res['0'][2], res['1'][2]) < 1e-4
+  assert rel_err(res['0'][0], res['1'][0]) < tol(torch.bfloat16)
+  assert rel_err(res['0'][3], res['1'][3]) < tol(torch.bfloat16)
+
+
 def test_split_input_dict_and_cluster():
   gan = _make_gan(64, 4, '50', 3)
   gan.d_step_per_g_step = 2
