@@ -1719,6 +1719,10 @@ struct WgradTapsParams {
   float* dw;
   int steps_y, steps_x;      // steps per image: ceil(Ho/2) x ceil(Wo/32)
   int total_steps, steps_per_split;
+  // thin output (Cout <= 8: the 128->3 / 128->1 heads): dy is a zero-padded copy with
+  // dy_cstride = 8 channels per pixel, only the first co_valid channels are real; the waves of
+  // the other three 32-channel blocks skip their MFMAs and dw rows have Cout (= co_valid) floats
+  int dy_cstride, co_valid;
 };
 
 __global__ void __launch_bounds__(512)
@@ -1783,8 +1787,8 @@ wgrad_taps_kernel(const WgradTapsParams p) {
     for (int j = 0; j < 2; ++j) {
       const int oy = sp.y0 + ya[j], ox = sp.x0 + yb[j];
       const T* src = zero + ych[j] * 8;
-      if (oy < p.Ho && ox < p.Wo)
-        src = p.dy + ((int64_t)(sp.img * p.Ho + oy) * p.Wo + ox) * p.Cout + co0 + ych[j] * 8;
+      if (oy < p.Ho && ox < p.Wo && co0 + ych[j] * 8 < p.dy_cstride)
+        src = p.dy + ((int64_t)(sp.img * p.Ho + oy) * p.Wo + ox) * p.dy_cstride + co0 + ych[j] * 8;
       if (real)
         __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(stg + (wave * 2 + j) * 4 * YROW), 16,
                                          0, 0);
@@ -1864,6 +1868,7 @@ wgrad_taps_kernel(const WgradTapsParams p) {
   if (iw == 1) __builtin_amdgcn_s_barrier();   // ping-pong: waves 4-7 run one slot behind
   // `far` receives the tiles of step st+2 (it held step st-1, whose last reads every wave has
   // retired before the barrier that opened this step)
+  const bool work = cw * 32 < p.co_valid;   // wave-uniform: this wave's channel block is real
   auto l_step = [&](unsigned char* cur, unsigned char* far, int st) {
     const bool has_far = st + NST - 1 < nsteps;
 #pragma unroll
@@ -1871,7 +1876,7 @@ wgrad_taps_kernel(const WgradTapsParams p) {
       // ---- read slot: 16 pixels (row a, columns b0 .. b0+15); this lane: pixels lb .. lb+7
       const int a = kq >> 1;
       uint4 yf, xf[9];
-      {
+      if (work) {
         const unsigned char* yp = cur + ylane + (a * 32 + (kq & 1) * 16) * YROW;
         uint2 v0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)yp));
         uint2 v1 = __builtin_bit_cast(
@@ -1879,7 +1884,7 @@ wgrad_taps_kernel(const WgradTapsParams p) {
         yf = make_uint4(v0.x, v0.y, v1.x, v1.y);
       }
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
+      for (int t = 0; work && t < 9; ++t) {
         const int ky = t / 3, kx = t - ky * 3;
         const unsigned char* xp =
             cur + xlane[kx][(a + ky) & 1] + ((a + ky) * PC + kx + (kq & 1) * 16) * XROW;
@@ -1903,7 +1908,7 @@ wgrad_taps_kernel(const WgradTapsParams p) {
       __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA slot
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int t = 0; work && t < 9; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, yf),
                                                          __builtin_bit_cast(bf16x8_t, xf[t]), acc[t],
                                                          0, 0, 0);
@@ -1930,13 +1935,33 @@ wgrad_taps_kernel(const WgradTapsParams p) {
   const int64_t K = (int64_t)9 * p.Cin;
   float* __restrict__ dw = p.dw + (int64_t)split * K * p.Cout;
   const int ci = ci0 + iw * 32 + l32;
+  if (!work) return;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
     float* row = dw + ((int64_t)t * p.Cin + ci) * p.Cout + co0 + cw * 32 + half * 4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      *reinterpret_cast<float4*>(row + g * 8) =
-          make_float4(acc[t][g * 4], acc[t][g * 4 + 1], acc[t][g * 4 + 2], acc[t][g * 4 + 3]);
+    for (int g = 0; g < 4; ++g) {
+      if (p.co_valid >= 128) {
+        *reinterpret_cast<float4*>(row + g * 8) =
+            make_float4(acc[t][g * 4], acc[t][g * 4 + 1], acc[t][g * 4 + 2], acc[t][g * 4 + 3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cw * 32 + g * 8 + half * 4 + e < p.co_valid) row[g * 8 + e] = acc[t][g * 4 + e];
+      }
+    }
+  }
+}
+
+// dy[px][cout] (cout <= 8) -> dst[px][8], zero padded (input of the thin tap-fused wgrad)
+__global__ void __launch_bounds__(256)
+pad_channels8_kernel(const uint16_t* __restrict__ src, int cout, int64_t px,
+                     uint16_t* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < px; i += (int64_t)gridDim.x * 256) {
+    uint16_t v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = c < cout ? src[i * cout + c] : (uint16_t)0;
+    *reinterpret_cast<uint4*>(dst + i * 8) = *reinterpret_cast<const uint4*>(v);
   }
 }
 
@@ -2303,6 +2328,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
       q.steps_y = ceil_div(ho, 2); q.steps_x = ceil_div(wo, 32);
       q.total_steps = tsteps;
       q.steps_per_split = ceil_div(tsteps, tsplits);
+      q.dy_cstride = cout; q.co_valid = cout;
       dim3 tgrid((unsigned)(cin / 64), (unsigned)(cout / 128), (unsigned)tsplits);
       hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(512), 0, s, q);
       const int64_t tnel = (int64_t)9 * cin * cout;
@@ -2344,9 +2370,28 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   return check_launch("conv2d_wgrad");
 }
 
+// thin-Cout layers through the tap-fused kernel (padded dy copy): split count, 0 = not eligible
+static int wgrad_taps_thin_splits(int n, int h, int w, int cin, int cout, int k, int* steps) {
+  if (k != 3 || cout > 8 || (cin % 64) != 0) return 0;
+  if (getenv("SE3DS_WGRAD_TAPS_THIN") && atoi(getenv("SE3DS_WGRAD_TAPS_THIN")) == 0) return 0;
+  const int64_t total = (int64_t)n * ceil_div(h, 2) * ceil_div(w, 32);
+  if (total > (1 << 30)) return 0;
+  *steps = (int)total;
+  const int64_t tiles = cin / 64;
+  int64_t sp = ceil_div((int64_t)256, tiles);   // one round of the 256 CUs
+  if (sp > total / 8) sp = total / 8;
+  if (sp < 1) sp = 1;
+  return (int)sp;
+}
+
 size_t se3ds_conv2d_wgrad_swapped_workspace_bytes(int n, int h, int w, int cin, int cout, int k) {
-  return se3ds_conv2d_wgrad_workspace_bytes(n, h, w, cout, cin, k, k) +
-         sizeof(float) * (size_t)k * k * cin * cout + 64;
+  const size_t a = se3ds_conv2d_wgrad_workspace_bytes(n, h, w, cout, cin, k, k) +
+                   sizeof(float) * (size_t)k * k * cin * cout + 64;
+  int steps = 0;
+  const int sp = wgrad_taps_thin_splits(n, h, w, cin, cout, k, &steps);
+  const size_t b = sp ? (size_t)n * h * w * 16 + 256 + sizeof(float) * (size_t)sp * 9 * cin * cout + 64
+                      : 0;
+  return a > b ? a : b;
 }
 
 int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dtype, int n, int h,
@@ -2354,6 +2399,33 @@ int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dty
                                void* workspace, size_t workspace_bytes, void* stream) {
   if (workspace_bytes < se3ds_conv2d_wgrad_swapped_workspace_bytes(n, h, w, cin, cout, k))
     return SE3DS_E_WORKSPACE;
+  if (dtype == SE3DS_BF16 && !g_disable_glds) {
+    int tsteps = 0;
+    const int tsplits = wgrad_taps_thin_splits(n, h, w, cin, cout, k, &tsteps);
+    if (tsplits > 0) {
+      hipStream_t s = as_stream(stream);
+      const int64_t px = (int64_t)n * h * w;
+      uint16_t* dyp = (uint16_t*)workspace;
+      float* part = (float*)((char*)workspace + ((size_t)px * 16 + 255) / 256 * 256);
+      hipLaunchKernelGGL(pad_channels8_kernel, dim3(grid_for(px, 256)), dim3(256), 0, s,
+                         (const uint16_t*)dy, cout, px, dyp);
+      WgradTapsParams q;
+      q.x = (const uint16_t*)x; q.H = h; q.W = w; q.Cin = cin;
+      q.dy = dyp; q.Ho = h; q.Wo = w; q.Cout = cout;
+      q.N = n; q.pad_t = pad; q.pad_l = pad; q.wrap_w = 0; q.src_mask = nullptr;
+      q.dw = part;
+      q.steps_y = ceil_div(h, 2); q.steps_x = ceil_div(w, 32);
+      q.total_steps = tsteps;
+      q.steps_per_split = ceil_div(tsteps, tsplits);
+      q.dy_cstride = 8; q.co_valid = cout;
+      dim3 tgrid((unsigned)(cin / 64), 1, (unsigned)tsplits);
+      hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(512), 0, s, q);
+      const int64_t tnel = (int64_t)9 * cin * cout;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(tnel, 256)), dim3(256), 0, s,
+                         (const float*)part, tsplits, tnel, accumulate, (const float*)nullptr, dw);
+      return check_launch("conv2d_wgrad(taps, thin)");
+    }
+  }
   // tmp[(ky',kx'),co,ci] = wgrad of the conv with input dy (cout channels), output-grad x
   float* tmp = (float*)workspace;
   const size_t tmp_bytes = (sizeof(float) * (size_t)k * k * cin * cout + 63) / 64 * 64;
