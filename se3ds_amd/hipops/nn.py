@@ -108,18 +108,22 @@ class ParamStore:
   def to_dict(self):
     return {k: v.detach().cpu().numpy().copy() for k, v in self.views.items()}
 
-  def segments(self, prefixes):
-    """{prefix: (t0, t1, e0, e1)}: tensor-index and element ranges of the trainable tensors
-    whose name starts with `prefix + '/'` (modules are registered contiguously)."""
+  def segments(self, groups):
+    """{name: (t0, t1, e0, e1)}: tensor-index and element ranges of the trainable tensors whose
+    names start with one of the group's prefixes + '/' (registered contiguously).  `groups` is
+    {name: (prefix, ...)} or a sequence of prefixes (each its own group)."""
+    if not isinstance(groups, dict):
+      groups = {g: (g,) for g in groups}
     out = {}
-    for pre in prefixes:
-      idx = [i for i, n in enumerate(self.trainable_names) if n.startswith(pre + '/')]
+    for name, prefixes in groups.items():
+      idx = [i for i, n in enumerate(self.trainable_names)
+             if any(n.startswith(pre + '/') for pre in prefixes)]
       if not idx:
         continue
-      assert idx == list(range(idx[0], idx[-1] + 1)), f'{pre} is not contiguous'
+      assert idx == list(range(idx[0], idx[-1] + 1)), f'{name} is not contiguous'
       o0 = self._off_tr[self.trainable_names[idx[0]]][0]
       last = self._off_tr[self.trainable_names[idx[-1]]]
-      out[pre] = (idx[0], idx[-1] + 1, o0, last[0] + last[1])
+      out[name] = (idx[0], idx[-1] + 1, o0, last[0] + last[1])
     return out
 
   def chunk_tables(self, chunk=65536):
@@ -486,7 +490,9 @@ class SpectralGroup:
     if prefix is not None:
       cache = self.__dict__.setdefault('_seg_tables', {})
       if prefix not in cache:
-        rows = [j for j, i in enumerate(self._eff) if self.layers[i].name.startswith(prefix + '/')]
+        pres = prefix if isinstance(prefix, (tuple, list)) else (prefix,)
+        rows = [j for j, i in enumerate(self._eff)
+                if any(self.layers[i].name.startswith(pre + '/') for pre in pres)]
         cache[prefix] = tab[rows].contiguous() if rows else None
       tab = cache[prefix]
       if tab is None:

@@ -99,18 +99,26 @@ class ResNetEncoder:
     self.final_bn = layers.SyncBatchNormalization(store, name + '/final_bn', d * 4)
 
   def __call__(self, ctx: Ctx, x: Var, mask: Optional[torch.Tensor] = None):
+    # gradient-synchronisation segments (see ResNetGenerator.SEGMENTS): a marker fires in the
+    # backward pass when the ops after it have all run, i.e. when the module's gradients are final
+    ctx.mark_segment('encoder_head')
     out, um = self.conv1(ctx, x, mask, pad=self.pad1)
     out = self.bn1(ctx, out, act=ACT_RELU)
     b1 = out
     out = nn.maxpool2x2(ctx, out)
     um = nn.maxpool2x2_mask(ctx, um)
+    ctx.mark_segment('encoder/stack1')
     out, um = self.stack1(ctx, out, um)
     s1 = out
+    ctx.mark_segment('encoder/stack2')
     out, um = self.stack2(ctx, out, um)
     s2 = out
+    ctx.mark_segment('encoder/stack3')
     out, um = self.stack3(ctx, out, um)
     s3 = out
+    ctx.mark_segment('encoder/stack4')
     out, um = self.stack4(ctx, out, um)
+    ctx.mark_segment('encoder_tail')
     out, um = self.final_conv(ctx, out, um, pad=self.final_pad)
     out = self.final_bn(ctx, out, act=ACT_RELU)
     return out, [b1, s1, s2, s3]
@@ -214,7 +222,15 @@ class _Head:
 @gin.configurable
 class ResNetGenerator(_Model):
   """ResNet generator model with partial convs (reference :27-193)."""
-  SEGMENTS = ('encoder', 'decoder', 'depth_decoder', 'rgb_conv', 'depth_conv', 'context')
+  # name -> parameter-name prefixes (contiguous in registration order).  The encoder is split per
+  # stage so that only its first, tiny stages are reduced after the backward pass has ended.
+  SEGMENTS = {
+      'encoder_head': ('encoder/conv1', 'encoder/bn1'),
+      'encoder/stack1': ('encoder/stack1',), 'encoder/stack2': ('encoder/stack2',),
+      'encoder/stack3': ('encoder/stack3',), 'encoder/stack4': ('encoder/stack4',),
+      'encoder_tail': ('encoder/final_conv', 'encoder/final_bn'),
+      'decoder': ('decoder',), 'depth_decoder': ('depth_decoder',), 'rgb_conv': ('rgb_conv',),
+      'depth_conv': ('depth_conv',), 'context': ('context',)}
 
   def __init__(self, image_size: int = 256, gen_dims: int = 96, z_dim: int = 128,
                resnet_version: str = '50', context_layer: str = 'convs',
@@ -262,8 +278,7 @@ class ResNetGenerator(_Model):
     n, h, w, _ = x.shape
     mask = gm.to(torch.float32).reshape(n, h, w).contiguous()
     self.spectral.power_iteration(ctx.training)
-    ctx.mark_segment('encoder')
-    hidden, skip = self.encoder(ctx, x, mask)
+    hidden, skip = self.encoder(ctx, x, mask)   # (marks its own segments)
     taps = getattr(ctx, 'taps', None)
     if taps is not None:
       taps.update(b1=skip[0], s1=skip[1], s2=skip[2], s3=skip[3], enc=hidden)

@@ -258,7 +258,7 @@ class GAN(gan_manager.GANManager):
         if name not in self._g_segments:
           return
         t0, t1, e0, e1 = self._g_segments[name]
-        G.spectral.backward_fixup(prefix=name)
+        G.spectral.backward_fixup(prefix=G.SEGMENTS[name])
         self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM)
         sync.reduce_range(G.store.grad, e0, e1)
       ctx_g.on_segment = segment_done

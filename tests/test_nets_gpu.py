@@ -620,7 +620,7 @@ def test_segment_grad_sync_matches_serial_path(monkeypatch):
     torch.cuda.synchronize()
     if mode == 'overlap':
       segs = gan._g_segments
-      assert set(segs) == {'encoder', 'decoder', 'depth_decoder', 'rgb_conv', 'depth_conv', 'context'}
+      assert set(segs) == set(gan.generator.SEGMENTS)
       assert sorted(v[2] for v in segs.values())[0] == 0
     m = gan._save_metrics_to_dict()
     res[mode] = (gan.generator.store.theta.clone(), gan.discriminator.store.theta.clone(),
