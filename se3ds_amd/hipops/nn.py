@@ -213,6 +213,7 @@ class Ctx:
     # update_mask derived from a binary mask).  Set False for fractional masks: exact, slower.
     self.binary_masks = True
     self.on_segment = None    # callback(name): a top-level module's parameter gradients are final
+    self.batch_limit = None   # backward passes that only concern the first samples of the batch
     self.group = group
     self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) \
         else 1
@@ -585,11 +586,17 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
   if stats is not None:
     out.col_stats = stats   # [rows][2][cout] partial (sum, sum of squares) of y
   if recording:
-    def bwd():
+    def bwd(n=n):
       dy = out.grad
       out.grad = None
       if dy is None:
         return
+      # ctx.batch_limit: this backward pass only concerns the first `limit` samples (their
+      # gradients do not depend on the others: no batch statistics on this path)
+      lim = getattr(ctx, 'batch_limit', None)
+      if lim is not None and lim < n:
+        assert not partial and dy.shape[0] == lim and not ctx.param_grads
+        n = lim
       if act != ACT_NONE:
         _chk(L.se3ds_act_bwd(dy.data_ptr(), y.data_ptr(), ctx.code, dy.numel(), act, float(alpha),
                              dy.data_ptr(), _lib.stream()), 'se3ds_act_bwd')
@@ -632,8 +639,8 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
                                       None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
                  'se3ds_conv2d_wgrad')
       if x.requires_grad:
-        dx = ctx.empty(xd.shape)
-        with _Timed('dgrad', flops, tag):
+        dx = ctx.empty((n,) + tuple(xd.shape[1:]))
+        with _Timed('dgrad', flops * n / xd.shape[0], tag):
           _chk(L.se3ds_conv2d_dgrad(dys.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h,
                                     w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
                                     1 if wrap else 0, _lib.ptr(row_scale), _lib.ptr(scale), None,
@@ -767,7 +774,7 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
                           y.data_ptr(), _lib.ptr(amask), _lib.stream()), 'se3ds_norm_apply')
   out = Var(y)
   if ctx.tape is not None:
-    def bwd():
+    def bwd(g=g):
       dy = out.grad
       out.grad = None
       if dy is None:
@@ -775,10 +782,18 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
       if post is not None:
         # y = act(.) + post: the activation mask must come from (y - post); recompute it
         raise NotImplementedError
+      lim = getattr(ctx, 'batch_limit', None)
+      shape = xd.shape
+      if lim is not None and lim < n:
+        # per-sample statistics only (instance norm): the first `lim` groups are a prefix of
+        # every buffer involved
+        assert inst and dy.shape[0] == lim and not ctx.param_grads
+        g = lim
+        shape = (lim,) + tuple(xd.shape[1:])
       ws = ctx.ws('norm', L.se3ds_norm_workspace_bytes(g, c))
       want_res = res is not None and res.requires_grad
-      dres = ctx.empty(xd.shape) if want_res else None
-      dx = ctx.empty(xd.shape)
+      dres = ctx.empty(shape) if want_res else None
+      dx = ctx.empty(shape)
       if use_moving:
         if ctx.param_grads:
           bs = torch.empty((g, 2, c), dtype=torch.float32, device=ctx.device)
@@ -887,12 +902,16 @@ def avgpool3s2(ctx: Ctx, x: Var) -> Var:
        'se3ds_avgpool3s2_fwd')
   out = Var(y, x.requires_grad)
   if ctx.tape is not None:
-    def bwd():
+    def bwd(n=n):
       dy = out.grad
       out.grad = None
       if dy is None or not x.requires_grad:
         return
-      dx = ctx.empty(xd.shape)
+      lim = getattr(ctx, 'batch_limit', None)
+      if lim is not None and lim < n:
+        assert dy.shape[0] == lim
+        n = lim
+      dx = ctx.empty((n,) + tuple(xd.shape[1:]))
       _chk(L.se3ds_avgpool3s2_bwd(dy.data_ptr(), ctx.code, n, h, w, c, dx.data_ptr(),
                                   _lib.stream()), 'se3ds_avgpool3s2_bwd')
       accumulate(x, dx)

@@ -226,9 +226,14 @@ class GAN(gan_manager.GANManager):
     if sync is not None:
       d_norm = self._sync_discriminator(sync)
     # ---- pass 2: gradient of the generator loss w.r.t. the fake images (gen_tape, :236)
+    # Only the fake half of [fake; real] carries generator loss, and nothing in the
+    # discriminator couples samples (instance norm, no batch statistics): the pass runs on the
+    # first n samples of every saved activation.
     ctx_d.param_grads = False
+    ctx_d.batch_limit = n
     self._set_input_grad(x_all, True)
-    self._backward_tape(ctx_d, tape_d, seeds_g, logits)
+    self._backward_tape(ctx_d, tape_d, [g[:n] for g in seeds_g], logits)
+    ctx_d.batch_limit = None
     gx = x_all.grad
     x_all.grad = None
     del tape_d
