@@ -190,6 +190,13 @@ int se3ds_conv2d_dgrad(const void* dy, const void* wn, void* dx, int dtype, int 
                        int pad_l, int wrap_w, const float* dy_row_scale, const float* scale,
                        const float* bias, const float* row_a, int act, float act_alpha,
                        void* stream);
+/* The same with dx = result + addend (addend: same layout / dtype as dx, may be dx itself): the
+ * gradient of a tensor with two consumers (a ResNet block's input) without an extra pass. */
+int se3ds_conv2d_dgrad_acc(const void* dy, const void* wn, void* dx, int dtype, int n, int h, int w,
+                       int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
+                       int pad_l, int wrap_w, const float* dy_row_scale, const float* scale,
+                       const float* bias, const float* row_a, int act, float act_alpha,
+                       const void* addend, void* stream);
 
 /* dW[kh,kw,cin,cout] (fp32) (+)= (*out_scale) * sum_pixels (x*in_mask)^T (dy*row_scale).
  * The reduction over n*ho*wo is split across workgroups and reduced deterministically. */

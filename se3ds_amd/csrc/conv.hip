@@ -78,6 +78,9 @@ struct IgemmParams {
   // igemm_halo_kernel, forward: per (pixel tile, pixel quarter) column sums of the stored
   // outputs, stats[row][2][oC] (sum, sum of squares), row = tile * 4 + quarter; or NULL
   float* stats;
+  // dx = conv result + addend (same layout and dtype as out; may alias out): the second
+  // contribution to a tensor with two consumers (ResNet block input) without a separate pass
+  const void* addend;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
@@ -158,6 +161,12 @@ __device__ __forceinline__ void store_pixel(const IgemmParams& p, f32x16_t (&acc
         v[e] = t;
       }
       T* o = out + opix * p.oC + co;
+      if (p.addend) {
+        const T* ad = (const T*)p.addend + opix * p.oC + co;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (co + e < p.oC) v[e] = tt::to_f(tt::from_f(v[e])) + tt::to_f(ad[e]);
+      }
       if (co + 3 < p.oC && (p.oC & 3) == 0) {
         if (sizeof(T) == 4) {
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -262,9 +271,23 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
 #pragma unroll
       for (int k = 0; k < PXC / PPI; ++k) {
         const int px = k * PPI + lane / LPP, c16 = lane % LPP;
-        const uint4 v = *reinterpret_cast<const uint4*>(scratch + px * RB + c16 * 16);
+        uint4 v = *reinterpret_cast<const uint4*>(scratch + px * RB + c16 * 16);
         const int64_t po = offs[px];
-        if (po >= 0) *reinterpret_cast<uint4*>(out + po * p.oC + co_base + c16 * 8) = v;
+        if (po >= 0) {
+          if (p.addend) {
+            const uint4 a = *reinterpret_cast<const uint4*>((const uint16_t*)p.addend + po * p.oC +
+                                                            co_base + c16 * 8);
+            uint32_t* vw = reinterpret_cast<uint32_t*>(&v);
+            const uint32_t* aw = reinterpret_cast<const uint32_t*>(&a);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
+              const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+              vw[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+            }
+          }
+          *reinterpret_cast<uint4*>(out + po * p.oC + co_base + c16 * 8) = v;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -2113,7 +2136,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
                        int stride, int pad_t, int pad_l, int wrap_w, const float* src_mask,
                        int mask_binary, const float* scale, const float* bias, const float* row_a,
                        const float* row_b, int act, float act_alpha, void* stream,
-                       float* stats = nullptr) {
+                       float* stats = nullptr, const void* addend = nullptr) {
   if (n <= 0 || h <= 0 || wdt <= 0 || cin <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || kh <= 0 ||
       kw <= 0 || stride <= 0 || stride > 2)
     return SE3DS_E_BADSHAPE;
@@ -2138,6 +2161,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   }
   p.vec = (p.sC % bk) == 0;
   p.stats = nullptr;
+  p.addend = addend;
   hipStream_t s = as_stream(stream);
   const bool glds = (p.sC % (2 * bk)) == 0 && (src_mask == nullptr || mask_binary) &&
                     !g_disable_glds;
@@ -2242,6 +2266,16 @@ int se3ds_conv2d_dgrad(const void* dy, const void* wn, void* dx, int dtype, int 
   return conv_common(MODE_DGRAD, dy, wn, dx, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride,
                      pad_t, pad_l, wrap_w, dy_row_scale, 0, scale, bias, row_a, nullptr, act,
                      act_alpha, stream);
+}
+
+int se3ds_conv2d_dgrad_acc(const void* dy, const void* wn, void* dx, int dtype, int n, int h, int w,
+                           int cin, int ho, int wo, int cout, int kh, int kw, int stride, int pad_t,
+                           int pad_l, int wrap_w, const float* dy_row_scale, const float* scale,
+                           const float* bias, const float* row_a, int act, float act_alpha,
+                           const void* addend, void* stream) {
+  return conv_common(MODE_DGRAD, dy, wn, dx, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride,
+                     pad_t, pad_l, wrap_w, dy_row_scale, 0, scale, bias, row_a, nullptr, act,
+                     act_alpha, stream, nullptr, addend);
 }
 
 static int wgrad_splits(int64_t L, int64_t tiles, int64_t nel) {

@@ -639,14 +639,26 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
                                       None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
                  'se3ds_conv2d_wgrad')
       if x.requires_grad:
-        dx = ctx.empty((n,) + tuple(xd.shape[1:]))
-        with _Timed('dgrad', flops * n / xd.shape[0], tag):
-          _chk(L.se3ds_conv2d_dgrad(dys.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h,
-                                    w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
-                                    1 if wrap else 0, _lib.ptr(row_scale), _lib.ptr(scale), None,
-                                    _lib.ptr(in_mask), ACT_NONE, 0.0, _lib.stream()),
-               'se3ds_conv2d_dgrad')
-        accumulate(x, dx)
+        prev = x.grad
+        shape = (n,) + tuple(xd.shape[1:])
+        if prev is not None and tuple(prev.shape) == shape and prev.dtype == xd.dtype:
+          # second contribution (e.g. a ResNet block's input: residual branch first, then this
+          # conv): the epilogue adds the existing gradient in place instead of a separate pass
+          with _Timed('dgrad', flops * n / xd.shape[0], tag):
+            _chk(L.se3ds_conv2d_dgrad_acc(dys.data_ptr(), wn.data_ptr(), prev.data_ptr(), ctx.code,
+                                          n, h, w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
+                                          1 if wrap else 0, _lib.ptr(row_scale), _lib.ptr(scale),
+                                          None, _lib.ptr(in_mask), ACT_NONE, 0.0, prev.data_ptr(),
+                                          _lib.stream()), 'se3ds_conv2d_dgrad_acc')
+        else:
+          dx = ctx.empty(shape)
+          with _Timed('dgrad', flops * n / xd.shape[0], tag):
+            _chk(L.se3ds_conv2d_dgrad(dys.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h,
+                                      w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
+                                      1 if wrap else 0, _lib.ptr(row_scale), _lib.ptr(scale), None,
+                                      _lib.ptr(in_mask), ACT_NONE, 0.0, _lib.stream()),
+                 'se3ds_conv2d_dgrad')
+          accumulate(x, dx)
     ctx.record(bwd)
   if partial:
     return out, um
