@@ -261,11 +261,14 @@ int se3ds_norm_bwd_stats(const void* dy, const void* y, const void* x, int dtype
                          int c, const float* mean, const float* rstd, int act, float alpha,
                          float* sums, float* dbeta_out, float* dgamma_out, const void* act_mask,
                          void* workspace, size_t workspace_bytes, void* stream);
-/* dx = gamma*rstd*(dpre - S0/count - xhat*S1/count); dres = dpre when non-NULL. */
+/* dx = gamma*rstd*(dpre - S0/count - xhat*S1/count); dres = dpre when non-NULL.
+ * in_act != 0: x is itself the output of activation in_act (alpha in_alpha) whose producer
+ * skips its own derivative pass: dx is additionally multiplied by act'(x). */
 int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
                          int c, const float* mean, const float* rstd, const float* gamma,
                          const float* sums, float count, int act, float alpha, void* dx,
-                         void* dres, const void* act_mask, void* stream);
+                         void* dres, const void* act_mask, int in_act, float in_alpha,
+                         void* stream);
 /* inference-mode backward: dx = dpre*scale; dres = dpre. */
 int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r, int c,
                      const float* scale, int act, float alpha, void* dx, void* dres,

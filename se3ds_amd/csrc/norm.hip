@@ -261,7 +261,8 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
                       const float* __restrict__ mean, const float* __restrict__ rstd,
                       const float* __restrict__ gamma, const float* __restrict__ sums, float count,
                       int64_t R, int C, int cx, int ry, int act, float alpha, T* __restrict__ dx,
-                      T* __restrict__ dres, const uint8_t* __restrict__ amask) {
+                      T* __restrict__ dres, const uint8_t* __restrict__ amask, int in_act,
+                      float in_alpha) {
   const int g = blockIdx.z;
   const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
   const int c0 = (blockIdx.y * cx + tx) * VEC;
@@ -302,6 +303,8 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
       dr[e] = d;
       float xh = (xv[e] - mu[e]) * rs[e];
       o[e] = gr[e] * (d - s0[e] - xh * s1[e]);
+      // x is the output of an activation whose producer left its derivative to us
+      if (in_act) o[e] *= act_grad_from_out(xv[e], in_act, in_alpha);
     }
     if constexpr (VEC > 1) {
       VT<T>::store(dx + off, reinterpret_cast<float(&)[VT<T>::V]>(o));
@@ -512,13 +515,15 @@ int se3ds_norm_bwd_stats(const void* dy, const void* y, const void* x, int dtype
 int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype, int g, int64_t r,
                          int c, const float* mean, const float* rstd, const float* gamma,
                          const float* sums, float count, int act, float alpha, void* dx,
-                         void* dres, const void* act_mask, void* stream) {
+                         void* dres, const void* act_mask, int in_act, float in_alpha,
+                         void* stream) {
   if (g <= 0 || r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
 #define LAUNCH_BWD(T, V)                                                                         \
   hipLaunchKernelGGL((norm_bwd_apply_kernel<T, V>), ew_grid(l, r, g), dim3(256), 0, s,           \
                      (const T*)dy, (const T*)y, (const T*)x, mean, rstd, gamma, sums, count, r,  \
-                     c, l.cx, l.ry, act, alpha, (T*)dx, (T*)dres, (const uint8_t*)act_mask)
+                     c, l.cx, l.ry, act, alpha, (T*)dx, (T*)dres, (const uint8_t*)act_mask,       \
+                     in_act, in_alpha)
   if (dtype == SE3DS_F32) {
     Layout2D l = make_layout(c, 4);
     if (l.vec > 1) LAUNCH_BWD(float, 4); else LAUNCH_BWD(float, 1);

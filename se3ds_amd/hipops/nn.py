@@ -185,13 +185,14 @@ def truncated_normal_init(shape, gen, std=0.05):
 # --------------------------------------------------------------------------------- context
 class Var:
   """Activation handle: NHWC tensor in the compute dtype plus its (lazy) gradient."""
-  __slots__ = ('data', 'grad', 'requires_grad', 'col_stats')
+  __slots__ = ('data', 'grad', 'requires_grad', 'col_stats', 'grad_pre_act')
 
   def __init__(self, data, requires_grad=True):
     self.data = data
     self.grad = None
     self.requires_grad = requires_grad
     self.col_stats = None   # conv outputs: partial column sums for a following batch norm
+    self.grad_pre_act = False   # the consumer already applied this tensor's activation derivative
 
   @property
   def shape(self):
@@ -597,9 +598,10 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
       if lim is not None and lim < n:
         assert not partial and dy.shape[0] == lim and not ctx.param_grads
         n = lim
-      if act != ACT_NONE:
+      if act != ACT_NONE and not out.grad_pre_act:
         _chk(L.se3ds_act_bwd(dy.data_ptr(), y.data_ptr(), ctx.code, dy.numel(), act, float(alpha),
                              dy.data_ptr(), _lib.stream()), 'se3ds_act_bwd')
+      out.grad_pre_act = False
       rows = n * ho * wo
       row_scale = None
       dys = dy
@@ -729,9 +731,12 @@ class NormLayer:
 
 
 def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: Var = None,
-             post: Var = None) -> Var:
+             post: Var = None, in_act=None) -> Var:
   """y = act(norm(x) [+ res]) [+ post].  Batch norm uses cross-replica batch statistics when
-  training (SyncBatchNormalization) and moving statistics otherwise."""
+  training (SyncBatchNormalization) and moving statistics otherwise.  in_act = (act, alpha):
+  x is the output of a conv with that fused activation and this norm is its ONLY consumer; the
+  backward then applies the activation derivative itself (it reads x anyway) and the conv skips
+  its separate derivative pass."""
   xd = x.data
   n, h, w, c = xd.shape
   st = layer.store
@@ -840,8 +845,11 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
         _chk(L.se3ds_norm_bwd_apply(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c,
                                     mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                     bs.data_ptr(), count, act, float(alpha), dx.data_ptr(),
-                                    _lib.ptr(dres), _lib.ptr(amask), _lib.stream()),
-             'se3ds_norm_bwd_apply')
+                                    _lib.ptr(dres), _lib.ptr(amask),
+                                    in_act[0] if in_act else 0, float(in_act[1]) if in_act else 0.0,
+                                    _lib.stream()), 'se3ds_norm_bwd_apply')
+        if in_act:
+          x.grad_pre_act = True
       accumulate(x, dx)
       if want_res:
         accumulate(res, dres)

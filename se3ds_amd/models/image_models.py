@@ -213,7 +213,8 @@ class _Head:
 
   def __call__(self, ctx, x):
     for i in range(3):
-      x = self.bn[i](ctx, x)
+      # bn[i] (i > 0) is the only consumer of conv[i-1]'s LeakyReLU output
+      x = self.bn[i](ctx, x, in_act=(ACT_LRELU, 0.3) if i > 0 else None)
       x = self.conv[i](ctx, x, pad=self.pad, act=ACT_LRELU if i < 2 else ACT_NONE, alpha=0.3)
     return x
 
@@ -285,7 +286,7 @@ class ResNetGenerator(_Model):
     if self.context_layer == 'convs':
       ctx.mark_segment('context')
       for i in range(4):
-        hidden = self.ctx_bn[i](ctx, hidden)
+        hidden = self.ctx_bn[i](ctx, hidden, in_act=(ACT_LRELU, 0.3) if i > 0 else None)
         hidden = self.ctx_conv[i](ctx, hidden, pad=self.ctx_pad,
                                   act=ACT_LRELU if i < 3 else ACT_NONE, alpha=0.3)
     hh, hw = hidden.shape[1], hidden.shape[2]

@@ -99,8 +99,9 @@ class SyncBatchNormalization:
   def __init__(self, store, name, channels):
     self.norm = NormLayer(store, name, channels, 'batch')
 
-  def __call__(self, ctx: Ctx, x: Var, act=ACT_NONE, alpha=0.0, res: Var = None) -> Var:
-    return nn.norm_act(ctx, x, self.norm, act=act, alpha=alpha, res=res)
+  def __call__(self, ctx: Ctx, x: Var, act=ACT_NONE, alpha=0.0, res: Var = None,
+               in_act=None) -> Var:
+    return nn.norm_act(ctx, x, self.norm, act=act, alpha=alpha, res=res, in_act=in_act)
 
 
 class InstanceNormalization:

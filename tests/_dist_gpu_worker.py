@@ -16,6 +16,8 @@ from tests.test_nets_gpu import synth_batch  # noqa: E402
 
 
 def main():
+  import signal
+  signal.alarm(200)   # never outlive the test: a failed peer would leave this rank in a collective
   dist.init_process_group('gloo')
   rank, world = dist.get_rank(), dist.get_world_size()
   dev = 'cuda:0'

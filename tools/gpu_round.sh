@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 ulimit -c 0
 mkdir -p gpurun_out
 SECONDS=0
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$? elapsed $SECONDS s"; tail -5 gpurun_out/pytest_gpu.log
 SECONDS=0
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
