@@ -60,12 +60,28 @@ class SE3DSModel(object):
         resnet_version=config.resnet_version, gen_dims=config.gen_dims,
         use_blurred_mask=config.use_blurred_mask, device=self.device, dtype=dtype)
     if config.ckpt_path is not None:
-      # TF object-graph checkpoints cannot be read here (no TensorFlow): the state-dict converter
-      # is the first "next" row of SURVEY.md section 8f.
-      raise NotImplementedError(
-          'loading tf.train.Checkpoint files is not supported yet; use config.ckpt_path = None '
-          'and SE3DSModel.model.store.load_dict(...)')
-    print('Initializing SE3DS model from scratch.')
+      # reference :100-104 restores tf.train.Checkpoint(ema_generator=model).  TensorFlow bundles
+      # cannot be read here; the same variables are accepted as an .npz with keys
+      # 'ema_generator/<variable path>' (GANManager.save_checkpoint, or the TF-side exporter of
+      # INTEGRATION.md section 5).
+      if not str(config.ckpt_path).endswith('.npz'):
+        raise NotImplementedError(
+            'tf.train.Checkpoint bundles cannot be read without TensorFlow: export the '
+            'ema_generator variables to .npz (INTEGRATION.md section 5)')
+      import numpy as _np
+      with _np.load(config.ckpt_path) as f:
+        for prefix in ('ema_generator/', 'generator/'):
+          sub = {k[len(prefix):]: f[k] for k in f.files if k.startswith(prefix)}
+          if sub:
+            break
+      missing = sorted(set(self.model.store.views) - set(sub))
+      if not sub or missing:
+        raise KeyError(f'{config.ckpt_path}: generator variables missing, e.g. {missing[:5]}')
+      self.model.store.load_dict({k: v for k, v in sub.items() if k in self.model.store.views})
+      print(f'Restored SE3DS generator from {config.ckpt_path}.')
+      self._restored = True
+    if not getattr(self, '_restored', False):
+      print('Initializing SE3DS model from scratch.')
     self.prev_rgb_frame = None
     self.batch_size = config.batch_size
     self.height = config.image_height

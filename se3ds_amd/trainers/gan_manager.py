@@ -1,6 +1,7 @@
 """GAN training manager -- MI355X implementation of the hot-path half of the reference's
 trainers/gan_manager.py: model / optimizer construction (:169-183), the cluster step
-(:351-385) and the EMA hooks (:642-655).  Dataset pipelines, checkpoint files, TensorBoard
+(:351-385), the EMA hooks (:642-655) and checkpoint save / restore as one .npz.  Dataset
+pipelines, TensorFlow checkpoint bundles, TensorBoard
 logging and the FID evaluation loop of the reference are out of scope;
 `train()` runs the same host loop on a synthetic (or user supplied) batch iterator."""
 import abc
@@ -277,6 +278,72 @@ class GANManager(abc.ABC):
         raise ValueError(f'NaN losses recorded for {key}.')
       output_dict[key] = r
     return output_dict
+
+  # -------------------------------------------------------------------------- checkpoint
+  # The reference keeps tf.train.Checkpoint(generator, discriminator, ema_generator, g_optimizer,
+  # d_optimizer) (:333-349).  TensorFlow's bundle format cannot be read or written here; the same
+  # state goes to one .npz whose keys are '<object>/<variable path>' with the variable paths of the
+  # ParamStore, which mirror the reference's attribute paths (INTEGRATION.md section 5 has the
+  # TF-side exporter that produces a compatible file from a real checkpoint).
+  def state_dict(self):
+    """Flat {key: numpy array} of everything a resumed run needs."""
+    out = {'global_step': np.asarray(self.global_step, np.int64)}
+    for prefix, model in (('generator', self.generator), ('discriminator', self.discriminator),
+                          ('ema_generator', self.ema_generator)):
+      for k, v in model.store.to_dict().items():
+        out[f'{prefix}/{k}'] = v
+    for prefix, opt in (('g_optimizer', self.g_optimizer), ('d_optimizer', self.d_optimizer)):
+      out[f'{prefix}/iter'] = np.asarray(opt.iterations, np.int64)
+      st = opt.model.store
+      m, v = opt.m.detach().cpu().numpy(), opt.v.detach().cpu().numpy()
+      for name in st.trainable_names:
+        o, n, shape = st._off_tr[name]
+        out[f'{prefix}/{name}/m'] = m[o:o + n].reshape(shape).copy()
+        out[f'{prefix}/{name}/v'] = v[o:o + n].reshape(shape).copy()
+    return out
+
+  def load_state_dict(self, d, strict=True):
+    if not hasattr(self, 'generator'):
+      self._create_obj()
+    seen = set()
+    for prefix, model in (('generator', self.generator), ('discriminator', self.discriminator),
+                          ('ema_generator', self.ema_generator)):
+      sub = {k[len(prefix) + 1:]: d[k] for k in d if k.startswith(prefix + '/')}
+      known = {k: v for k, v in sub.items() if k in model.store.views}
+      if strict and set(known) != set(model.store.views):
+        missing = sorted(set(model.store.views) - set(known))[:5]
+        raise KeyError(f'checkpoint lacks {prefix} variables, e.g. {missing}')
+      model.store.load_dict(known)
+      seen.update(f'{prefix}/{k}' for k in known)
+    for prefix, opt in (('g_optimizer', self.g_optimizer), ('d_optimizer', self.d_optimizer)):
+      if f'{prefix}/iter' not in d:
+        if strict:
+          raise KeyError(f'checkpoint lacks {prefix}/iter')
+        continue
+      opt.iterations = int(d[f'{prefix}/iter'])
+      st = opt.model.store
+      for name in st.trainable_names:
+        o, n, shape = st._off_tr[name]
+        for slot, arena in (('m', opt.m), ('v', opt.v)):
+          key = f'{prefix}/{name}/{slot}'
+          if key in d:
+            arena[o:o + n].copy_(torch.as_tensor(np.asarray(d[key]), dtype=torch.float32)
+                                 .reshape(-1).to(arena.device))
+            seen.add(key)
+          elif strict:
+            raise KeyError(f'checkpoint lacks {key}')
+    if 'global_step' in d:
+      self.global_step = int(d['global_step'])
+    return sorted(set(d) - seen - {'global_step', 'g_optimizer/iter', 'd_optimizer/iter'})
+
+  def save_checkpoint(self, path):
+    """One uncompressed .npz (reference: checkpoint_manager.save, :425-428)."""
+    np.savez(path, **self.state_dict())
+
+  def restore_checkpoint(self, path, strict=True):
+    """Returns the keys of the file that matched nothing (reference: checkpoint.restore)."""
+    with np.load(path) as f:
+      return self.load_state_dict({k: f[k] for k in f.files}, strict=strict)
 
   # ---------------------------------------------------------------------------------- EMA
   def update_ema_model(self):
