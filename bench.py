@@ -34,11 +34,19 @@ def _dist_setup(ngpus):
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
   local = int(os.environ.get('LOCAL_RANK', '0'))
+  # test hook: SE3DS_BENCH_BACKEND=gloo runs several ranks on ONE GPU (RCCL refuses that), which
+  # exercises this file's multi-rank plumbing on a 1-GPU box
+  backend = os.environ.get('SE3DS_BENCH_BACKEND', 'nccl')
+  if backend != 'nccl':
+    local = 0
   torch.cuda.set_device(local)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', rank=rank, world_size=world,
-                            device_id=torch.device('cuda', local))
+    if backend == 'nccl':
+      dist.init_process_group('nccl', rank=rank, world_size=world,
+                              device_id=torch.device('cuda', local))
+    else:
+      dist.init_process_group(backend, rank=rank, world_size=world)
   return rank, world, local
 
 
