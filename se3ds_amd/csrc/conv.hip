@@ -1755,7 +1755,8 @@ wgrad_taps_kernel(const WgradTapsParams p) {
   constexpr int YT = 64 * YROW;              // 16 KiB
   constexpr int XR = 4 * PC;                 // 136 halo rows
   constexpr int XPIECES = (XR + 7) / 8;      // 17
-  constexpr int XT = XPIECES * 8 * XROW;     // 17 KiB
+  constexpr int XT = XPIECES * 8 * XROW + 1024;   // 17 KiB + slack: the 12-pixel window of the last
+                                                  // halo row overshoots by two rows (never used)
   // NST stages: the tiles of step st + NST - 1 are fetched during step st.  (Three stages
   // measured slower than two on every shape: 0.43 vs 0.36 ms on 3x3 1024->1024 @32x64.)
   constexpr int NST = 2;
@@ -1898,23 +1899,26 @@ wgrad_taps_kernel(const WgradTapsParams p) {
     for (int kq = 0; kq < 4; ++kq) {
       // ---- read slot: 16 pixels (row a, columns b0 .. b0+15); this lane: pixels lb .. lb+7
       const int a = kq >> 1;
-      uint4 yf, xf[9];
+      // x: per tap row ky ONE window of 12 pixels (three transposing reads); the fragments of
+      // kx = 0, 1, 2 are pixels [0,8), [1,9), [2,10) of it (kx = 1 by four v_alignbit) -- 11 LDS
+      // reads per 9 MFMAs instead of 20.
+      uint4 yf;
+      uint2 xr[3][3];
       if (work) {
         const unsigned char* yp = cur + ylane + (a * 32 + (kq & 1) * 16) * YROW;
         uint2 v0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)yp));
         uint2 v1 = __builtin_bit_cast(
             uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(yp + 4 * YROW)));
         yf = make_uint4(v0.x, v0.y, v1.x, v1.y);
-      }
 #pragma unroll
-      for (int t = 0; work && t < 9; ++t) {
-        const int ky = t / 3, kx = t - ky * 3;
-        const unsigned char* xp =
-            cur + xlane[kx][(a + ky) & 1] + ((a + ky) * PC + kx + (kq & 1) * 16) * XROW;
-        uint2 v0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)xp));
-        uint2 v1 = __builtin_bit_cast(
-            uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(xp + 4 * XROW)));
-        xf[t] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned char* xp =
+              cur + xlane[0][(a + ky) & 1] + ((a + ky) * PC + (kq & 1) * 16) * XROW;
+#pragma unroll
+          for (int w = 0; w < 3; ++w)
+            xr[ky][w] = __builtin_bit_cast(
+                uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(xp + w * 4 * XROW)));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (kq == 0) issue_y(fp, far, has_far);
@@ -1930,11 +1934,24 @@ wgrad_taps_kernel(const WgradTapsParams p) {
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA slot
+      if (work) {
 #pragma unroll
-      for (int t = 0; work && t < 9; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, yf),
-                                                         __builtin_bit_cast(bf16x8_t, xf[t]), acc[t],
-                                                         0, 0, 0);
+        for (int ky = 0; ky < 3; ++ky) {
+          const uint2 v0 = xr[ky][0], v1 = xr[ky][1], v2 = xr[ky][2];
+          const uint4 f0 = make_uint4(v0.x, v0.y, v1.x, v1.y);
+          const uint4 f1 = make_uint4(__builtin_amdgcn_alignbit(v0.y, v0.x, 16),
+                                      __builtin_amdgcn_alignbit(v1.x, v0.y, 16),
+                                      __builtin_amdgcn_alignbit(v1.y, v1.x, 16),
+                                      __builtin_amdgcn_alignbit(v2.x, v1.y, 16));
+          const uint4 f2 = make_uint4(v0.y, v1.x, v1.y, v2.x);
+          acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8_t, yf), __builtin_bit_cast(bf16x8_t, f0), acc[ky * 3 + 0], 0, 0, 0);
+          acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8_t, yf), __builtin_bit_cast(bf16x8_t, f1), acc[ky * 3 + 1], 0, 0, 0);
+          acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8_t, yf), __builtin_bit_cast(bf16x8_t, f2), acc[ky * 3 + 2], 0, 0, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
