@@ -171,8 +171,8 @@ def bench_gan_step(args, rank, world, dev):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=5)
-  ap.add_argument('--warmup', type=int, default=2)
+  ap.add_argument('--steps', type=int, default=10)
+  ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--workload', default=None, choices=['gan_step', 'warp'])
   ap.add_argument('--warp-height', type=int, default=1024)
   ap.add_argument('--batch', type=int, default=0, help='per-GPU batch for gan_step (0 = auto)')

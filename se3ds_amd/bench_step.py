@@ -66,6 +66,11 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
     gan.global_step += gan.num_batched_steps
   for _ in range(args.warmup):
     step()
+  # a full (generation-2) garbage collection of the Python heap costs ~40 ms of host time about
+  # every fifth step (tools/step_times.py); run it now so that a short timed region measures the
+  # steady state rather than the position of that pause
+  import gc
+  gc.collect()
   barrier(world)
   t0 = time.perf_counter()
   for _ in range(args.steps):
