@@ -77,6 +77,9 @@ BIG_TILE_CASES = [
     ('plain', 512, 256, 3, 1, 'VALID', 1, False, True, False, 3, 11, 23),      # several taps x K steps
     ('spectral', 192, 128, 3, 1, 'VALID', 1, False, True, False, 1, 20, 70),   # 3 slabs, ragged tiles
     ('plain', 64, 128, 3, 1, 'SAME', 0, False, False, False, 2, 8, 32),        # one slab, SAME pad
+    # more than 256 work items: the persistent halo kernel takes several items per workgroup
+    ('plain', 64, 128, 3, 1, 'VALID', 1, False, True, False, 3, 128, 256),
+    ('spectral', 128, 256, 3, 1, 'VALID', 1, False, True, False, 3, 128, 256),
 ]
 
 
