@@ -80,6 +80,7 @@ BIG_TILE_CASES = [
     # more than 256 work items: the persistent halo kernel takes several items per workgroup
     ('plain', 64, 128, 3, 1, 'VALID', 1, False, True, False, 3, 128, 256),
     ('spectral', 128, 256, 3, 1, 'VALID', 1, False, True, False, 3, 128, 256),
+    ('plain', 128, 128, 3, 1, 'VALID', 1, False, True, False, 3, 128, 256),    # two slabs per item
 ]
 
 
