@@ -154,6 +154,99 @@ SE3DS_HD int32_t se3ds_splat_index(float px, float py, float pz, int width, int 
   return v * width + u;
 }
 
+/* ---------------------------------------------------------------------------------------
+ * Fast fp32 screen for the pixel index (device hot path; the host twin exists so that the
+ * CPU tests can measure its error bound).  The binary64 transcendentals above cost several
+ * hundred instructions per point.  The splat only needs them for trunc(fx), trunc(fy), so the
+ * kernels first evaluate the same chain with the fp32 atan2 below (same table step, Taylor to
+ * t^7, error a few fp32 ulps) and accept the index when fx and fy are farther than a margin
+ * from every integer -- then no integer lies between the fast and the exact value and
+ * trunc / range tests agree.  Everything else takes the exact path.  The margin
+ * SE3DS_FAST_MARGIN * size is >= 16x the largest deviation tests/test_oracle_warp.py measures.
+ * z (= rad) does not depend on the transcendentals and is the same op in both paths. */
+#define SE3DS_FAST_MARGIN 4.0e-6f
+
+SE3DS_HD float se3ds_atan_tab_f32(int j) {
+  switch (j) {
+    case 0: return 0.0f;
+    case 1: return 0.12435499454676144f;
+    case 2: return 0.24497866312686414f;
+    case 3: return 0.35877067027057225f;
+    case 4: return 0.46364760900080609f;
+    case 5: return 0.55859931534356244f;
+    case 6: return 0.64350110879328437f;
+    case 7: return 0.71882999962162453f;
+    default: return 0.78539816339744828f;
+  }
+}
+
+/* fp32 atan2 for finite inputs, no signed-zero care (callers reject the degenerate cases). */
+SE3DS_HD float se3ds_atan2_fast(float y, float x) {
+  float ay = y < 0.0f ? -y : y;
+  float ax = x < 0.0f ? -x : x;
+  int swap = ay > ax;
+  float a = swap ? ax : ay;
+  float b = swap ? ay : ax;
+  float q = a / b; /* b == 0 -> NaN -> the caller's margin test fails */
+  int j = (int)(q * 8.0f + 0.5f);
+  j = j > 8 ? 8 : (j < 0 ? 0 : j);
+  float c = (float)j * 0.125f;
+  float t = __builtin_fmaf(-c, b, a) / __builtin_fmaf(c, a, b);
+  float s = t * t;
+  float p = -1.0f / 7.0f;
+  p = __builtin_fmaf(p, s, 1.0f / 5.0f);
+  p = __builtin_fmaf(p, s, -1.0f / 3.0f);
+  float r = se3ds_atan_tab_f32(j) + __builtin_fmaf(t * s, p, t);
+  if (swap) r = 1.57079632679489661923f - r;
+  if (x < 0.0f) r = 3.14159265358979323846f - r;
+  return y < 0.0f ? -r : r;
+}
+
+/* (fx, fy) of utils/point_cloud_utils.py:129-138 from the projected coordinates. */
+SE3DS_HD void se3ds_splat_fxy(float px, float py, float pz, int width, int height, float* fx,
+                              float* fy) {
+  float vx = se3ds_div_no_nan(px, pz);
+  float vy = se3ds_div_no_nan(py, pz);
+  *fx = (vx + 1.0f) / 2.0f * (float)width;
+  *fy = (vy + 1.0f) / 2.0f * (float)height;
+}
+
+/* The fast chain: (fx, fy) and rad = pz. */
+SE3DS_HD void se3ds_equirect_fxy_fast(float x, float y, float z, int width, int height, float* fx,
+                                      float* fy, float* pz) {
+  float rad = __builtin_sqrtf((x * x + y * y) + z * z);
+  *pz = rad;
+  float heading = se3ds_atan2_fast(y, x);
+  heading = SE3DS_F32_ONE_HALF_PI - heading;
+  heading = heading + SE3DS_F32_TWO_PI * (heading <= 0.0f ? 1.0f : 0.0f);
+  heading = heading - SE3DS_F32_TWO_PI * (heading > SE3DS_F32_TWO_PI ? 1.0f : 0.0f);
+  float w = z / rad;
+  float elevation = se3ds_atan2_fast(__builtin_sqrtf((1.0f - w) * (1.0f + w)), w);
+  float px = rad * ((heading / SE3DS_F32_TWO_PI) * 2.0f - 1.0f);
+  float py = rad * ((elevation / SE3DS_F32_PI) * 2.0f - 1.0f);
+  se3ds_splat_fxy(px, py, rad, width, height, fx, fy);
+}
+
+/* Fast screen: returns 1 and the index (or -1) when the fast evaluation decides it, 0 when the
+ * point needs the exact path.  *pz is rad in either case. */
+SE3DS_HD int se3ds_equirect_index_fast(float x, float y, float z, int width, int height,
+                                       int feat_valid, int32_t* idx, float* pz) {
+  float fx, fy;
+  se3ds_equirect_fxy_fast(x, y, z, width, height, &fx, &fy, pz);
+  float rad = *pz;
+  float dx = fx - __builtin_rintf(fx), dy = fy - __builtin_rintf(fy);
+  dx = dx < 0.0f ? -dx : dx;
+  dy = dy < 0.0f ? -dy : dy;
+  /* NaN / inf anywhere fails these comparisons; rad must be a positive normal number */
+  int decided = (dx > SE3DS_FAST_MARGIN * (float)width) &&
+                (dy > SE3DS_FAST_MARGIN * (float)height) && (rad > 1.0e-30f) && (rad < 1.0e30f);
+  if (!decided) return 0;
+  int ok = (fx > -1.0f) && (fx < (float)width) && (fy > -1.0f) && (fy < (float)height) &&
+           feat_valid;
+  *idx = ok ? (int32_t)fy * width + (int32_t)fx : -1;
+  return 1;
+}
+
 /* Order-preserving map float -> uint32 (total order of finite floats, -0 < +0). */
 SE3DS_HD uint32_t se3ds_f32_to_ordered(float f) {
   union { float f; uint32_t u; } c;

@@ -66,6 +66,15 @@ def equirect_project_coords(xyz1, offset=None):
   return out
 
 
+def fast_screen_stats(xyz, height, width):
+  """(max |dfx|/W, max |dfy|/H, decided, wrong) of the fast index screen on xyz (3,M)."""
+  xyz = _f32(xyz)
+  out = np.zeros(4, np.float64)
+  lib().oracle_fast_screen_stats(_p(xyz), ctypes.c_int64(xyz.shape[1]), ctypes.c_int(width),
+                                 ctypes.c_int(height), out.ctypes.data_as(ctypes.c_void_p))
+  return out
+
+
 def project_to_feat(coords, feats, height, width, depth_scale, input_void_class,
                     output_void_class=0, return_flat=False):
   coords = _f32(coords)

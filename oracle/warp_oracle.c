@@ -149,3 +149,36 @@ void oracle_unproject_equirect(const float* feats, const float* depth, const flo
       }
   }
 }
+
+/* Error statistics of the fast index screen (se3ds_geom_math.h) against the exact chain, for
+ * xyz (3,M) already relative to the camera.  out[0] = max |fx_fast - fx| / W, out[1] = max
+ * |fy_fast - fy| / H (points where both are finite), out[2] = points the screen decides,
+ * out[3] = decided points whose index differs from the exact one (must be 0). */
+void oracle_fast_screen_stats(const float* xyz, int64_t m, int width, int height, double* out) {
+  double ex = 0.0, ey = 0.0;
+  int64_t decided = 0, wrong = 0;
+  for (int64_t i = 0; i < m; ++i) {
+    float x = xyz[i], y = xyz[m + i], z = xyz[2 * m + i];
+    float px, py, pz, fx, fy, gx, gy, gz;
+    se3ds_equirect_project(x, y, z, &px, &py, &pz);
+    se3ds_splat_fxy(px, py, pz, width, height, &fx, &fy);
+    se3ds_equirect_fxy_fast(x, y, z, width, height, &gx, &gy, &gz);
+    if (fx == fx && gx == gx && fy == fy && gy == gy && pz > 0.0f) {
+      double dx = (double)gx - (double)fx, dy = (double)gy - (double)fy;
+      dx = dx < 0 ? -dx : dx;
+      dy = dy < 0 ? -dy : dy;
+      if (dx / width > ex) ex = dx / width;
+      if (dy / height > ey) ey = dy / height;
+    }
+    int32_t idx = 0;
+    float rz;
+    if (se3ds_equirect_index_fast(x, y, z, width, height, 1, &idx, &rz)) {
+      ++decided;
+      if (idx != se3ds_splat_index(px, py, pz, width, height, 1) || !(rz == pz)) ++wrong;
+    }
+  }
+  out[0] = ex;
+  out[1] = ey;
+  out[2] = (double)decided;
+  out[3] = (double)wrong;
+}

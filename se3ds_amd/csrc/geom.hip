@@ -369,63 +369,103 @@ splat_debug_copy_kernel(SplatWs ws, int64_t total, int32_t* idx_out, float* z_ou
 // ------------------------------------------------------------------ binned splat (owner computes)
 // The scatter version above pays 4 agent-scope atomics per point on memory that eight
 // non-coherent L2s share (executed memory-side, ~28 G/s: 350 us at 4 M points).  Here the points
-// are first binned by TARGET tile (16 x 128 pixels): per-block LDS histograms -> one global add
-// per (block, tile) -> scan -> scatter of (pixel-in-tile, z, features) records; then one
+// are first binned by TARGET tile (16 x 128 pixels): one LDS histogram per chunk of points ->
+// column scan over the chunks -> scatter of (pixel-in-tile, z, features) records; then one
 // workgroup per tile resolves z-min and the per-channel max in LDS and writes depth, features
 // and mask directly.  min / max do not depend on the record order, so the result is bit-identical
 // to the scatter version.  Used for <= 7 channels and <= 4096 tiles per image.
 constexpr int kTileY = 16, kTileX = 128, kTilePx = kTileY * kTileX;
 constexpr int kMaxTiles = 4096;      // per image (LDS histogram)
 constexpr int kMaxBinChannels = 7;
+// The points of one image are cut into contiguous CHUNKS (one workgroup each, the same cut in the
+// count and the scatter pass).  Each chunk owns a histogram row, so record positions come from a
+// column scan of those rows: no global atomics anywhere (2 M cursor atomics cost ~70 us before).
+constexpr int kChunkThreads = 512;
+constexpr int kChunkPoints = 8192;   // minimum points per chunk (16 per thread)
+constexpr int kMaxChunks = 1024;     // per image
+constexpr int kScanWaves = 16;
+constexpr int kExactQueue = 2048;   // per chunk, points waiting for the binary64 path
+
+struct ChunkGeom {
+  int chunks;     // per image
+  int64_t per;    // points per chunk (multiple of kChunkThreads)
+};
+__host__ __device__ inline ChunkGeom chunk_geom(int64_t m, int n) {
+  int64_t cap = kMaxSinkBlocks / (n > 0 ? n : 1);
+  cap = cap < 1 ? 1 : (cap > kMaxChunks ? kMaxChunks : cap);
+  int64_t chunks = (m + kChunkPoints - 1) / kChunkPoints;
+  chunks = chunks < 1 ? 1 : (chunks > cap ? cap : chunks);
+  int64_t per = (m + chunks - 1) / chunks;
+  per = (per + kChunkThreads - 1) / kChunkThreads * kChunkThreads;
+  if (per < kChunkThreads) per = kChunkThreads;
+  chunks = (m + per - 1) / per;
+  ChunkGeom g;
+  g.chunks = (int)(chunks < 1 ? 1 : chunks);
+  g.per = per;
+  return g;
+}
 
 struct BinWs {
   uint32_t* tile_count;   // [nb]
   uint32_t* tile_off;     // [nb + 1]
-  uint32_t* cursor;       // [nb]
+  uint32_t* hist;         // [n][chunks][ntiles]: counts, then exclusive prefix over the chunks
   uint32_t* fpart2;       // [nb][C] sink partials of the occluded points, per tile
-  int32_t* rec_idx;       // [N*M] pixel inside the tile
-  float* rec_z;           // [N*M]
-  float* rec_feat;        // [N*M][C]
+  uint32_t* rec;          // [N*M][2 + C]: pixel inside the tile, z bits, feature bits
 };
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) / 16 * 16; }
 __host__ __device__ inline size_t bin_ws_bytes(int n, int64_t m, int height, int width, int channels) {
-  const size_t nb = (size_t)n * ceil_div(height, kTileY) * ceil_div(width, kTileX);
+  const size_t ntiles = (size_t)ceil_div(height, kTileY) * ceil_div(width, kTileX);
+  const size_t nb = (size_t)n * ntiles;
   const size_t pts = (size_t)n * (size_t)(m > 0 ? m : 0);
-  return align16(4 * nb) + align16(4 * (nb + 1)) + align16(4 * nb) + align16(4 * nb * channels) +
-         align16(4 * pts) + align16(4 * pts) + align16(4 * pts * channels);
+  const size_t chunks = (size_t)chunk_geom(m, n).chunks;
+  return align16(4 * nb) + align16(4 * (nb + 1)) + align16(4 * nb * chunks) +
+         align16(4 * nb * channels) + align16(4 * pts * (2 + channels));
 }
 __host__ __device__ inline BinWs carve_bin_ws(void* base, int n, int64_t m, int height, int width,
                                              int channels) {
-  const size_t nb = (size_t)n * ceil_div(height, kTileY) * ceil_div(width, kTileX);
-  const size_t pts = (size_t)n * (size_t)(m > 0 ? m : 0);
+  const size_t ntiles = (size_t)ceil_div(height, kTileY) * ceil_div(width, kTileX);
+  const size_t nb = (size_t)n * ntiles;
+  const size_t chunks = (size_t)chunk_geom(m, n).chunks;
   char* p = (char*)base;
   BinWs w;
   w.tile_count = (uint32_t*)p; p += align16(4 * nb);
   w.tile_off = (uint32_t*)p; p += align16(4 * (nb + 1));
-  w.cursor = (uint32_t*)p; p += align16(4 * nb);
+  w.hist = (uint32_t*)p; p += align16(4 * nb * chunks);
   w.fpart2 = (uint32_t*)p; p += align16(4 * nb * channels);
-  w.rec_idx = (int32_t*)p; p += align16(4 * pts);
-  w.rec_z = (float*)p; p += align16(4 * pts);
-  w.rec_feat = (float*)p;
+  w.rec = (uint32_t*)p;
   return w;
 }
 
-__device__ __forceinline__ void tile_of(int32_t idx, int width, int tiles_x, int* tile, int* local) {
-  const int y = idx / width, x = idx - y * width;
+// packed target of a valid point: tile << 11 | pixel inside the tile (kTilePx = 2048).
+// y = idx / width through a host-made reciprocal: wmagic = 2^40 / width + 1 is exact while
+// idx * width < 2^40 (checked by the launcher).
+__device__ __forceinline__ int32_t pack_tile(int32_t idx, int width, uint64_t wmagic, int tiles_x) {
+  const int y = (int)(((uint64_t)(uint32_t)idx * wmagic) >> 40), x = idx - y * width;
   const int ty = y / kTileY, tx = x / kTileX;
-  *tile = ty * tiles_x + tx;
-  *local = (y - ty * kTileY) * kTileX + (x - tx * kTileX);
+  return ((ty * tiles_x + tx) << 11) | ((y - ty * kTileY) * kTileX + (x - tx * kTileX));
 }
 
-// A: per point -> (idx, z) as splat_zmin_kernel, no z-buffer atomics; per-block tile histogram.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// A: per point -> (packed target, z) as splat_zmin_kernel, no z-buffer atomics; one histogram row
+// per chunk.
 template <typename T, bool EQUIRECT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kChunkThreads)
 splat_bin_count_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
-                       const T* __restrict__ feats, int64_t m, int channels, int height, int width,
-                       float input_void, int ntiles, int tiles_x, SplatWs ws, BinWs bw) {
+                       const T* __restrict__ feats, int64_t m, int64_t per, int channels,
+                       int height, int width, uint64_t wmagic, float input_void, int ntiles,
+                       int tiles_x, SplatWs ws, BinWs bw) {
   extern __shared__ uint32_t s_hist[];   // [ntiles]
   const int b = blockIdx.y;
-  for (int t = threadIdx.x; t < ntiles; t += kBlock) s_hist[t] = 0u;
+  for (int t = threadIdx.x; t < ntiles; t += kChunkThreads) s_hist[t] = 0u;
   __syncthreads();
   const float* X = coords + (int64_t)b * 4 * m;
   float ox = 0.f, oy = 0.f, oz = 0.f;
@@ -435,142 +475,227 @@ splat_bin_count_kernel(const float* __restrict__ coords, const float* __restrict
     oz = offset[b * 3 + 2];
   }
   uint32_t sink = 0xffffffffu;
-  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < m; i0 += (int64_t)gridDim.x * kBlock) {
-    int64_t i = i0 + threadIdx.x;
-    if (i < m) {
-      float x = X[i], y = X[m + i], z = X[2 * m + i];
-      float px, py, pz;
-      if (EQUIRECT) {
-        if (offset) {
-          x = x - ox;
-          y = y - oy;
-          z = z - oz;
-        }
-        se3ds_equirect_project(x, y, z, &px, &py, &pz);
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
+  // the tail every point ends with, whichever path produced (idx, pz)
+  auto finish = [&](int64_t i, int32_t idx, float pz) {
+    if (idx >= 0) {
+      atomicAdd(&s_hist[pack_tile(idx, width, wmagic, tiles_x) >> 11], 1u);
+    } else if (pz == pz) {
+      uint32_t o = se3ds_f32_to_ordered(pz);
+      sink = o < sink ? o : sink;
+    }
+    ws.idx[(int64_t)b * m + i] = idx;
+    ws.z[(int64_t)b * m + i] = pz;
+  };
+  auto exact = [&](int64_t i, float x, float y, float z, int fv) {
+    float px, py, pz;
+    if (EQUIRECT) {
+      se3ds_equirect_project(x, y, z, &px, &py, &pz);
+    } else {
+      px = x;
+      py = y;
+      pz = z;
+    }
+    finish(i, se3ds_splat_index(px, py, pz, width, height, fv), pz);
+  };
+  auto load = [&](int64_t i, float* x, float* y, float* z, int* fv) {
+    *x = X[i];
+    *y = X[m + i];
+    *z = X[2 * m + i];
+    if (EQUIRECT && offset) {
+      *x = *x - ox;
+      *y = *y - oy;
+      *z = *z - oz;
+    }
+    const T* f = feats + ((int64_t)b * m + i) * channels;
+    int v = 1;
+    for (int k = 0; k < channels; ++k) v &= (FeatIO<T>::load(f + k) != input_void);
+    *fv = v;
+  };
+  // Equirect: the fp32 screen (se3ds_geom_math.h) decides ~97 % of the points; the rest are
+  // queued in LDS and take the binary64 path densely after the loop (a divergent fallback would
+  // make nearly every wave pay for it).
+  __shared__ uint32_t s_queue[kExactQueue];
+  __shared__ uint32_t s_qn;
+  if (threadIdx.x == 0) s_qn = 0u;
+  __syncthreads();
+  for (int64_t i = lo + threadIdx.x; i < hi; i += kChunkThreads) {
+    float x, y, z;
+    int fv;
+    load(i, &x, &y, &z, &fv);
+    if (EQUIRECT) {
+      int32_t idx = -1;
+      float pz;
+      if (se3ds_equirect_index_fast(x, y, z, width, height, fv, &idx, &pz)) {
+        finish(i, idx, pz);
       } else {
-        px = x;
-        py = y;
-        pz = z;
+        const uint32_t slot = atomicAdd(&s_qn, 1u);
+        if (slot < (uint32_t)kExactQueue)
+          s_queue[slot] = (uint32_t)(i - lo);
+        else
+          exact(i, x, y, z, fv);
       }
-      const T* f = feats + ((int64_t)b * m + i) * channels;
-      int fv = 1;
-      for (int k = 0; k < channels; ++k) fv &= (FeatIO<T>::load(f + k) != input_void);
-      int32_t idx = se3ds_splat_index(px, py, pz, width, height, fv);
-      ws.idx[(int64_t)b * m + i] = idx;
-      ws.z[(int64_t)b * m + i] = pz;
-      if (idx >= 0) {
-        int tile, local;
-        tile_of(idx, width, tiles_x, &tile, &local);
-        atomicAdd(&s_hist[tile], 1u);
-      } else if (pz == pz) {
-        uint32_t o = se3ds_f32_to_ordered(pz);
-        sink = o < sink ? o : sink;
-      }
+    } else {
+      exact(i, x, y, z, fv);
     }
   }
-  __shared__ uint32_t s_sink[kBlock / 64];
+  if (EQUIRECT) {
+    __syncthreads();
+    const uint32_t qn = s_qn < (uint32_t)kExactQueue ? s_qn : (uint32_t)kExactQueue;
+    for (uint32_t q = threadIdx.x; q < qn; q += kChunkThreads) {
+      const int64_t i = lo + s_queue[q];
+      float x, y, z;
+      int fv;
+      load(i, &x, &y, &z, &fv);
+      exact(i, x, y, z, fv);
+    }
+  }
+  __shared__ uint32_t s_sink[kChunkThreads / 64];
   sink = wave_min_u32(sink);
   if ((threadIdx.x & 63) == 0) s_sink[threadIdx.x >> 6] = sink;
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t v = s_sink[0];
-    for (int i = 1; i < kBlock / 64; ++i) v = s_sink[i] < v ? s_sink[i] : v;
+    for (int i = 1; i < kChunkThreads / 64; ++i) v = s_sink[i] < v ? s_sink[i] : v;
     ws.zpart[blockIdx.y * gridDim.x + blockIdx.x] = v;
   }
-  for (int t = threadIdx.x; t < ntiles; t += kBlock)
-    if (s_hist[t]) atomicAdd(&bw.tile_count[(int64_t)b * ntiles + t], s_hist[t]);
+  uint32_t* row = bw.hist + ((int64_t)b * gridDim.x + blockIdx.x) * ntiles;
+  for (int t = threadIdx.x; t < ntiles; t += kChunkThreads) row[t] = s_hist[t];
 }
 
-// B: exclusive scan of the tile counts (one block), cursors := offsets; the same block reduces
-// the per-block sink-z partials (saves a launch).
+// B1: per tile, exclusive prefix of the chunk rows (in place) and the tile total.  One workgroup
+// per 64 tiles (lanes, coalesced rows); its 16 waves split the chunks.
+__global__ void __launch_bounds__(64 * kScanWaves)
+splat_bin_colscan_kernel(BinWs bw, int chunks, int ntiles, int nb) {
+  __shared__ uint32_t s_sum[kScanWaves][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int gt = blockIdx.x * 64 + lane;
+  const bool ok = gt < nb;
+  const int b = ok ? gt / ntiles : 0, t = ok ? gt - b * ntiles : 0;
+  const int rows = ceil_div(chunks, kScanWaves);
+  const int c0 = w * rows, c1 = c0 + rows < chunks ? c0 + rows : chunks;
+  uint32_t* H = bw.hist + (int64_t)b * chunks * ntiles + t;
+  uint32_t sum = 0;
+  if (ok) {
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) sum += H[(int64_t)c * ntiles];
+  }
+  s_sum[w][lane] = sum;
+  __syncthreads();
+  uint32_t run = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < kScanWaves; ++i) {
+    const uint32_t v = s_sum[i][lane];
+    if (i < w) run += v;
+    total += v;
+  }
+  if (ok) {
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) {
+      const uint32_t v = H[(int64_t)c * ntiles];
+      H[(int64_t)c * ntiles] = run;
+      run += v;
+    }
+    if (w == 0) bw.tile_count[gt] = total;
+  }
+}
+
+// B2: exclusive scan of the tile totals (one block); the same block reduces the per-chunk sink-z
+// partials (saves a launch).
 __global__ void __launch_bounds__(1024)
 splat_bin_scan_kernel(BinWs bw, int nb, SplatWs ws, int nparts) {
-  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_part[1024 / 64];
   __shared__ uint32_t s_sinkz[1024 / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   {
     uint32_t v = 0xffffffffu;
     for (int i = threadIdx.x; i < nparts; i += 1024) v = ws.zpart[i] < v ? ws.zpart[i] : v;
     v = wave_min_u32(v);
-    if ((threadIdx.x & 63) == 0) s_sinkz[threadIdx.x >> 6] = v;
+    if (lane == 0) s_sinkz[w] = v;
   }
   const int per = ceil_div(nb, 1024);
   const int lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
   uint32_t sum = 0;
   for (int i = lo; i < hi; ++i) sum += bw.tile_count[i];
-  s_part[threadIdx.x] = sum;
+  const uint32_t incl = wave_incl_scan_u32(sum);
+  if (lane == 63) s_part[w] = incl;
   __syncthreads();
+  uint32_t run = incl - sum, all = 0;
+#pragma unroll
+  for (int i = 0; i < 1024 / 64; ++i) {
+    const uint32_t v = s_part[i];
+    if (i < w) run += v;
+    all += v;
+  }
   if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i < 1024; ++i) {
-      uint32_t t = s_part[i];
-      s_part[i] = run;
-      run += t;
-    }
-    bw.tile_off[nb] = run;
+    bw.tile_off[nb] = all;
     uint32_t v = s_sinkz[0];
     for (int i = 1; i < 1024 / 64; ++i) v = s_sinkz[i] < v ? s_sinkz[i] : v;
     *ws.sink_z = v;
   }
-  __syncthreads();
-  uint32_t run = s_part[threadIdx.x];
   for (int i = lo; i < hi; ++i) {
     bw.tile_off[i] = run;
-    bw.cursor[i] = run;
     run += bw.tile_count[i];
   }
 }
 
-// C: scatter the valid points into their tile's record range; invalid points feed the sink.
+// C: scatter the valid points of a chunk into its slice of every tile's record range; invalid
+// points feed the sink.
 template <typename T>
-__global__ void __launch_bounds__(kBlock)
-splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int channels, int width, int ntiles,
-                         int tiles_x, SplatWs ws, BinWs bw) {
-  extern __shared__ uint32_t s_mem[];   // [ntiles] counts -> bases, [ntiles] ranks
-  uint32_t* s_base = s_mem;
-  uint32_t* s_rank = s_mem + ntiles;
+__global__ void __launch_bounds__(kChunkThreads)
+splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int64_t per, int channels,
+                         int width, uint64_t wmagic, int ntiles, int tiles_x, SplatWs ws,
+                         BinWs bw) {
+  extern __shared__ uint32_t s_base[];   // [ntiles] next free record of this chunk, per tile
   const int b = blockIdx.y;
-  for (int t = threadIdx.x; t < 2 * ntiles; t += kBlock) s_mem[t] = 0u;
-  __syncthreads();
-  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < m; i0 += (int64_t)gridDim.x * kBlock) {
-    int64_t i = i0 + threadIdx.x;
-    if (i < m) {
-      const int32_t idx = ws.idx[(int64_t)b * m + i];
-      if (idx >= 0) {
-        int tile, local;
-        tile_of(idx, width, tiles_x, &tile, &local);
-        atomicAdd(&s_base[tile], 1u);
-      }
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < ntiles; t += kBlock) {
-    const uint32_t c = s_base[t];
-    s_base[t] = c ? atomicAdd(&bw.cursor[(int64_t)b * ntiles + t], c) : 0u;
+  {
+    const uint32_t* row = bw.hist + ((int64_t)b * gridDim.x + blockIdx.x) * ntiles;
+    const uint32_t* off = bw.tile_off + (int64_t)b * ntiles;
+    for (int t = threadIdx.x; t < ntiles; t += kChunkThreads) s_base[t] = off[t] + row[t];
   }
   __syncthreads();
   constexpr int kMaxC = kMaxBinChannels;
+  constexpr int kU = 4;
   uint32_t smax[kMaxC];
 #pragma unroll
   for (int k = 0; k < kMaxC; ++k) smax[k] = 0u;
-  for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < m; i0 += (int64_t)gridDim.x * kBlock) {
-    int64_t i = i0 + threadIdx.x;
-    if (i < m) {
-      const int32_t idx = ws.idx[(int64_t)b * m + i];
-      const T* f = feats + ((int64_t)b * m + i) * channels;
-      if (idx >= 0) {
-        int tile, local;
-        tile_of(idx, width, tiles_x, &tile, &local);
-        const uint32_t pos = s_base[tile] + atomicAdd(&s_rank[tile], 1u);
-        bw.rec_idx[pos] = local;
-        bw.rec_z[pos] = ws.z[(int64_t)b * m + i];
+  const int stride = 2 + channels;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
+  const int32_t* I = ws.idx + (int64_t)b * m;
+  const float* Z = ws.z + (int64_t)b * m;
+  const T* F = feats + (int64_t)b * m * channels;
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kU * kChunkThreads) {
+    int32_t idx[kU];
+    float z[kU], f[kU][kMaxC];
+    bool in[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + u * kChunkThreads;
+      in[u] = i < hi;
+      const int64_t j = in[u] ? i : lo;
+      idx[u] = I[j];
+      z[u] = Z[j];
+#pragma unroll
+      for (int k = 0; k < kMaxC; ++k)
+        if (k < channels) f[u][k] = FeatIO<T>::load(F + j * channels + k);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (!in[u]) continue;
+      if (idx[u] >= 0) {
+        const int32_t pk = pack_tile(idx[u], width, wmagic, tiles_x);
+        const uint32_t pos = atomicAdd(&s_base[pk >> 11], 1u);
+        uint32_t* r = bw.rec + (int64_t)pos * stride;
+        r[0] = (uint32_t)(pk & (kTilePx - 1));
+        r[1] = __float_as_uint(z[u]);
 #pragma unroll
         for (int k = 0; k < kMaxC; ++k)
-          if (k < channels) bw.rec_feat[(int64_t)pos * channels + k] = FeatIO<T>::load(f + k);
+          if (k < channels) r[2 + k] = __float_as_uint(f[u][k]);
       } else {
 #pragma unroll
         for (int k = 0; k < kMaxC; ++k)
           if (k < channels) {
-            const float v = FeatIO<T>::load(f + k);
+            const float v = f[u][k];
             if (v == v) {
               const uint32_t o = se3ds_f32_to_ordered(v);
               smax[k] = o > smax[k] ? o : smax[k];
@@ -579,7 +704,7 @@ splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int channels, i
       }
     }
   }
-  __shared__ uint32_t s_f[kMaxC][kBlock / 64];
+  __shared__ uint32_t s_f[kMaxC][kChunkThreads / 64];
 #pragma unroll
   for (int k = 0; k < kMaxC; ++k) {
     uint32_t v = wave_max_u32(smax[k]);
@@ -588,14 +713,17 @@ splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int channels, i
   __syncthreads();
   if ((int)threadIdx.x < channels) {
     uint32_t v = 0u;
-    for (int i = 0; i < kBlock / 64; ++i) v = s_f[threadIdx.x][i] > v ? s_f[threadIdx.x][i] : v;
+    for (int i = 0; i < kChunkThreads / 64; ++i)
+      v = s_f[threadIdx.x][i] > v ? s_f[threadIdx.x][i] : v;
     ws.fpart[(int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * channels + threadIdx.x] = v;
   }
 }
 
-// D: one workgroup per target tile: z-min, tolerance test, per-channel max, finalize.
+// D: one workgroup per target tile: z-min, tolerance test, per-channel max, finalize.  Records
+// are read four at a time per thread (independent loads in flight; the loops are latency bound).
+constexpr int kResolveThreads = 512;
 template <bool ORDERED>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kResolveThreads)
 splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int tiles_x,
                           float depth_scale, float output_void, float mask_void,
                           float* __restrict__ depth, float* __restrict__ feat,
@@ -607,12 +735,25 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
   const int b = bt / ntiles, t = bt - b * ntiles;
   const int ty = t / tiles_x, tx = t - ty * tiles_x;
   const uint32_t fvoid = se3ds_f32_to_ordered(output_void);
-  for (int p = threadIdx.x; p < kTilePx; p += kBlock) s_z[p] = __float_as_uint(depth_scale);
-  for (int p = threadIdx.x; p < kTilePx * channels; p += kBlock) s_fe[p] = fvoid;
-  __syncthreads();
   const uint32_t r0 = bw.tile_off[bt], r1 = bw.tile_off[bt + 1];
-  for (uint32_t r = r0 + threadIdx.x; r < r1; r += kBlock)
-    atomicMin(&s_z[bw.rec_idx[r]], __float_as_uint(bw.rec_z[r]));   // valid => z > 0
+  for (int p = threadIdx.x; p < kTilePx; p += kResolveThreads) s_z[p] = __float_as_uint(depth_scale);
+  for (int p = threadIdx.x; p < kTilePx * channels; p += kResolveThreads) s_fe[p] = fvoid;
+  __syncthreads();
+  constexpr int kU = 4;
+  const int stride = 2 + channels;
+  for (uint32_t q0 = r0 + threadIdx.x; q0 < r1; q0 += kU * kResolveThreads) {
+    uint32_t li[kU], zb[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const uint32_t q = q0 + u * kResolveThreads;
+      const uint32_t* r = bw.rec + (int64_t)(q < r1 ? q : r0) * stride;
+      li[u] = r[0];
+      zb[u] = r[1];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u)
+      if (q0 + u * kResolveThreads < r1) atomicMin(&s_z[li[u]], zb[u]);   // valid => z > 0
+  }
   __syncthreads();
   const bool have_sink_z = (*ws.sink_z != 0xffffffffu);
   const float sink_z = se3ds_ordered_to_f32(*ws.sink_z);
@@ -621,25 +762,40 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
   uint32_t smax[kMaxC];
 #pragma unroll
   for (int k = 0; k < kMaxC; ++k) smax[k] = 0u;
-  for (uint32_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
-    const int li = bw.rec_idx[r];
-    const float z = bw.rec_z[r];
-    float zm = __uint_as_float(s_z[li]);
-    if (first && li == 0 && have_sink_z) zm = sink_z < zm ? sink_z : zm;
-    const bool keep = z < zm + 0.1f;
+  for (uint32_t q0 = r0 + threadIdx.x; q0 < r1; q0 += kU * kResolveThreads) {
+    uint32_t li[kU], zb[kU], fb[kU][kMaxC];
 #pragma unroll
-    for (int k = 0; k < kMaxC; ++k)
-      if (k < channels) {
-        const float v = bw.rec_feat[(int64_t)r * channels + k];
-        if (keep) {
-          if (ORDERED || v > 0.0f) atomicMax(&s_fe[k * kTilePx + li], se3ds_f32_to_ordered(v));
-        } else if (v == v) {
-          const uint32_t o = se3ds_f32_to_ordered(v);
-          smax[k] = o > smax[k] ? o : smax[k];
+    for (int u = 0; u < kU; ++u) {
+      const uint32_t q = q0 + u * kResolveThreads;
+      const uint32_t* r = bw.rec + (int64_t)(q < r1 ? q : r0) * stride;
+      li[u] = r[0];
+      zb[u] = r[1];
+#pragma unroll
+      for (int k = 0; k < kMaxC; ++k)
+        if (k < channels) fb[u][k] = r[2 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (q0 + u * kResolveThreads >= r1) continue;
+      const float z = __uint_as_float(zb[u]);
+      float zm = __uint_as_float(s_z[li[u]]);
+      if (first && li[u] == 0 && have_sink_z) zm = sink_z < zm ? sink_z : zm;
+      const bool keep = z < zm + 0.1f;
+#pragma unroll
+      for (int k = 0; k < kMaxC; ++k)
+        if (k < channels) {
+          const float v = __uint_as_float(fb[u][k]);
+          if (keep) {
+            if (ORDERED || v > 0.0f)
+              atomicMax(&s_fe[k * kTilePx + li[u]], se3ds_f32_to_ordered(v));
+          } else if (v == v) {
+            const uint32_t o = se3ds_f32_to_ordered(v);
+            smax[k] = o > smax[k] ? o : smax[k];
+          }
         }
-      }
+    }
   }
-  __shared__ uint32_t s_f[kMaxC][kBlock / 64];
+  __shared__ uint32_t s_f[kMaxC][kResolveThreads / 64];
 #pragma unroll
   for (int k = 0; k < kMaxC; ++k) {
     uint32_t v = wave_max_u32(smax[k]);
@@ -648,12 +804,12 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
   __syncthreads();
   if ((int)threadIdx.x < channels) {
     uint32_t v = 0u;
-    for (int i = 0; i < kBlock / 64; ++i) v = s_f[threadIdx.x][i] > v ? s_f[threadIdx.x][i] : v;
+    for (int i = 0; i < kResolveThreads / 64; ++i) v = s_f[threadIdx.x][i] > v ? s_f[threadIdx.x][i] : v;
     bw.fpart2[(int64_t)bt * channels + threadIdx.x] = v;
   }
-  // finalize (pixel 0's feature / mask fold of the sink happens in splat_pixel0_kernel)
+  // finalize (pixel 0's feature / mask fold of the sink happens in splat_sink_feat2_kernel)
   const int64_t hw = (int64_t)height * width;
-  for (int p = threadIdx.x; p < kTilePx; p += kBlock) {
+  for (int p = threadIdx.x; p < kTilePx; p += kResolveThreads) {
     const int y = ty * kTileY + p / kTileX, x = tx * kTileX + (p % kTileX);
     if (y >= height || x >= width) continue;
     const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
@@ -725,22 +881,25 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
   const int tiles_x = ceil_div(width, kTileX), tiles_y = ceil_div(height, kTileY);
   const int ntiles = tiles_x * tiles_y, nb = n * ntiles;
   const bool ordered = !(output_void >= 0.0f);
-  (void)hipMemsetAsync(bw.tile_count, 0, 4 * (size_t)nb, stream);
-  dim3 g_pt = point_grid(m, n, kBlock);
-  const int nparts = (int)(g_pt.x * g_pt.y);
-  hipLaunchKernelGGL((splat_bin_count_kernel<T, EQUIRECT>), g_pt, dim3(kBlock), 4 * ntiles, stream,
-                     coords, offset, feats, m, channels, height, width, input_void, ntiles, tiles_x,
-                     ws, bw);
+  const ChunkGeom cg = chunk_geom(m, n);
+  const uint64_t wmagic = ((uint64_t)1 << 40) / (uint64_t)width + 1;
+  const dim3 g_pt((unsigned)cg.chunks, (unsigned)n);
+  const int nparts = cg.chunks * n;
+  hipLaunchKernelGGL((splat_bin_count_kernel<T, EQUIRECT>), g_pt, dim3(kChunkThreads), 4 * ntiles,
+                     stream, coords, offset, feats, m, cg.per, channels, height, width, wmagic,
+                     input_void, ntiles, tiles_x, ws, bw);
+  hipLaunchKernelGGL(splat_bin_colscan_kernel, dim3(ceil_div(nb, 64)), dim3(64 * kScanWaves), 0,
+                     stream, bw, cg.chunks, ntiles, nb);
   hipLaunchKernelGGL(splat_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, bw, nb, ws, nparts);
-  hipLaunchKernelGGL((splat_bin_scatter_kernel<T>), g_pt, dim3(kBlock), 8 * ntiles, stream, feats, m,
-                     channels, width, ntiles, tiles_x, ws, bw);
+  hipLaunchKernelGGL((splat_bin_scatter_kernel<T>), g_pt, dim3(kChunkThreads), 4 * ntiles, stream,
+                     feats, m, cg.per, channels, width, wmagic, ntiles, tiles_x, ws, bw);
   const size_t tile_lds = 4 * (size_t)kTilePx * (1 + channels);
   if (ordered)
-    hipLaunchKernelGGL(splat_tile_resolve_kernel<true>, dim3(nb), dim3(kBlock), tile_lds, stream,
+    hipLaunchKernelGGL(splat_tile_resolve_kernel<true>, dim3(nb), dim3(kResolveThreads), tile_lds, stream,
                        channels, height, width, ntiles, tiles_x, depth_scale, output_void, mask_void,
                        depth, feat, mask, ws, bw);
   else
-    hipLaunchKernelGGL(splat_tile_resolve_kernel<false>, dim3(nb), dim3(kBlock), tile_lds, stream,
+    hipLaunchKernelGGL(splat_tile_resolve_kernel<false>, dim3(nb), dim3(kResolveThreads), tile_lds, stream,
                        channels, height, width, ntiles, tiles_x, depth_scale, output_void, mask_void,
                        depth, feat, mask, ws, bw);
   hipLaunchKernelGGL(splat_sink_feat2_kernel, dim3(1), dim3(kBlock), 0, stream, ws, bw, nparts, nb,
@@ -757,7 +916,8 @@ int launch_splat(const float* coords, const float* offset, const T* feats, int n
     static const bool no_bin = getenv("SE3DS_SPLAT_SCATTER") != nullptr;
     const int64_t ntiles = (int64_t)ceil_div(height, kTileY) * ceil_div(width, kTileX);
     if (!no_bin && m > 0 && channels <= kMaxBinChannels && ntiles <= kMaxTiles &&
-        (int64_t)n * m < ((int64_t)1 << 31))
+        (int64_t)n * m < ((int64_t)1 << 31) &&
+        (int64_t)height * width * width < ((int64_t)1 << 40))
       return launch_splat_binned<T, EQUIRECT>(coords, offset, feats, n, m, channels, height, width,
                                               depth_scale, input_void, output_void, depth, feat,
                                               mask, mask_void, workspace, stream);

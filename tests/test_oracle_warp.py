@@ -192,3 +192,31 @@ def test_interpolate_bilinear_identity_and_clamp():
   np.testing.assert_array_equal(warp_np.interpolate_bilinear(g, qxy, indexing='xy'), out)
   far = np.array([[[-3.0, 100.0]]], F32).repeat(2, 0)
   np.testing.assert_allclose(warp_np.interpolate_bilinear(g, far)[:, 0], g[:, 0, -1], atol=1e-6)
+
+
+@pytest.mark.parametrize('h', [64, 1024, 2048])
+def test_fast_index_screen_error_bound(h):
+  """include/se3ds_geom_math.h: the fp32 screen the splat kernels use before the binary64 path.
+  Every index it decides equals the exact one, and its deviation stays >= 16x below the margin."""
+  rng = np.random.default_rng(5 + h)
+  w, m = 2 * h, 400_000
+  clouds = [rng.standard_normal((3, m)) * rng.uniform(0.01, 20, (1, m))]
+  for axis, scale in [(0, 1e-4), (1, 1e-4), (2, 1e-5)]:   # next to the wrap, the poles' axis, the equator
+    v = rng.standard_normal((3, m))
+    v[axis] *= scale
+    clouds.append(v)
+  v = rng.standard_normal((3, m))
+  v[:2] *= 1e-3                                            # next to the poles
+  clouds.append(v)
+  clouds.append(rng.standard_normal((3, m)) * 1e-18)
+  clouds.append(rng.integers(-3, 4, (3, m)))               # exact ties, zeros
+  margin = 4.0e-6                                          # SE3DS_FAST_MARGIN
+  for v in clouds:
+    ex, ey, decided, wrong = warp_c.fast_screen_stats(v.astype(np.float32), h, w)
+    assert wrong == 0
+    # the heading wrap (fx ~ 0 vs ~ W) is the one place the two chains differ by a full width;
+    # both values then sit on an integer and the screen leaves the point to the exact path
+    assert ex <= margin / 16 or ex > 0.99
+    assert ey <= margin / 16
+  ex, ey, decided, _ = warp_c.fast_screen_stats(clouds[0].astype(np.float32), h, w)
+  assert decided / m > 0.9
