@@ -211,7 +211,10 @@ SE3DS_HD void se3ds_splat_fxy(float px, float py, float pz, int width, int heigh
   *fy = (vy + 1.0f) / 2.0f * (float)height;
 }
 
-/* The fast chain: (fx, fy) and rad = pz. */
+/* The fast chain: (fx, fy) and rad = pz.  Algebraically the reference's chain collapses to
+ * fx = heading * W / (2 pi), fy = elevation * H / pi (the multiplication by rad and the division
+ * by pz = rad cancel); the few ulps by which the individually rounded chain differs are part of
+ * the measured deviation. */
 SE3DS_HD void se3ds_equirect_fxy_fast(float x, float y, float z, int width, int height, float* fx,
                                       float* fy, float* pz) {
   float rad = __builtin_sqrtf((x * x + y * y) + z * z);
@@ -222,9 +225,8 @@ SE3DS_HD void se3ds_equirect_fxy_fast(float x, float y, float z, int width, int 
   heading = heading - SE3DS_F32_TWO_PI * (heading > SE3DS_F32_TWO_PI ? 1.0f : 0.0f);
   float w = z / rad;
   float elevation = se3ds_atan2_fast(__builtin_sqrtf((1.0f - w) * (1.0f + w)), w);
-  float px = rad * ((heading / SE3DS_F32_TWO_PI) * 2.0f - 1.0f);
-  float py = rad * ((elevation / SE3DS_F32_PI) * 2.0f - 1.0f);
-  se3ds_splat_fxy(px, py, rad, width, height, fx, fy);
+  *fx = (heading * 0.159154943091895336f) * (float)width;  /* 1 / (2 pi) */
+  *fy = (elevation * 0.318309886183790672f) * (float)height; /* 1 / pi */
 }
 
 /* Fast screen: returns 1 and the index (or -1) when the fast evaluation decides it, 0 when the

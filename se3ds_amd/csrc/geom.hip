@@ -407,7 +407,6 @@ __host__ __device__ inline ChunkGeom chunk_geom(int64_t m, int n) {
 
 struct BinWs {
   uint32_t* tile_count;   // [nb]
-  uint32_t* tile_off;     // [nb + 1]
   uint32_t* hist;         // [n][chunks][ntiles]: counts, then exclusive prefix over the chunks
   uint32_t* fpart2;       // [nb][C] sink partials of the occluded points, per tile
   uint32_t* rec;          // [N*M][2 + C]: pixel inside the tile, z bits, feature bits
@@ -418,7 +417,7 @@ __host__ __device__ inline size_t bin_ws_bytes(int n, int64_t m, int height, int
   const size_t nb = (size_t)n * ntiles;
   const size_t pts = (size_t)n * (size_t)(m > 0 ? m : 0);
   const size_t chunks = (size_t)chunk_geom(m, n).chunks;
-  return align16(4 * nb) + align16(4 * (nb + 1)) + align16(4 * nb * chunks) +
+  return align16(4 * nb) + align16(4 * nb * chunks) +
          align16(4 * nb * channels) + align16(4 * pts * (2 + channels));
 }
 __host__ __device__ inline BinWs carve_bin_ws(void* base, int n, int64_t m, int height, int width,
@@ -429,7 +428,6 @@ __host__ __device__ inline BinWs carve_bin_ws(void* base, int n, int64_t m, int 
   char* p = (char*)base;
   BinWs w;
   w.tile_count = (uint32_t*)p; p += align16(4 * nb);
-  w.tile_off = (uint32_t*)p; p += align16(4 * (nb + 1));
   w.hist = (uint32_t*)p; p += align16(4 * nb * chunks);
   w.fpart2 = (uint32_t*)p; p += align16(4 * nb * channels);
   w.rec = (uint32_t*)p;
@@ -453,6 +451,25 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     if (lane >= d) v += o;
   }
   return v;
+}
+
+// Exclusive scan of `v` over the workgroup (NW waves); *total = sum.  s_w: NW words of LDS.
+template <int NW>
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t incl = wave_incl_scan_u32(v);
+  __syncthreads();   // s_w may still be read from a previous call
+  if (lane == 63) s_w[w] = incl;
+  __syncthreads();
+  uint32_t run = incl - v, all = 0;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const uint32_t t = s_w[i];
+    if (i < w) run += t;
+    all += t;
+  }
+  *total = all;
+  return run;
 }
 
 // A: per point -> (packed target, z) as splat_zmin_kernel, no z-buffer atomics; one histogram row
@@ -519,10 +536,14 @@ splat_bin_count_kernel(const float* __restrict__ coords, const float* __restrict
   __shared__ uint32_t s_qn;
   if (threadIdx.x == 0) s_qn = 0u;
   __syncthreads();
+  // the next point's inputs are requested before the current one is worked on
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  int nfv = 0;
+  if (lo + threadIdx.x < hi) load(lo + threadIdx.x, &nx, &ny, &nz, &nfv);
   for (int64_t i = lo + threadIdx.x; i < hi; i += kChunkThreads) {
-    float x, y, z;
-    int fv;
-    load(i, &x, &y, &z, &fv);
+    const float x = nx, y = ny, z = nz;
+    const int fv = nfv;
+    if (i + kChunkThreads < hi) load(i + kChunkThreads, &nx, &ny, &nz, &nfv);
     if (EQUIRECT) {
       int32_t idx = -1;
       float pz;
@@ -600,45 +621,6 @@ splat_bin_colscan_kernel(BinWs bw, int chunks, int ntiles, int nb) {
   }
 }
 
-// B2: exclusive scan of the tile totals (one block); the same block reduces the per-chunk sink-z
-// partials (saves a launch).
-__global__ void __launch_bounds__(1024)
-splat_bin_scan_kernel(BinWs bw, int nb, SplatWs ws, int nparts) {
-  __shared__ uint32_t s_part[1024 / 64];
-  __shared__ uint32_t s_sinkz[1024 / 64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  {
-    uint32_t v = 0xffffffffu;
-    for (int i = threadIdx.x; i < nparts; i += 1024) v = ws.zpart[i] < v ? ws.zpart[i] : v;
-    v = wave_min_u32(v);
-    if (lane == 0) s_sinkz[w] = v;
-  }
-  const int per = ceil_div(nb, 1024);
-  const int lo = threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
-  uint32_t sum = 0;
-  for (int i = lo; i < hi; ++i) sum += bw.tile_count[i];
-  const uint32_t incl = wave_incl_scan_u32(sum);
-  if (lane == 63) s_part[w] = incl;
-  __syncthreads();
-  uint32_t run = incl - sum, all = 0;
-#pragma unroll
-  for (int i = 0; i < 1024 / 64; ++i) {
-    const uint32_t v = s_part[i];
-    if (i < w) run += v;
-    all += v;
-  }
-  if (threadIdx.x == 0) {
-    bw.tile_off[nb] = all;
-    uint32_t v = s_sinkz[0];
-    for (int i = 1; i < 1024 / 64; ++i) v = s_sinkz[i] < v ? s_sinkz[i] : v;
-    *ws.sink_z = v;
-  }
-  for (int i = lo; i < hi; ++i) {
-    bw.tile_off[i] = run;
-    run += bw.tile_count[i];
-  }
-}
-
 // C: scatter the valid points of a chunk into its slice of every tile's record range; invalid
 // points feed the sink.
 template <typename T>
@@ -649,9 +631,24 @@ splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int64_t per, in
   extern __shared__ uint32_t s_base[];   // [ntiles] next free record of this chunk, per tile
   const int b = blockIdx.y;
   {
+    // first record of (image b, tile t) = exclusive scan of the tile totals; every workgroup
+    // redoes it in LDS (a few K values) rather than waiting for a one-block scan kernel
+    __shared__ uint32_t s_w[kChunkThreads / 64];
+    uint32_t before = 0, base;
+    for (int64_t i = threadIdx.x; i < (int64_t)b * ntiles; i += kChunkThreads)
+      before += bw.tile_count[i];
+    (void)block_excl_scan_u32<kChunkThreads / 64>(before, s_w, &base);
+    const uint32_t* cnt = bw.tile_count + (int64_t)b * ntiles;
     const uint32_t* row = bw.hist + ((int64_t)b * gridDim.x + blockIdx.x) * ntiles;
-    const uint32_t* off = bw.tile_off + (int64_t)b * ntiles;
-    for (int t = threadIdx.x; t < ntiles; t += kChunkThreads) s_base[t] = off[t] + row[t];
+    const int pt = ceil_div(ntiles, kChunkThreads);
+    const int t0 = threadIdx.x * pt, t1 = t0 + pt < ntiles ? t0 + pt : ntiles;
+    uint32_t sum = 0, all;
+    for (int t = t0; t < t1; ++t) sum += cnt[t];
+    uint32_t run = base + block_excl_scan_u32<kChunkThreads / 64>(sum, s_w, &all);
+    for (int t = t0; t < t1; ++t) {
+      s_base[t] = run + row[t];
+      run += cnt[t];
+    }
   }
   __syncthreads();
   constexpr int kMaxC = kMaxBinChannels;
@@ -721,13 +718,17 @@ splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int64_t per, in
 
 // D: one workgroup per target tile: z-min, tolerance test, per-channel max, finalize.  Records
 // are read four at a time per thread (independent loads in flight; the loops are latency bound).
+// With SC > 0 (channels <= SC) a thread's first kStash records stay in registers between the two
+// passes, so they are read once.
 constexpr int kResolveThreads = 512;
-template <bool ORDERED>
+constexpr int kStash = 8;
+constexpr int kStashChannels = 3;
+template <bool ORDERED, int SC>
 __global__ void __launch_bounds__(kResolveThreads)
 splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int tiles_x,
                           float depth_scale, float output_void, float mask_void,
                           float* __restrict__ depth, float* __restrict__ feat,
-                          float* __restrict__ mask, SplatWs ws, BinWs bw) {
+                          float* __restrict__ mask, SplatWs ws, BinWs bw, uint32_t zpart_count) {
   extern __shared__ uint32_t s_tile[];   // z[kTilePx], feat[channels][kTilePx]
   uint32_t* s_z = s_tile;
   uint32_t* s_fe = s_tile + kTilePx;
@@ -735,13 +736,58 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
   const int b = bt / ntiles, t = bt - b * ntiles;
   const int ty = t / tiles_x, tx = t - ty * tiles_x;
   const uint32_t fvoid = se3ds_f32_to_ordered(output_void);
-  const uint32_t r0 = bw.tile_off[bt], r1 = bw.tile_off[bt + 1];
+  __shared__ uint32_t s_w[kResolveThreads / 64];
+  uint32_t r0, r1;   // record range of the tile = prefix of the tile totals
+  {
+    uint32_t part = 0;
+    for (int i = threadIdx.x; i < bt; i += kResolveThreads) part += bw.tile_count[i];
+    (void)block_excl_scan_u32<kResolveThreads / 64>(part, s_w, &r0);
+    r1 = r0 + bw.tile_count[bt];
+  }
+  const bool first = bt == 0;   // holds flat pixel 0, which also receives the sink
+  uint32_t sink_o = 0xffffffffu;   // min z of the invalid points (all chunks, all images)
+  if (first) {
+    uint32_t v = 0xffffffffu;
+    for (uint32_t i = threadIdx.x; i < zpart_count; i += kResolveThreads) {
+      const uint32_t z = ws.zpart[i];
+      v = z < v ? z : v;
+    }
+    v = wave_min_u32(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    for (int i = 0; i < kResolveThreads / 64; ++i) sink_o = s_w[i] < sink_o ? s_w[i] : sink_o;
+  }
+  const bool have_sink_z = sink_o != 0xffffffffu;
+  const float sink_z = se3ds_ordered_to_f32(sink_o);
   for (int p = threadIdx.x; p < kTilePx; p += kResolveThreads) s_z[p] = __float_as_uint(depth_scale);
   for (int p = threadIdx.x; p < kTilePx * channels; p += kResolveThreads) s_fe[p] = fvoid;
   __syncthreads();
   constexpr int kU = 4;
   const int stride = 2 + channels;
-  for (uint32_t q0 = r0 + threadIdx.x; q0 < r1; q0 += kU * kResolveThreads) {
+  constexpr int NS = SC > 0 ? kStash : 1, NC = SC > 0 ? SC : 1;
+  uint32_t st_li[NS], st_z[NS], st_f[NS][NC];
+  if (SC > 0) {
+#pragma unroll
+    for (int k0 = 0; k0 < NS; k0 += kU) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t q = r0 + threadIdx.x + (k0 + u) * kResolveThreads;
+        const uint32_t* r = bw.rec + (int64_t)(q < r1 ? q : r0) * stride;
+        const bool in = q < r1;
+        st_li[k0 + u] = in ? r[0] : 0u;
+        st_z[k0 + u] = in ? r[1] : 0u;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) st_f[k0 + u][k] = (in && k < channels) ? r[2 + k] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (r0 + threadIdx.x + (k0 + u) * kResolveThreads < r1)
+          atomicMin(&s_z[st_li[k0 + u]], st_z[k0 + u]);
+    }
+  }
+  const uint32_t rest = r0 + threadIdx.x + (SC > 0 ? kStash * kResolveThreads : 0);
+  for (uint32_t q0 = rest; q0 < r1; q0 += kU * kResolveThreads) {
     uint32_t li[kU], zb[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -755,14 +801,33 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
       if (q0 + u * kResolveThreads < r1) atomicMin(&s_z[li[u]], zb[u]);   // valid => z > 0
   }
   __syncthreads();
-  const bool have_sink_z = (*ws.sink_z != 0xffffffffu);
-  const float sink_z = se3ds_ordered_to_f32(*ws.sink_z);
-  const bool first = bt == 0;   // holds flat pixel 0, which also receives the sink
   constexpr int kMaxC = kMaxBinChannels;
   uint32_t smax[kMaxC];
 #pragma unroll
   for (int k = 0; k < kMaxC; ++k) smax[k] = 0u;
-  for (uint32_t q0 = r0 + threadIdx.x; q0 < r1; q0 += kU * kResolveThreads) {
+  if (SC > 0) {
+#pragma unroll
+    for (int k0 = 0; k0 < NS; ++k0) {
+      if (r0 + threadIdx.x + k0 * kResolveThreads >= r1) continue;
+      const uint32_t li = st_li[k0];
+      const float z = __uint_as_float(st_z[k0]);
+      float zm = __uint_as_float(s_z[li]);
+      if (first && li == 0 && have_sink_z) zm = sink_z < zm ? sink_z : zm;
+      const bool keep = z < zm + 0.1f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (k < channels) {
+          const float v = __uint_as_float(st_f[k0][k]);
+          if (keep) {
+            if (ORDERED || v > 0.0f) atomicMax(&s_fe[k * kTilePx + li], se3ds_f32_to_ordered(v));
+          } else if (v == v) {
+            const uint32_t o = se3ds_f32_to_ordered(v);
+            smax[k] = o > smax[k] ? o : smax[k];
+          }
+        }
+    }
+  }
+  for (uint32_t q0 = rest; q0 < r1; q0 += kU * kResolveThreads) {
     uint32_t li[kU], zb[kU], fb[kU][kMaxC];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -890,18 +955,20 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
                      input_void, ntiles, tiles_x, ws, bw);
   hipLaunchKernelGGL(splat_bin_colscan_kernel, dim3(ceil_div(nb, 64)), dim3(64 * kScanWaves), 0,
                      stream, bw, cg.chunks, ntiles, nb);
-  hipLaunchKernelGGL(splat_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, bw, nb, ws, nparts);
   hipLaunchKernelGGL((splat_bin_scatter_kernel<T>), g_pt, dim3(kChunkThreads), 4 * ntiles, stream,
                      feats, m, cg.per, channels, width, wmagic, ntiles, tiles_x, ws, bw);
   const size_t tile_lds = 4 * (size_t)kTilePx * (1 + channels);
-  if (ordered)
-    hipLaunchKernelGGL(splat_tile_resolve_kernel<true>, dim3(nb), dim3(kResolveThreads), tile_lds, stream,
-                       channels, height, width, ntiles, tiles_x, depth_scale, output_void, mask_void,
-                       depth, feat, mask, ws, bw);
-  else
-    hipLaunchKernelGGL(splat_tile_resolve_kernel<false>, dim3(nb), dim3(kResolveThreads), tile_lds, stream,
-                       channels, height, width, ntiles, tiles_x, depth_scale, output_void, mask_void,
-                       depth, feat, mask, ws, bw);
+#define SE3DS_RESOLVE(ORD, SC)                                                                   \
+  hipLaunchKernelGGL((splat_tile_resolve_kernel<ORD, SC>), dim3(nb), dim3(kResolveThreads),      \
+                     tile_lds, stream, channels, height, width, ntiles, tiles_x, depth_scale,    \
+                     output_void, mask_void, depth, feat, mask, ws, bw, (uint32_t)nparts)
+  static const bool no_stash = getenv("SE3DS_RESOLVE_NOSTASH") != nullptr;
+  if (channels <= kStashChannels && !no_stash) {
+    if (ordered) SE3DS_RESOLVE(true, kStashChannels); else SE3DS_RESOLVE(false, kStashChannels);
+  } else {
+    if (ordered) SE3DS_RESOLVE(true, 0); else SE3DS_RESOLVE(false, 0);
+  }
+#undef SE3DS_RESOLVE
   hipLaunchKernelGGL(splat_sink_feat2_kernel, dim3(1), dim3(kBlock), 0, stream, ws, bw, nparts, nb,
                      channels, depth, feat, mask, mask_void);
   return check_launch("splat(binned)");
