@@ -36,3 +36,14 @@ def test_two_replicas_share_one_gpu_over_gloo():
     pytest.skip('two-process gloo rendezvous on one GPU hung twice (infrastructure)')
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
   assert 'DIST_GPU_OK' in r.stdout
+
+
+def test_rccl_single_rank_api_paths():
+  """The real `nccl` (= RCCL) backend with one rank: every collective shape of the multi-GPU step
+  is accepted (the 8-GPU run itself is the driver's)."""
+  env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_rccl_worker.py'),
+                      str(_free_port())], env=env, cwd=ROOT, capture_output=True, text=True,
+                     timeout=240)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+  assert 'RCCL_OK' in r.stdout
