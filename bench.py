@@ -132,7 +132,7 @@ def bench_warp(args, rank, world, dev):
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
       'data': 'synthetic',
       'config': {'workload': f'warp cfg5 {h}x{w} V={views} (replicas only)'},
-      'roofline': {'bound': 'hbm', 'kernel': 'project+splat (bin count, scan, scatter, per-tile resolve)',
+      'roofline': {'bound': 'hbm', 'kernel': 'project+splat (chunk count, column scan, scatter, per-tile resolve)',
                    'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                    'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                    'ms_per_launch': proj_ms, 'algorithmic_bytes': algo_bytes},
