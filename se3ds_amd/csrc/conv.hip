@@ -318,7 +318,8 @@ template <typename T, int MODE, int NI = 2>
 __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)[NI][2],
                                            int64_t m_base, int co_base, int64_t Mc, int cH, int cW,
                                            int py, int px, int half, int l32,
-                                           unsigned char* scratch = nullptr) {
+                                           unsigned char* scratch = nullptr,
+                                           float* stats_row = nullptr) {
   const int s = p.stride;
   const float scale = p.scale ? *p.scale : 1.0f;
   int64_t opix[2];
@@ -334,7 +335,15 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)
     opix[j] = ((int64_t)n * p.oH + a) * p.oW + b;
   }
   if (sizeof(T) == 2 && scratch != nullptr && (p.oC & 7) == 0 && co_base + NI * 32 <= p.oC) {
-    store_wave_lds<NI>(p, acc, opix, co_base, half * 32 + l32, scratch);
+    if (NI == 4 && stats_row != nullptr) {
+      // column sums are kept per 64-channel half (lane = channel)
+      store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base,
+                        half * 32 + l32, scratch, stats_row);
+      store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64,
+                        half * 32 + l32, scratch, stats_row);
+    } else {
+      store_wave_lds<NI>(p, acc, opix, co_base, half * 32 + l32, scratch, stats_row);
+    }
     return;
   }
 #pragma unroll
@@ -753,8 +762,10 @@ igemm_glds_kernel(const IgemmParams p) {
     if (kt + 1 < nk) k_step(stage1, stage0, kt + 2 < nk);
   }
   // (the loop's closing __syncthreads leaves both stages idle: stage0 is the epilogue scratch)
+  float* stats_row = (MODE == MODE_FWD && p.stats)
+                         ? p.stats + ((int64_t)(tile_m * (BM / 64) + wn) * 2) * p.oC : nullptr;
   store_tile<T, MODE>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py, px,
-                      half, l32, stage0 + wave * kEpiScratch<2>);
+                      half, l32, stage0 + wave * kEpiScratch<2>, stats_row);
 }
 
 // ------------------------------------------------------------------ 256-pixel macro tiles
@@ -983,9 +994,11 @@ igemm_big_kernel(const IgemmParams p) {
   if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the late start of channel half 1
   // every wave is past its last fragment read: the stages become the epilogue scratch
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+  float* stats_row = (MODE == MODE_FWD && p.stats)
+                         ? p.stats + ((int64_t)(tile_m * (PIX / 64) + wn) * 2) * p.oC : nullptr;
   store_tile<T, MODE, NI>(p, acc, (int64_t)tile_m * PIX + wn * 64, n0 + wm * (CO / 2), Mc, cH, cW,
                           py, px, half, l32,
-                          (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>);
+                          (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>, stats_row);
 }
 
 // ------------------------------------------------------------------ halo-resident 3x3 tiles
@@ -2146,6 +2159,20 @@ static int big_tile_channels(const IgemmParams& p, int mode) {
   return t_big < t_small ? co : 0;
 }
 
+// Rows of the [rows][2][oC] column-sum array the routed FORWARD kernel emits from its epilogue
+// (one row per 64-pixel wave tile), or 0 when that kernel cannot (fp32, scalar gather, ragged
+// channel tiles).  Must follow conv_common's routing order: halo, 256-pixel macro tile, 128 x 128.
+static int64_t fwd_stats_rows(const IgemmParams& p, int dtype, int stride, int kh, int kw,
+                              bool glds) {
+  if (!glds || dtype != SE3DS_BF16) return 0;
+  const int64_t M = (int64_t)p.N * p.oH * p.oW;
+  if (stride == 1 && kh == 3 && kw == 3 && halo_tile_channels(p))
+    return (int64_t)p.N * ceil_div(p.oH, 8) * ceil_div(p.oW, 32) * 4;
+  if (big_tile_channels(p, MODE_FWD)) return ceil_div(M, (int64_t)256) * 4;
+  if ((p.oC % BN) == 0) return ceil_div(M, (int64_t)BM) * (BM / 64);
+  return 0;
+}
+
 extern "C" {
 
 static int conv_common(int mode, const void* src, const void* w, void* out, int dtype, int n,
@@ -2182,9 +2209,10 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   hipStream_t s = as_stream(stream);
   const bool glds = (p.sC % (2 * bk)) == 0 && (src_mask == nullptr || mask_binary) &&
                     !g_disable_glds;
-  if (stats != nullptr && !(glds && dtype == SE3DS_BF16 && stride == 1 && kh == 3 && kw == 3 &&
-                            mode == MODE_FWD && halo_tile_channels(p)))
+  if (stats != nullptr &&
+      !(mode == MODE_FWD && fwd_stats_rows(p, dtype, stride, kh, kw, glds) > 0))
     return SE3DS_E_UNSUPPORTED;   // callers ask se3ds_conv2d_fwd_stats_rows first
+  p.stats = mode == MODE_FWD ? stats : nullptr;
   if (glds && dtype == SE3DS_BF16 && stride == 1 && kh == 3 && kw == 3) {
     const int co = halo_tile_channels(p);
     if (co) {
@@ -2254,14 +2282,18 @@ int se3ds_conv2d_fwd(const void* x, const void* wt, void* y, int dtype, int n, i
 
 int64_t se3ds_conv2d_fwd_stats_rows(int dtype, int n, int cin, int ho, int wo, int cout, int kh,
                                     int kw, int stride, int has_in_mask, int in_mask_binary) {
-  if (dtype != SE3DS_BF16 || stride != 1 || kh != 3 || kw != 3 || (cin % 64) != 0 ||
+  if (dtype != SE3DS_BF16 || stride < 1 || stride > 2 || (cin % 64) != 0 ||
       (has_in_mask && !in_mask_binary) || g_disable_glds)
     return 0;
-  if (getenv("SE3DS_FUSED_BN_STATS") && atoi(getenv("SE3DS_FUSED_BN_STATS")) == 0) return 0;
+  // SE3DS_FUSED_BN_STATS: 0 = never, 1 = only the halo-resident 3x3 kernel, default = every
+  // LDS-DMA kernel
+  const char* e = getenv("SE3DS_FUSED_BN_STATS");
+  const int lvl = e ? atoi(e) : 2;
+  if (lvl == 0) return 0;
   IgemmParams p;
-  p.N = n; p.oH = ho; p.oW = wo; p.oC = cout;
-  if (!halo_tile_channels(p)) return 0;
-  return (int64_t)n * ceil_div(ho, 8) * ceil_div(wo, 32) * 4;
+  p.N = n; p.oH = ho; p.oW = wo; p.oC = cout; p.stride = stride;
+  if (lvl == 1 && !(stride == 1 && kh == 3 && kw == 3 && halo_tile_channels(p))) return 0;
+  return fwd_stats_rows(p, dtype, stride, kh, kw, true);
 }
 
 int se3ds_conv2d_fwd_stats(const void* x, const void* wt, void* y, int dtype, int n, int h, int w,

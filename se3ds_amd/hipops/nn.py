@@ -561,7 +561,8 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
   # Training forward: convs that can also emit the column sums of their output (the statistics
   # a following SyncBatchNormalization needs) do so; norm_act picks them up from the Var.
   stats_rows = 0
-  if ctx.training and recording and act == ACT_NONE and not getattr(ctx, 'bn_use_moving', False):
+  # (the sums are taken over the stored, activated outputs, so a fused activation is fine)
+  if ctx.training and recording and not getattr(ctx, 'bn_use_moving', False):
     stats_rows = int(L.se3ds_conv2d_fwd_stats_rows(ctx.code, n, cin, ho, wo, layer.cout, k, k, s,
                                                    1 if in_mask is not None else 0,
                                                    1 if ctx.binary_masks else 0))

@@ -636,30 +636,39 @@ def test_segment_grad_sync_matches_serial_path(monkeypatch):
   assert res['serial'][5] == pytest.approx(res['overlap'][5], rel=1e-6)
 
 
-@pytest.mark.parametrize('cin,cout,n,h,w', [(64, 128, 2, 16, 32), (128, 256, 3, 11, 70)])
-def test_fused_bn_statistics_match_separate_pass(cin, cout, n, h, w, monkeypatch):
+@pytest.mark.parametrize('cin,cout,n,h,w,conv_act,k,stride,big', [
+    (64, 128, 2, 16, 32, 0, 3, 1, None), (128, 256, 3, 11, 70, 0, 3, 1, None),
+    (64, 128, 2, 16, 32, 2, 3, 1, None),          # activation fused into the conv
+    (64, 256, 2, 16, 40, 0, 1, 1, '1'),           # 1x1 on the 256-pixel macro tile (ragged last tile)
+    (128, 256, 3, 9, 30, 0, 1, 1, '0'),           # 1x1 on the 128 x 128 tile
+    (64, 128, 2, 17, 33, 1, 3, 2, '0'),           # strided 3x3, relu fused
+])
+def test_fused_bn_statistics_match_separate_pass(cin, cout, n, h, w, conv_act, k, stride, big,
+                                                 monkeypatch):
   """conv -> SyncBatchNormalization: the column sums emitted by the conv epilogue must give the
   same normalised output / moving statistics as the separate statistics pass."""
+  if big is not None:
+    monkeypatch.setenv('SE3DS_BIG_TILE', big)
   res = {}
-  for mode in ('0', '1'):
+  for mode in ('0', '2'):
     monkeypatch.setenv('SE3DS_FUSED_BN_STATS', mode)
     store = nn.ParamStore()
-    conv = nn.ConvLayer(store, 'c', cin, cout, 3, 1, 'VALID', True, 'plain')
+    conv = nn.ConvLayer(store, 'c', cin, cout, k, stride, 'VALID', True, 'plain')
     bn = nn.NormLayer(store, 'n', cout, 'batch')
     store.finalize(DEV, torch.Generator().manual_seed(3))
     ctx = nn.Ctx(DEV, torch.bfloat16, training=True, record=True)
     x = nn.Var(torch.randn((n, h, w, cin), generator=torch.Generator().manual_seed(4)).to(DEV).bfloat16())
-    y = nn.conv2d(ctx, x, conv, pad=1)
-    assert (y.col_stats is not None) == (mode == '1')
+    y = nn.conv2d(ctx, x, conv, pad=k // 2, act=conv_act, alpha=0.3)
+    assert (y.col_stats is not None) == (mode == '2')
     z = nn.norm_act(ctx, y, bn, act=2, alpha=0.2)
     z.grad = torch.ones_like(z.data)
     ctx.backward()
     res[mode] = (z.data.float().cpu().numpy(), store['n/moving_mean'].cpu().numpy().copy(),
                  store['n/moving_variance'].cpu().numpy().copy(), x.grad.float().cpu().numpy())
   # fp32 statistics agree to summation-order noise; bf16 tensors to a rounding step
-  assert rel_err(res['0'][1], res['1'][1]) < 1e-4 and rel_err(res['0'][2], res['1'][2]) < 1e-4
-  assert rel_err(res['0'][0], res['1'][0]) < tol(torch.bfloat16)
-  assert rel_err(res['0'][3], res['1'][3]) < tol(torch.bfloat16)
+  assert rel_err(res['0'][1], res['2'][1]) < 1e-4 and rel_err(res['0'][2], res['2'][2]) < 1e-4
+  assert rel_err(res['0'][0], res['2'][0]) < tol(torch.bfloat16)
+  assert rel_err(res['0'][3], res['2'][3]) < tol(torch.bfloat16)
 
 
 def test_checkpoint_resume_is_bit_exact(tmp_path):
