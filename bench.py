@@ -65,11 +65,33 @@ def _max_over_ranks(x, world, dev):
 
 
 # ----------------------------------------------------------------------------- warp workload
-def _warp_inputs(rng, h, w, views, dev):
+def _room_depth(rng, h, w, pos):
+  """Depth of a 9 x 7 x 3 m box room seen from `pos` (metres / 20), half-pixel-centre equirect
+  grid as pano_utils.py:211-218, plus 1 cm noise: a smooth map like real scans."""
+  hp = 0.5 * np.pi / h
+  el = np.linspace(hp, np.pi - hp, h)[:, None]
+  hd = np.linspace(1.5 * np.pi - hp, -0.5 * np.pi + hp, w)[None, :]
+  d = np.stack([np.sin(el) * np.cos(hd), np.sin(el) * np.sin(hd), np.cos(el) * np.ones_like(hd)])
+  lo = np.array([-4.5, -3.5, -1.5])[:, None, None] - pos.reshape(3, 1, 1)
+  hi = np.array([4.5, 3.5, 1.5])[:, None, None] - pos.reshape(3, 1, 1)
+  with np.errstate(divide='ignore', invalid='ignore'):
+    t = np.where(d > 0, hi / d, np.where(d < 0, lo / d, np.inf))
+  dist = t.min(0) + rng.normal(0, 0.01, (h, w))
+  return (dist / 20.0).astype(np.float32)[None]
+
+
+def _warp_inputs(rng, h, w, views, dev, depth_kind='random'):
   panos = []
   for _ in range(views):
     rgb = rng.integers(0, 256, (1, h, w, 3)).astype(np.int32)
     depth = rng.uniform(0, 1, (1, h, w)).astype(np.float32)
+    if depth_kind == 'room':
+      pos = (rng.standard_normal((1, 3)) * 0.5).astype(np.float32)
+      depth = _room_depth(rng, h, w, pos[0].astype(np.float64))
+      poison = rng.uniform(0, 1, (1, h, w))
+      depth[poison < 0.02] = 0.0
+      panos.append((rgb, depth, pos))
+      continue
     poison = rng.uniform(0, 1, (1, h, w))
     depth[poison < 0.02] = 0.0
     depth[poison > 0.99] = 1.0
@@ -83,7 +105,7 @@ def bench_warp(args, rank, world, dev):
   from se3ds_amd.utils import pano_utils
   h, w, views = args.warp_height, 2 * args.warp_height, 2
   rng = np.random.default_rng(1234 + rank)
-  panos, target = _warp_inputs(rng, h, w, views, dev)
+  panos, target = _warp_inputs(rng, h, w, views, dev, args.warp_depth)
   g = [(torch.from_numpy(r).to(dev), torch.from_numpy(d).to(dev), torch.from_numpy(p).to(dev))
        for r, d, p in panos]
   tgt = torch.from_numpy(target).to(dev)
@@ -131,7 +153,8 @@ def bench_warp(args, rank, world, dev):
       'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
       'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
       'data': 'synthetic',
-      'config': {'workload': f'warp cfg5 {h}x{w} V={views} (replicas only)'},
+      'config': {'workload': f'warp cfg5 {h}x{w} V={views} (replicas only)' +
+                             ('' if args.warp_depth == 'random' else f', {args.warp_depth} depth')},
       'roofline': {'bound': 'hbm', 'kernel': 'project+splat (chunk count, column scan, scatter, per-tile resolve)',
                    'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                    'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
@@ -175,6 +198,9 @@ def main():
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--workload', default=None, choices=['gan_step', 'warp'])
   ap.add_argument('--warp-height', type=int, default=1024)
+  ap.add_argument('--warp-depth', default='random', choices=['random', 'room'],
+                  help='random: independent depth per pixel (worst case for the splat, default); '
+                       'room: smooth box-room depth like a real scan')
   ap.add_argument('--batch', type=int, default=0, help='per-GPU batch for gan_step (0 = auto)')
   ap.add_argument('--image-size', type=int, default=512)
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
