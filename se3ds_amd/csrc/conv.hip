@@ -2047,6 +2047,120 @@ wgrad_swap_fixup_kernel(const float* __restrict__ tmp, int k, int cin, int cout,
   }
 }
 
+// ------------------------------------------------------------------ thin-Cout 3x3 forward
+// Stride-1 3x3 convolutions onto <= 4 output channels (the generator's RGB / depth heads at full
+// resolution): 1 GB of input and 10-30 GFLOP of real work per call, HBM bound.  Through the
+// 128-channel MFMA tiles they ran at 1.75 ms (42x padded FLOPs).  Here a workgroup stages the
+// (4+2) x (32+2) pixel input patch of a 4 x 32 output tile in LDS once (all Cin channels), the
+// <= 4 weight rows next to it, and each of its 4 waves runs one output row through 32x32x16
+// MFMAs whose A operand has only those rows populated: 9 * Cin / 16 MFMAs per wave, patch
+// overhead 1.6x (mostly L2 hits), two workgroups per CU so that one fills while the other
+// computes.
+constexpr int kThinRows = 4, kThinCols = 32, kThinPH = kThinRows + 2, kThinPW = kThinCols + 2;
+__host__ __device__ inline int thin_pixel_bytes(int cin) { return cin * 2 + 16; }
+__host__ __device__ inline int thin_weight_bytes(int cin) { return 9 * cin * 2 + 16; }
+__host__ __device__ inline size_t thin_lds_bytes(int cin, int cout) {
+  return (size_t)kThinPH * kThinPW * thin_pixel_bytes(cin) + (size_t)cout * thin_weight_bytes(cin);
+}
+
+__global__ void __launch_bounds__(256)
+thin_cout_fwd_kernel(const IgemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char t_smem[];
+  const int C = p.sC, K = 9 * C;
+  const int pstride = thin_pixel_bytes(C), wstride = thin_weight_bytes(C);
+  unsigned char* xs = t_smem;                                    // [PH * PW][pstride]
+  unsigned char* ws = t_smem + kThinPH * kThinPW * pstride;      // [oC][wstride]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int tiles_x = ceil_div(p.oW, kThinCols), tiles_y = ceil_div(p.oH, kThinRows);
+  int b = blockIdx.x;
+  const int tx = b % tiles_x;
+  b /= tiles_x;
+  const int ty = b % tiles_y, n = b / tiles_y;
+  const int oy0 = ty * kThinRows, ox0 = tx * kThinCols;
+  const uint16_t* __restrict__ src = (const uint16_t*)p.src;
+  {
+    const uint16_t* __restrict__ w = (const uint16_t*)p.w;   // wt [oC][K]
+    const int chunks = K / 8;
+    for (int i = tid; i < p.oC * chunks; i += 256) {
+      const int co = i / chunks, c = i - co * chunks;
+      *reinterpret_cast<uint4*>(ws + co * wstride + c * 16) =
+          *reinterpret_cast<const uint4*>(w + (int64_t)co * K + c * 8);
+    }
+  }
+  {
+    const int cpp = C / 8;   // 16-byte chunks per pixel
+    const int total = kThinPH * kThinPW * cpp;
+    constexpr int kB = 4;    // loads in flight per thread
+    for (int i0 = tid; i0 < total; i0 += kB * 256) {
+      uint4 v[kB];
+      int dst[kB];
+#pragma unroll
+      for (int u = 0; u < kB; ++u) {
+        const int i = i0 + u * 256;
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        dst[u] = -1;
+        if (i < total) {
+          const int pix = i / cpp, c = i - pix * cpp;
+          const int r = pix / kThinPW, q = pix - r * kThinPW;
+          const int sy = oy0 - p.pad_t + r;
+          int sx = ox0 - p.pad_l + q;
+          if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+          dst[u] = pix * pstride + c * 16;
+          if (sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW)
+            v[u] = *reinterpret_cast<const uint4*>(
+                src + (((int64_t)n * p.sH + sy) * p.sW + sx) * C + c * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kB; ++u)
+        if (dst[u] >= 0) *reinterpret_cast<uint4*>(xs + dst[u]) = v[u];
+    }
+  }
+  __syncthreads();
+  f32x16_t acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int kc_n = C / 16;
+  const bool wrow_ok = l32 < p.oC;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const unsigned char* xrow = xs + ((wave + ky) * kThinPW + l32 + kx) * pstride + half * 16;
+    const unsigned char* wrow = ws + (wrow_ok ? l32 : 0) * wstride + tap * C * 2 + half * 16;
+    for (int kc = 0; kc < kc_n; kc += 4) {   // Cin % 64 == 0: four fragments per trip
+      uint4 xf[4], wf[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xf[u] = *reinterpret_cast<const uint4*>(xrow + (kc + u) * 32);
+        wf[u] = *reinterpret_cast<const uint4*>(wrow + (kc + u) * 32);
+        if (!wrow_ok) wf[u] = make_uint4(0u, 0u, 0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf[u]),
+                                                      __builtin_bit_cast(bf16x8_t, xf[u]), acc, 0,
+                                                      0, 0);
+    }
+  }
+  // lanes 0..31 hold output channels 0..3 of pixel (oy0 + wave, ox0 + l32) in acc[0..3]
+  const int oy = oy0 + wave, ox = ox0 + l32;
+  if (half == 0 && oy < p.oH && ox < p.oW) {
+    const float scale = p.scale ? *p.scale : 1.0f;
+    uint16_t* out = (uint16_t*)p.out + (((int64_t)n * p.oH + oy) * p.oW + ox) * p.oC;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (c < p.oC) {
+        float t = acc[c] * scale;
+        if (p.bias) t = t + p.bias[c];
+        if (p.act == 1) t = t > 0.f ? t : 0.f;
+        else if (p.act == 2) t = t > 0.f ? t : t * p.act_alpha;
+        out[c] = f32_to_bf16(t);
+      }
+  }
+}
+
 // ------------------------------------------------------------------------ weight prep
 // fp32 master HWIO [K][Cout] -> compute-dtype copies: wt [Cout][K] (forward operand) and,
 // optionally, wn [K][Cout] (input-gradient operand).  32x32 LDS-tiled transpose.
@@ -2213,6 +2327,21 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       !(mode == MODE_FWD && fwd_stats_rows(p, dtype, stride, kh, kw, glds) > 0))
     return SE3DS_E_UNSUPPORTED;   // callers ask se3ds_conv2d_fwd_stats_rows first
   p.stats = mode == MODE_FWD ? stats : nullptr;
+  if (mode == MODE_FWD && dtype == SE3DS_BF16 && kh == 3 && kw == 3 && stride == 1 && cout <= 4 &&
+      (cin % 64) == 0 && cin <= 256 && src_mask == nullptr && row_a == nullptr &&
+      stats == nullptr && addend == nullptr && !getenv("SE3DS_NO_THIN_FWD")) {
+    const size_t lds = thin_lds_bytes(cin, cout);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      if (hipFuncSetAttribute((const void*)thin_cout_fwd_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SE3DS_E_LAUNCH;
+      lds_set = lds;
+    }
+    const int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinRows) * ceil_div(p.oW, kThinCols);
+    hipLaunchKernelGGL(thin_cout_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds, s, p);
+    return check_launch("conv2d_fwd(thin)");
+  }
   if (glds && dtype == SE3DS_BF16 && stride == 1 && kh == 3 && kw == 3) {
     const int co = halo_tile_channels(p);
     if (co) {

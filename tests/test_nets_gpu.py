@@ -84,6 +84,20 @@ BIG_TILE_CASES = [
 ]
 
 
+# the generator's heads: 3x3 onto <= 4 channels (thin_cout_fwd_kernel; thin weight gradients)
+THIN_CASES = [
+    ('spectral', 128, 3, 3, 1, 'VALID', 1, False, True, False, 2, 12, 64),
+    ('spectral', 128, 1, 3, 1, 'VALID', 1, False, True, False, 2, 9, 37),     # ragged tiles
+    ('plain', 64, 3, 3, 1, 'VALID', 1, True, False, False, 1, 16, 32),        # circular width
+    ('plain', 256, 4, 3, 1, 'SAME', 0, False, True, False, 1, 7, 45),         # SAME padding, 4 rows
+]
+
+
+@pytest.mark.parametrize('case', THIN_CASES)
+def test_conv_thin_cout(case):
+  _run_conv_case(case, torch.bfloat16)
+
+
 @pytest.mark.parametrize('halo', ['0', '1'])
 @pytest.mark.parametrize('case', BIG_TILE_CASES)
 def test_conv_macro_tile_fwd_bwd(case, halo, monkeypatch):
