@@ -2047,6 +2047,136 @@ wgrad_swap_fixup_kernel(const float* __restrict__ tmp, int k, int cin, int cout,
   }
 }
 
+// ------------------------------------------------------------------ thin-Cout 3x3 data gradient
+// dx (Cin channels) from dy with <= 4 channels: K = 9 * Cout <= 36 reduction elements per output,
+// 1 GB of dx to write per call -- store bound.  A workgroup covers 8 rows x 32 columns; the dy
+// patch (10 x 34 pixels x Cout) and the transposed weights W'[ci][tap * Cout + co] sit in LDS,
+// each wave builds the im2col fragments of its two rows element by element (16-bit LDS reads,
+// a few dozen per lane) and writes through the LDS-transposed full-line epilogue.
+constexpr int kThinDRows = 8, kThinCols = 32;
+template <int NI>
+__global__ void __launch_bounds__(256)
+thin_cout_dgrad_kernel(const IgemmParams p) {
+  constexpr int PH = kThinDRows + 2, PW = kThinCols + 2, KP = 48;   // K padded to 3 MFMA steps
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[4][kEpiScratch<NI>];
+  __shared__ __attribute__((aligned(16))) uint16_t dys[PH * PW * 4];
+  __shared__ __attribute__((aligned(16))) uint16_t wk[NI * 32][KP + 8];   // (+8: bank spread)
+  __shared__ int16_t koff[KP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int Co = p.sC, Ci = p.oC, K = 9 * Co;
+  const int tiles_x = ceil_div(p.oW, kThinCols), tiles_y = ceil_div(p.oH, kThinDRows);
+  const int64_t n_tiles = (int64_t)p.N * tiles_y * tiles_x;
+  const uint16_t* __restrict__ dy = (const uint16_t*)p.src;
+  const uint16_t* __restrict__ wn = (const uint16_t*)p.w;   // wn [(tap * Ci + ci)][Co]
+  // element k = tap * Co + co reads the patch at (y + 2 - ky, x + 2 - kx, co)
+  if (tid < KP) {
+    int o = -1;
+    if (tid < K) {
+      const int tap = tid / Co, co = tid - tap * Co;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      o = ((2 - ky) * PW + (2 - kx)) * Co + co;
+    }
+    koff[tid] = (int16_t)o;
+  }
+  // W'[ci][k] of channel group g (zero beyond K); persistent workgroups build it once when the
+  // layer has a single group
+  auto load_weights = [&](int g) {
+    for (int i = tid; i < NI * 32 * KP; i += 256) {
+      const int ci = i / KP, k = i - ci * KP;
+      uint16_t v = 0;
+      if (k < K) {
+        const int tap = k / Co, co = k - tap * Co;
+        v = wn[((int64_t)tap * Ci + g + ci) * Co + co];
+      }
+      wk[ci][k] = v;
+    }
+  };
+  const bool one_group = Ci == NI * 32;
+  if (one_group) load_weights(0);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  int64_t b = tile;
+  const int tx = (int)(b % tiles_x);
+  b /= tiles_x;
+  const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
+  const int oy0 = ty * kThinDRows, ox0 = tx * kThinCols;
+  __syncthreads();   // the previous tile's patch is consumed
+  // dy patch: row r <-> sy = oy0 + pad_t - 2 + r, column q <-> sx = ox0 + pad_l - 2 + q
+  {
+    constexpr int kB = 4;
+    const int total = PH * PW * Co;
+    for (int i0 = tid; i0 < total; i0 += kB * 256) {
+      uint16_t v[kB];
+#pragma unroll
+      for (int u = 0; u < kB; ++u) {
+        const int i = i0 + u * 256;
+        v[u] = 0;
+        if (i < total) {
+          const int pix = i / Co, c = i - pix * Co;
+          const int r = pix / PW, q = pix - r * PW;
+          const int sy = oy0 + p.pad_t - 2 + r;
+          int sx = ox0 + p.pad_l - 2 + q;
+          if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+          if (sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW)
+            v[u] = dy[(((int64_t)n * p.sH + sy) * p.sW + sx) * Co + c];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kB; ++u)
+        if (i0 + u * 256 < total) dys[i0 + u * 256] = v[u];
+    }
+  }
+  for (int g = 0; g < Ci; g += NI * 32) {
+    if (!one_group) {
+      __syncthreads();   // (previous group's fragments are consumed)
+      load_weights(g);
+    }
+    __syncthreads();
+    f32x16_t acc[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KP / 16; ++ks) {
+      if (ks * 16 >= K) break;
+      uint4 xf[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int base = ((wave * 2 + j) * PW + l32) * Co;
+        uint16_t e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int o = koff[ks * 16 + half * 8 + q];
+          e[q] = o >= 0 ? dys[base + o] : (uint16_t)0;
+        }
+        xf[j] = make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                           (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const uint4 wf = *reinterpret_cast<const uint4*>(&wk[i * 32 + l32][ks * 16 + half * 8]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
+                                                              __builtin_bit_cast(bf16x8_t, xf[j]),
+                                                              acc[i][j], 0, 0, 0);
+      }
+    }
+    int64_t opix[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int oy = oy0 + wave * 2 + j, ox = ox0 + l32;
+      opix[j] = (oy < p.oH && ox < p.oW) ? ((int64_t)n * p.oH + oy) * p.oW + ox : -1;
+    }
+    store_wave_lds<NI>(p, acc, opix, g, lane, scratch[wave]);
+  }
+  }
+}
+
 // ------------------------------------------------------------------ thin-Cout 3x3 forward
 // Stride-1 3x3 convolutions onto <= 4 output channels (the generator's RGB / depth heads at full
 // resolution): 1 GB of input and 10-30 GFLOP of real work per call, HBM bound.  Through the
@@ -2056,7 +2186,7 @@ wgrad_swap_fixup_kernel(const float* __restrict__ tmp, int k, int cin, int cout,
 // MFMAs whose A operand has only those rows populated: 9 * Cin / 16 MFMAs per wave, patch
 // overhead 1.6x (mostly L2 hits), two workgroups per CU so that one fills while the other
 // computes.
-constexpr int kThinRows = 4, kThinCols = 32, kThinPH = kThinRows + 2, kThinPW = kThinCols + 2;
+constexpr int kThinRows = 4, kThinPH = kThinRows + 2, kThinPW = kThinCols + 2;
 __host__ __device__ inline int thin_pixel_bytes(int cin) { return cin * 2 + 16; }
 __host__ __device__ inline int thin_weight_bytes(int cin) { return 9 * cin * 2 + 16; }
 __host__ __device__ inline size_t thin_lds_bytes(int cin, int cout) {
@@ -2327,6 +2457,17 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       !(mode == MODE_FWD && fwd_stats_rows(p, dtype, stride, kh, kw, glds) > 0))
     return SE3DS_E_UNSUPPORTED;   // callers ask se3ds_conv2d_fwd_stats_rows first
   p.stats = mode == MODE_FWD ? stats : nullptr;
+  if (mode == MODE_DGRAD && dtype == SE3DS_BF16 && kh == 3 && kw == 3 && stride == 1 && cout <= 4 &&
+      (cin % 64) == 0 && src_mask == nullptr && row_a == nullptr &&
+      !getenv("SE3DS_NO_THIN_DGRAD")) {
+    int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinDRows) * ceil_div(p.oW, kThinCols);
+    if (blocks > 3 * 256) blocks = 3 * 256;   // persistent: three workgroups per CU
+    if ((cin % 128) == 0)
+      hipLaunchKernelGGL(thin_cout_dgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL(thin_cout_dgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return check_launch("conv2d_dgrad(thin)");
+  }
   if (mode == MODE_FWD && dtype == SE3DS_BF16 && kh == 3 && kw == 3 && stride == 1 && cout <= 4 &&
       (cin % 64) == 0 && cin <= 256 && src_mask == nullptr && row_a == nullptr &&
       stats == nullptr && addend == nullptr && !getenv("SE3DS_NO_THIN_FWD")) {
