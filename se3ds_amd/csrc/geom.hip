@@ -405,31 +405,55 @@ __host__ __device__ inline ChunkGeom chunk_geom(int64_t m, int n) {
   return g;
 }
 
+constexpr uint32_t kSliceRecords = 8192;   // records per band workgroup aimed at
+__host__ __device__ inline int tile_bands_log2(uint32_t count, uint32_t slice_records) {
+  int lg = 0;
+  while (lg < 3 && ((uint64_t)slice_records << lg) < count) ++lg;
+  return lg;
+}
+// upper bound of the resolve items: every tile has one band, and a tile with c > slice_records
+// records has a power of two < 2 c / slice_records + 1 < 3 c / slice_records of them
+__host__ __device__ inline int64_t resolve_items_max(int64_t nb, int64_t points, uint32_t slice_records) {
+  return nb + 3 * ((points + slice_records - 1) / slice_records);
+}
+// (SE3DS_SPLAT_SLICE overrides the slice size: the parity tests use small slices to exercise
+// banded tiles on small images)
+inline uint32_t slice_records() {
+  static const uint32_t v = [] {
+    const char* e = getenv("SE3DS_SPLAT_SLICE");
+    const long x = e ? atol(e) : 0;
+    return (uint32_t)(x >= 16 ? x : (long)kSliceRecords);
+  }();
+  return v;
+}
+
 struct BinWs {
   uint32_t* tile_count;   // [nb]
   uint32_t* hist;         // [n][chunks][ntiles]: counts, then exclusive prefix over the chunks
-  uint32_t* fpart2;       // [nb][C] sink partials of the occluded points, per tile
+  uint32_t* fpart2;       // [items][C] sink partials of the occluded points, per resolve item
   uint32_t* rec;          // [N*M][2 + C]: pixel inside the tile, z bits, feature bits
 };
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) / 16 * 16; }
-__host__ __device__ inline size_t bin_ws_bytes(int n, int64_t m, int height, int width, int channels) {
+inline size_t bin_ws_bytes(int n, int64_t m, int height, int width, int channels) {
   const size_t ntiles = (size_t)ceil_div(height, kTileY) * ceil_div(width, kTileX);
   const size_t nb = (size_t)n * ntiles;
   const size_t pts = (size_t)n * (size_t)(m > 0 ? m : 0);
   const size_t chunks = (size_t)chunk_geom(m, n).chunks;
+  const size_t items = (size_t)resolve_items_max((int64_t)nb, (int64_t)pts, slice_records());
   return align16(4 * nb) + align16(4 * nb * chunks) +
-         align16(4 * nb * channels) + align16(4 * pts * (2 + channels));
+         align16(4 * items * channels) + align16(4 * pts * (2 + channels));
 }
-__host__ __device__ inline BinWs carve_bin_ws(void* base, int n, int64_t m, int height, int width,
-                                             int channels) {
+inline BinWs carve_bin_ws(void* base, int n, int64_t m, int height, int width, int channels) {
   const size_t ntiles = (size_t)ceil_div(height, kTileY) * ceil_div(width, kTileX);
   const size_t nb = (size_t)n * ntiles;
   const size_t chunks = (size_t)chunk_geom(m, n).chunks;
+  const size_t items = (size_t)resolve_items_max(
+      (int64_t)nb, (int64_t)n * (m > 0 ? m : 0), slice_records());
   char* p = (char*)base;
   BinWs w;
   w.tile_count = (uint32_t*)p; p += align16(4 * nb);
   w.hist = (uint32_t*)p; p += align16(4 * nb * chunks);
-  w.fpart2 = (uint32_t*)p; p += align16(4 * nb * channels);
+  w.fpart2 = (uint32_t*)p; p += align16(4 * items * channels);
   w.rec = (uint32_t*)p;
   return w;
 }
@@ -725,26 +749,64 @@ constexpr int kStash = 8;
 constexpr int kStashChannels = 3;
 template <bool ORDERED, int SC>
 __global__ void __launch_bounds__(kResolveThreads)
-splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int tiles_x,
-                          float depth_scale, float output_void, float mask_void,
-                          float* __restrict__ depth, float* __restrict__ feat,
+splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int tiles_x, int nb,
+                          uint32_t slice_records, float depth_scale, float output_void,
+                          float mask_void, float* __restrict__ depth, float* __restrict__ feat,
                           float* __restrict__ mask, SplatWs ws, BinWs bw, uint32_t zpart_count) {
   extern __shared__ uint32_t s_tile[];   // z[kTilePx], feat[channels][kTilePx]
   uint32_t* s_z = s_tile;
   uint32_t* s_fe = s_tile + kTilePx;
-  const int bt = blockIdx.x;
+  __shared__ uint32_t s_w[kResolveThreads / 64];
+  __shared__ int s_item[3];      // tile, band, log2(bands of the tile)
+  __shared__ uint32_t s_r0;
+  // Work items: a tile with many records (a surface seen from farther away compresses into few
+  // target pixels; 14x the mean was measured on a smooth depth map) is cut into 2 / 4 / 8 bands
+  // of rows.  Every band workgroup reads all records of the tile and keeps the ones of its rows,
+  // so bands never exchange anything.  item -> (tile, band) by a scan of the bands per tile.
+  const uint32_t item = blockIdx.x;
+  if (threadIdx.x == 0) s_item[0] = -1;
+  {
+    const int per = ceil_div(nb, kResolveThreads);
+    const int t0 = threadIdx.x * per, t1 = t0 + per < nb ? t0 + per : nb;
+    uint32_t sum_s = 0, sum_c = 0;
+    for (int t = t0; t < t1; ++t) {
+      const uint32_t c = bw.tile_count[t];
+      sum_s += 1u << tile_bands_log2(c, slice_records);
+      sum_c += c;
+    }
+    uint32_t tot;
+    uint32_t run_s = block_excl_scan_u32<kResolveThreads / 64>(sum_s, s_w, &tot);
+    uint32_t run_c = block_excl_scan_u32<kResolveThreads / 64>(sum_c, s_w, &tot);
+    if (item >= run_s && item < run_s + sum_s) {
+      for (int t = t0; t < t1; ++t) {
+        const uint32_t c = bw.tile_count[t];
+        const int lg = tile_bands_log2(c, slice_records);
+        if (item < run_s + (1u << lg)) {
+          s_item[0] = t;
+          s_item[1] = (int)(item - run_s);
+          s_item[2] = lg;
+          s_r0 = run_c;
+          break;
+        }
+        run_s += 1u << lg;
+        run_c += c;
+      }
+    }
+  }
+  __syncthreads();
+  const int bt = s_item[0];
+  if (bt < 0) {   // beyond the last item: this row of the sink partials must still be defined
+    if ((int)threadIdx.x < channels) bw.fpart2[(int64_t)item * channels + threadIdx.x] = 0u;
+    return;
+  }
+  const int band = s_item[1], band_shift = 4 - s_item[2];   // rows per band = 16 >> log2(bands)
+  const bool banded = s_item[2] != 0;
+  const uint32_t r0 = s_r0, r1 = r0 + bw.tile_count[bt];
   const int b = bt / ntiles, t = bt - b * ntiles;
   const int ty = t / tiles_x, tx = t - ty * tiles_x;
   const uint32_t fvoid = se3ds_f32_to_ordered(output_void);
-  __shared__ uint32_t s_w[kResolveThreads / 64];
-  uint32_t r0, r1;   // record range of the tile = prefix of the tile totals
-  {
-    uint32_t part = 0;
-    for (int i = threadIdx.x; i < bt; i += kResolveThreads) part += bw.tile_count[i];
-    (void)block_excl_scan_u32<kResolveThreads / 64>(part, s_w, &r0);
-    r1 = r0 + bw.tile_count[bt];
-  }
-  const bool first = bt == 0;   // holds flat pixel 0, which also receives the sink
+  auto mine = [&](uint32_t li) { return !banded || (int)((li >> 7) >> band_shift) == band; };
+  const bool first = bt == 0 && band == 0;   // holds flat pixel 0, which also receives the sink
   uint32_t sink_o = 0xffffffffu;   // min z of the invalid points (all chunks, all images)
   if (first) {
     uint32_t v = 0xffffffffu;
@@ -782,7 +844,7 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u)
-        if (r0 + threadIdx.x + (k0 + u) * kResolveThreads < r1)
+        if (r0 + threadIdx.x + (k0 + u) * kResolveThreads < r1 && mine(st_li[k0 + u]))
           atomicMin(&s_z[st_li[k0 + u]], st_z[k0 + u]);
     }
   }
@@ -798,7 +860,7 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u)
-      if (q0 + u * kResolveThreads < r1) atomicMin(&s_z[li[u]], zb[u]);   // valid => z > 0
+      if (q0 + u * kResolveThreads < r1 && mine(li[u])) atomicMin(&s_z[li[u]], zb[u]);   // valid => z > 0
   }
   __syncthreads();
   constexpr int kMaxC = kMaxBinChannels;
@@ -808,7 +870,7 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
   if (SC > 0) {
 #pragma unroll
     for (int k0 = 0; k0 < NS; ++k0) {
-      if (r0 + threadIdx.x + k0 * kResolveThreads >= r1) continue;
+      if (r0 + threadIdx.x + k0 * kResolveThreads >= r1 || !mine(st_li[k0])) continue;
       const uint32_t li = st_li[k0];
       const float z = __uint_as_float(st_z[k0]);
       float zm = __uint_as_float(s_z[li]);
@@ -841,7 +903,7 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
     }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
-      if (q0 + u * kResolveThreads >= r1) continue;
+      if (q0 + u * kResolveThreads >= r1 || !mine(li[u])) continue;
       const float z = __uint_as_float(zb[u]);
       float zm = __uint_as_float(s_z[li[u]]);
       if (first && li[u] == 0 && have_sink_z) zm = sink_z < zm ? sink_z : zm;
@@ -870,13 +932,13 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
   if ((int)threadIdx.x < channels) {
     uint32_t v = 0u;
     for (int i = 0; i < kResolveThreads / 64; ++i) v = s_f[threadIdx.x][i] > v ? s_f[threadIdx.x][i] : v;
-    bw.fpart2[(int64_t)bt * channels + threadIdx.x] = v;
+    bw.fpart2[(int64_t)item * channels + threadIdx.x] = v;
   }
   // finalize (pixel 0's feature / mask fold of the sink happens in splat_sink_feat2_kernel)
   const int64_t hw = (int64_t)height * width;
   for (int p = threadIdx.x; p < kTilePx; p += kResolveThreads) {
     const int y = ty * kTileY + p / kTileX, x = tx * kTileX + (p % kTileX);
-    if (y >= height || x >= width) continue;
+    if (y >= height || x >= width || !mine((uint32_t)p)) continue;
     const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
     float z = __uint_as_float(s_z[p]);
     if (i == 0 && have_sink_z) z = sink_z < z ? sink_z : z;
@@ -958,10 +1020,13 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
   hipLaunchKernelGGL((splat_bin_scatter_kernel<T>), g_pt, dim3(kChunkThreads), 4 * ntiles, stream,
                      feats, m, cg.per, channels, width, wmagic, ntiles, tiles_x, ws, bw);
   const size_t tile_lds = 4 * (size_t)kTilePx * (1 + channels);
+  const uint32_t slice = slice_records();
+  const int items = (int)resolve_items_max(nb, (int64_t)n * m, slice);
 #define SE3DS_RESOLVE(ORD, SC)                                                                   \
-  hipLaunchKernelGGL((splat_tile_resolve_kernel<ORD, SC>), dim3(nb), dim3(kResolveThreads),      \
-                     tile_lds, stream, channels, height, width, ntiles, tiles_x, depth_scale,    \
-                     output_void, mask_void, depth, feat, mask, ws, bw, (uint32_t)nparts)
+  hipLaunchKernelGGL((splat_tile_resolve_kernel<ORD, SC>), dim3(items), dim3(kResolveThreads),   \
+                     tile_lds, stream, channels, height, width, ntiles, tiles_x, nb, slice,      \
+                     depth_scale, output_void, mask_void, depth, feat, mask, ws, bw,             \
+                     (uint32_t)nparts)
   static const bool no_stash = getenv("SE3DS_RESOLVE_NOSTASH") != nullptr;
   if (channels <= kStashChannels && !no_stash) {
     if (ordered) SE3DS_RESOLVE(true, kStashChannels); else SE3DS_RESOLVE(false, kStashChannels);
@@ -969,8 +1034,8 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
     if (ordered) SE3DS_RESOLVE(true, 0); else SE3DS_RESOLVE(false, 0);
   }
 #undef SE3DS_RESOLVE
-  hipLaunchKernelGGL(splat_sink_feat2_kernel, dim3(1), dim3(kBlock), 0, stream, ws, bw, nparts, nb,
-                     channels, depth, feat, mask, mask_void);
+  hipLaunchKernelGGL(splat_sink_feat2_kernel, dim3(1), dim3(kBlock), 0, stream, ws, bw, nparts,
+                     items, channels, depth, feat, mask, mask_void);
   return check_launch("splat(binned)");
 }
 

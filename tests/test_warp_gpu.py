@@ -295,3 +295,19 @@ def test_bilinear_and_resampling_paths():
   e_o = warp_np.get_perspective_from_equirectangular_image(pano[0], K, mats[0], 24, 24)
   e_g = pano_utils.get_perspective_from_equirectangular_image(t(pano[0]), K, mats[0], 24, 24)
   assert (np.abs(e_g.cpu().numpy() - e_o).max(-1) <= 1e-4).mean() > 0.995
+
+
+def test_splat_banded_tiles_bit_exact():
+  """Tiles with many records are cut into bands of rows (splat_tile_resolve_kernel); with a tiny
+  slice size every tile of the small parity images is banded.  The switch is read once per
+  process, so the splat parity tests are re-run in a child process."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, SE3DS_SPLAT_SLICE='48', PYTHONPATH=root)
+  env.pop('SE3DS_SPLAT_SCATTER', None)
+  r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_warp_gpu.py'),
+                      '-q', '-x', '-m', 'gpu', '-k', 'project and not banded'],
+                     env=env, cwd=root, capture_output=True, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+  assert ' passed' in r.stdout
