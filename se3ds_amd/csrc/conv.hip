@@ -2054,13 +2054,14 @@ wgrad_swap_fixup_kernel(const float* __restrict__ tmp, int k, int cin, int cout,
 // each wave builds the im2col fragments of its two rows element by element (16-bit LDS reads,
 // a few dozen per lane) and writes through the LDS-transposed full-line epilogue.
 constexpr int kThinDRows = 8, kThinCols = 32;
-template <int NI>
+constexpr int kThinDCinMax = 256;
 __global__ void __launch_bounds__(256)
 thin_cout_dgrad_kernel(const IgemmParams p) {
+  constexpr int NI = 2;   // 64 output channels per pass (keeps three workgroups on a CU)
   constexpr int PH = kThinDRows + 2, PW = kThinCols + 2, KP = 48;   // K padded to 3 MFMA steps
   __shared__ __attribute__((aligned(16))) unsigned char scratch[4][kEpiScratch<NI>];
   __shared__ __attribute__((aligned(16))) uint16_t dys[PH * PW * 4];
-  __shared__ __attribute__((aligned(16))) uint16_t wk[NI * 32][KP + 8];   // (+8: bank spread)
+  __shared__ __attribute__((aligned(16))) uint16_t wk[kThinDCinMax][KP + 8];   // (+8: bank spread)
   __shared__ int16_t koff[KP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2080,21 +2081,16 @@ thin_cout_dgrad_kernel(const IgemmParams p) {
     }
     koff[tid] = (int16_t)o;
   }
-  // W'[ci][k] of channel group g (zero beyond K); persistent workgroups build it once when the
-  // layer has a single group
-  auto load_weights = [&](int g) {
-    for (int i = tid; i < NI * 32 * KP; i += 256) {
-      const int ci = i / KP, k = i - ci * KP;
-      uint16_t v = 0;
-      if (k < K) {
-        const int tap = k / Co, co = k - tap * Co;
-        v = wn[((int64_t)tap * Ci + g + ci) * Co + co];
-      }
-      wk[ci][k] = v;
+  // W'[ci][k] for every output channel (zero beyond K), loaded once per persistent workgroup
+  for (int i = tid; i < Ci * KP; i += 256) {
+    const int ci = i / KP, k = i - ci * KP;
+    uint16_t v = 0;
+    if (k < K) {
+      const int tap = k / Co, co = k - tap * Co;
+      v = wn[((int64_t)tap * Ci + ci) * Co + co];
     }
-  };
-  const bool one_group = Ci == NI * 32;
-  if (one_group) load_weights(0);
+    wk[ci][k] = v;
+  }
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
   int64_t b = tile;
   const int tx = (int)(b % tiles_x);
@@ -2128,11 +2124,7 @@ thin_cout_dgrad_kernel(const IgemmParams p) {
     }
   }
   for (int g = 0; g < Ci; g += NI * 32) {
-    if (!one_group) {
-      __syncthreads();   // (previous group's fragments are consumed)
-      load_weights(g);
-    }
-    __syncthreads();
+    if (g == 0) __syncthreads();   // patch (and, the first time, the weights) are in place
     f32x16_t acc[NI][2];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -2158,7 +2150,7 @@ thin_cout_dgrad_kernel(const IgemmParams p) {
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const uint4 wf = *reinterpret_cast<const uint4*>(&wk[i * 32 + l32][ks * 16 + half * 8]);
+        const uint4 wf = *reinterpret_cast<const uint4*>(&wk[g + i * 32 + l32][ks * 16 + half * 8]);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
@@ -2174,6 +2166,166 @@ thin_cout_dgrad_kernel(const IgemmParams p) {
     }
     store_wave_lds<NI>(p, acc, opix, g, lane, scratch[wave]);
   }
+  }
+}
+
+// ------------------------------------------------------------------ thin-Cin forward
+// First layers (5 -> 128 7x7 s2 of the generator, 4 -> 128 4x4 s2 of the discriminator): K =
+// kh * kw * Cin <= 256 reduction elements, hundreds of MB of output -- store bound, but the
+// scalar-gather fallback ran them at 1.1 / 0.7 ms.  One persistent workgroup per CU keeps the
+// zero-padded weight rows W[co][k] of 128 output channels in LDS; per 16 x 32 output tile it loads
+// the (masked) input patch once and each of the 8 waves builds the im2col fragments of its two
+// rows with 16-bit LDS gathers through an offset table; full-line stores through the LDS
+// epilogue (two 64-channel halves per wave to keep its scratch small).  LDS is sized per layer.
+constexpr int kThinKMax = 256, kThinCinMax = 8, kThinFRows = 16, kThinFThreads = 512;
+struct ThinCinLds {
+  int kp, ws, ph, pw;
+  size_t xs_off, wk_off, koff_off, bytes;
+};
+__host__ __device__ inline ThinCinLds thin_cin_lds(int kh, int kw, int cin, int stride) {
+  ThinCinLds l;
+  l.kp = (kh * kw * cin + 15) / 16 * 16;
+  l.ws = l.kp + 8;
+  l.ph = (kThinFRows - 1) * stride + kh;
+  l.pw = (kThinCols - 1) * stride + kw;
+  l.xs_off = (size_t)(kThinFThreads / 64) * kEpiScratch<2>;
+  l.wk_off = l.xs_off + ((size_t)l.ph * l.pw * cin * 2 + 15) / 16 * 16;
+  l.koff_off = l.wk_off + (size_t)128 * l.ws * 2;
+  l.bytes = l.koff_off + (size_t)l.kp * 2;
+  return l;
+}
+__global__ void __launch_bounds__(kThinFThreads)
+thin_cin_fwd_kernel(const IgemmParams p) {
+  constexpr int NI = 4, NT = kThinFThreads;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tc_smem[];
+  const ThinCinLds L = thin_cin_lds(p.kh, p.kw, p.sC, p.stride);
+  unsigned char* scratch = tc_smem;
+  uint16_t* xs = reinterpret_cast<uint16_t*>(tc_smem + L.xs_off);
+  uint16_t* wk = reinterpret_cast<uint16_t*>(tc_smem + L.wk_off);
+  int16_t* koff = reinterpret_cast<int16_t*>(tc_smem + L.koff_off);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int Ci = p.sC, K = p.kh * p.kw * Ci, KP = L.kp, WS = L.ws;
+  const int st = p.stride;
+  const int PH = L.ph, PW = L.pw;
+  const int tiles_x = ceil_div(p.oW, kThinCols), tiles_y = ceil_div(p.oH, kThinFRows);
+  const int64_t n_tiles = (int64_t)p.N * tiles_y * tiles_x;
+  const uint16_t* __restrict__ src = (const uint16_t*)p.src;
+  const uint16_t* __restrict__ wt = (const uint16_t*)p.w;   // wt [oC][K], k = (ky * kw + kx) * Ci + ci
+  for (int k = tid; k < KP; k += NT) {
+    int o = -1;
+    if (k < K) {
+      const int tap = k / Ci, ci = k - tap * Ci;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      o = (ky * PW + kx) * Ci + ci;
+    }
+    koff[k] = (int16_t)o;
+  }
+  auto load_weights = [&](int g) {
+    for (int i = tid; i < NI * 32 * KP; i += NT) {
+      const int co = i / KP, k = i - co * KP;
+      wk[co * WS + k] = k < K ? wt[(int64_t)(g + co) * K + k] : (uint16_t)0;
+    }
+  };
+  const bool one_group = p.oC == NI * 32;
+  if (one_group) load_weights(0);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int64_t b = tile;
+    const int tx = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
+    const int oy0 = ty * kThinFRows, ox0 = tx * kThinCols;
+    __syncthreads();   // the previous tile's patch is consumed
+    {
+      // one pixel (<= 8 channels) per thread and trip, two pixels in flight
+      constexpr int kB = 2;
+      const int npix = PH * PW;
+      for (int q0 = tid; q0 < npix; q0 += kB * NT) {
+        uint16_t v[kB][kThinCinMax];
+        float mk[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int pix = q0 + u * NT;
+          mk[u] = 1.0f;
+#pragma unroll
+          for (int c = 0; c < kThinCinMax; ++c) v[u][c] = 0;
+          if (pix < npix) {
+            const int r = pix / PW, q = pix - r * PW;
+            const int sy = oy0 * st - p.pad_t + r;
+            int sx = ox0 * st - p.pad_l + q;
+            if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+            if (sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW) {
+              const int64_t sp = ((int64_t)n * p.sH + sy) * p.sW + sx;
+              const uint16_t* px = src + sp * Ci;
+#pragma unroll
+              for (int c = 0; c < kThinCinMax; ++c)
+                if (c < Ci) v[u][c] = px[c];
+              if (p.src_mask) mk[u] = p.src_mask[sp];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int pix = q0 + u * NT;
+          if (pix < npix) {
+#pragma unroll
+            for (int c = 0; c < kThinCinMax; ++c)
+              if (c < Ci)
+                xs[pix * Ci + c] = p.src_mask ? f32_to_bf16(bf16_to_f32(v[u][c]) * mk[u]) : v[u][c];
+          }
+        }
+      }
+    }
+    for (int g = 0; g < p.oC; g += NI * 32) {
+      if (!one_group) {
+        __syncthreads();
+        load_weights(g);
+      }
+      __syncthreads();
+      f32x16_t acc[NI][2];
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+      const int base0 = ((wave * 2) * st * PW + l32 * st) * Ci;
+      const int base1 = base0 + st * PW * Ci;
+      for (int ks = 0; ks < KP; ks += 16) {
+        uint4 xf[2];
+        int o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = koff[ks + half * 8 + q];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int base = j ? base1 : base0;
+          uint16_t e[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) e[q] = o[q] >= 0 ? xs[base + o[q]] : (uint16_t)0;
+          xf[j] = make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
+                             (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const uint4 wf = *reinterpret_cast<const uint4*>(&wk[(i * 32 + l32) * WS + ks + half * 8]);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
+                                                                __builtin_bit_cast(bf16x8_t, xf[j]),
+                                                                acc[i][j], 0, 0, 0);
+        }
+      }
+      int64_t opix[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int oy = oy0 + wave * 2 + j, ox = ox0 + l32;
+        opix[j] = (oy < p.oH && ox < p.oW) ? ((int64_t)n * p.oH + oy) * p.oW + ox : -1;
+      }
+      unsigned char* scr = scratch + wave * kEpiScratch<2>;
+      store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, g, lane, scr);
+      store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), opix, g + 64, lane, scr);
+    }
   }
 }
 
@@ -2222,7 +2374,7 @@ thin_cout_fwd_kernel(const IgemmParams p) {
   {
     const int cpp = C / 8;   // 16-byte chunks per pixel
     const int total = kThinPH * kThinPW * cpp;
-    constexpr int kB = 4;    // loads in flight per thread
+    constexpr int kB = 7;    // loads in flight per thread (a 128-channel patch is two trips)
     for (int i0 = tid; i0 < total; i0 += kB * 256) {
       uint4 v[kB];
       int dst[kB];
@@ -2457,15 +2609,30 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       !(mode == MODE_FWD && fwd_stats_rows(p, dtype, stride, kh, kw, glds) > 0))
     return SE3DS_E_UNSUPPORTED;   // callers ask se3ds_conv2d_fwd_stats_rows first
   p.stats = mode == MODE_FWD ? stats : nullptr;
+  if (mode == MODE_FWD && dtype == SE3DS_BF16 && cin <= kThinCinMax && (cout % 128) == 0 &&
+      kh * kw * cin <= kThinKMax && kh <= 7 && kw <= 7 && stats == nullptr && addend == nullptr &&
+      !getenv("SE3DS_NO_THIN_CIN")) {
+    const ThinCinLds L = thin_cin_lds(kh, kw, cin, stride);
+    static size_t lds_set = 0;
+    if (L.bytes > lds_set) {
+      if (hipFuncSetAttribute((const void*)thin_cin_fwd_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.bytes) != hipSuccess)
+        return SE3DS_E_LAUNCH;
+      lds_set = L.bytes;
+    }
+    int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinFRows) * ceil_div(p.oW, kThinCols);
+    const int64_t resident = 256;   // persistent: one 8-wave workgroup per CU (register bound)
+    if (blocks > resident) blocks = resident;
+    hipLaunchKernelGGL(thin_cin_fwd_kernel, dim3((unsigned)blocks), dim3(kThinFThreads), L.bytes, s,
+                       p);
+    return check_launch("conv2d_fwd(thin cin)");
+  }
   if (mode == MODE_DGRAD && dtype == SE3DS_BF16 && kh == 3 && kw == 3 && stride == 1 && cout <= 4 &&
-      (cin % 64) == 0 && src_mask == nullptr && row_a == nullptr &&
+      (cin % 64) == 0 && cin <= kThinDCinMax && src_mask == nullptr && row_a == nullptr &&
       !getenv("SE3DS_NO_THIN_DGRAD")) {
     int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinDRows) * ceil_div(p.oW, kThinCols);
     if (blocks > 3 * 256) blocks = 3 * 256;   // persistent: three workgroups per CU
-    if ((cin % 128) == 0)
-      hipLaunchKernelGGL(thin_cout_dgrad_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    else
-      hipLaunchKernelGGL(thin_cout_dgrad_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(thin_cout_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     return check_launch("conv2d_dgrad(thin)");
   }
   if (mode == MODE_FWD && dtype == SE3DS_BF16 && kh == 3 && kw == 3 && stride == 1 && cout <= 4 &&

@@ -98,6 +98,20 @@ def test_conv_thin_cout(case):
   _run_conv_case(case, torch.bfloat16)
 
 
+# first layers: <= 8 input channels onto a multiple of 128 (thin_cin_fwd_kernel)
+THIN_CIN_CASES = [
+    ('partial', 5, 128, 7, 2, 'VALID', 3, False, True, True, 2, 32, 64),      # generator conv1
+    ('plain', 4, 128, 4, 2, 'VALID', 2, False, True, False, 2, 34, 66),       # discriminator conv1
+    ('plain', 4, 256, 3, 1, 'VALID', 1, True, False, False, 1, 12, 40),       # two channel groups, wrap
+    ('spectral', 8, 128, 3, 2, 'VALID', 1, False, True, False, 3, 19, 45),    # ragged tiles
+]
+
+
+@pytest.mark.parametrize('case', THIN_CIN_CASES)
+def test_conv_thin_cin(case):
+  _run_conv_case(case, torch.bfloat16)
+
+
 @pytest.mark.parametrize('halo', ['0', '1'])
 @pytest.mark.parametrize('case', BIG_TILE_CASES)
 def test_conv_macro_tile_fwd_bwd(case, halo, monkeypatch):
