@@ -2024,8 +2024,17 @@ wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t n, int a
                     const float* __restrict__ out_scale, float* __restrict__ out) {
   const float sc = out_scale ? *out_scale : 1.0f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float s = 0.0f;
-    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * n + i];
+    // four independent partial sums keep the loads of a long split list in flight
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      s0 += part[(int64_t)k * n + i];
+      s1 += part[(int64_t)(k + 1) * n + i];
+      s2 += part[(int64_t)(k + 2) * n + i];
+      s3 += part[(int64_t)(k + 3) * n + i];
+    }
+    for (; k < splits; ++k) s0 += part[(int64_t)k * n + i];
+    float s = (s0 + s1) + (s2 + s3);
     s *= sc;
     out[i] = accumulate ? out[i] + s : s;
   }
@@ -2169,6 +2178,185 @@ thin_cout_dgrad_kernel(const IgemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------ thin-Cin weight gradient
+// dW[k][co] = sum over pixels of im2col(x)[px][k] * dy[px][co] for the same first layers
+// (K = kh * kw * Cin <= 256, Cout = 128): 32 K outputs, hundreds of MB of dy to read.  The
+// scalar-gather kernel ran them at 1.2 - 1.6 ms.  Persistent workgroups (one per CU, 8 waves)
+// walk 8 x 32 pixel tiles: the dy tile (256 px x 128 ch) and the (masked) x patch go to LDS, both
+// MFMA operands are gathered with 16-bit LDS reads (pixels are the reduction dimension, so both
+// need 8 pixels per lane), the K/32 x 4 accumulator tiles stay in registers across all tiles of
+// the workgroup and leave as one partial slab per workgroup for wgrad_reduce_kernel.
+constexpr int kThinKMax = 256, kThinCinMax = 8;
+constexpr int kThinWRows = 8, kThinWThreads = 512, kThinWDyStride = 128 * 2 + 8;   // bytes per dy pixel
+struct ThinCinWgradParams {
+  const uint16_t* x; const uint16_t* dy; float* part;
+  int N, H, W, Cin, Ho, Wo, Cout, kh, kw, stride, pad_t, pad_l, wrap_w;
+  const float* src_mask; const float* row_scale;
+};
+__host__ __device__ inline size_t thin_cin_wgrad_lds(int kh, int kw, int cin, int stride) {
+  const int ph = (kThinWRows - 1) * stride + kh, pw = (kThinCols - 1) * stride + kw;
+  return (size_t)kThinWRows * kThinCols * kThinWDyStride + ((size_t)ph * pw * cin * 2 + 15) / 16 * 16 +
+         kThinKMax * 2;
+}
+__global__ void __launch_bounds__(kThinWThreads)
+thin_cin_wgrad_kernel(const ThinCinWgradParams p) {
+  constexpr int NT = kThinWThreads, PX = kThinWRows * kThinCols, DYS = kThinWDyStride;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];
+  const int Ci = p.Cin, K = p.kh * p.kw * Ci, MB = (K + 31) / 32;
+  const int st = p.stride;
+  const int PH = (kThinWRows - 1) * st + p.kh, PW = (kThinCols - 1) * st + p.kw;
+  unsigned char* dys = tw_smem;                                   // [PX][DYS]
+  uint16_t* xs = reinterpret_cast<uint16_t*>(tw_smem + (size_t)PX * DYS);
+  int16_t* koff = reinterpret_cast<int16_t*>(tw_smem + (size_t)PX * DYS +
+                                             ((size_t)PH * PW * Ci * 2 + 15) / 16 * 16);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  for (int k = tid; k < kThinKMax; k += NT) {
+    int o = -1;
+    if (k < K) {
+      const int tap = k / Ci, ci = k - tap * Ci;
+      const int ky = tap / p.kw, kx = tap - ky * p.kw;
+      o = (ky * PW + kx) * Ci + ci;
+    }
+    koff[k] = (int16_t)o;
+  }
+  __syncthreads();
+  // accumulator tile i of this wave: t = wave + 8 i -> (m block t / 4, n block t % 4)
+  const int nb = wave & 3;
+  int ko[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mb = (wave + 8 * i) >> 2;
+    ko[i] = mb < MB ? koff[mb * 32 + l32] : -1;
+  }
+  f32x16_t acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const int tiles_x = ceil_div(p.Wo, kThinCols), tiles_y = ceil_div(p.Ho, kThinWRows);
+  const int64_t n_tiles = (int64_t)p.N * tiles_y * tiles_x;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int64_t b = tile;
+    const int tx = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
+    const int oy0 = ty * kThinWRows, ox0 = tx * kThinCols;
+    __syncthreads();   // the previous tile's operands are consumed
+    // dy tile (zero outside the image; optional per-pixel scale)
+    {
+      uint4 v[PX * 16 / NT];
+#pragma unroll
+      for (int u = 0; u < PX * 16 / NT; ++u) {
+        const int i = tid + u * NT;
+        const int px = i >> 4, c = i & 15;
+        const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+        v[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (oy < p.Ho && ox < p.Wo) {
+          const int64_t op = ((int64_t)n * p.Ho + oy) * p.Wo + ox;
+          v[u] = *reinterpret_cast<const uint4*>(p.dy + op * 128 + c * 8);
+          if (p.row_scale) {
+            const float rs = p.row_scale[op];
+            uint32_t* w = reinterpret_cast<uint32_t*>(&v[u]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float lo = __uint_as_float(w[q] << 16) * rs;
+              const float hi = __uint_as_float(w[q] & 0xffff0000u) * rs;
+              w[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PX * 16 / NT; ++u) {
+        const int i = tid + u * NT;
+        // (pixel rows are 8 bytes off 16-byte alignment: two 8-byte stores)
+        uint2* d = reinterpret_cast<uint2*>(dys + (i >> 4) * DYS + (i & 15) * 16);
+        d[0] = make_uint2(v[u].x, v[u].y);
+        d[1] = make_uint2(v[u].z, v[u].w);
+      }
+    }
+    // x patch, one pixel (<= 8 channels) per thread and trip
+    {
+      constexpr int kB = 2;
+      const int npix = PH * PW;
+      for (int q0 = tid; q0 < npix; q0 += kB * NT) {
+        uint16_t v[kB][kThinCinMax];
+        float mk[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int pix = q0 + u * NT;
+          mk[u] = 1.0f;
+#pragma unroll
+          for (int c = 0; c < kThinCinMax; ++c) v[u][c] = 0;
+          if (pix < npix) {
+            const int r = pix / PW, q = pix - r * PW;
+            const int sy = oy0 * st - p.pad_t + r;
+            int sx = ox0 * st - p.pad_l + q;
+            if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
+            if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W) {
+              const int64_t sp = ((int64_t)n * p.H + sy) * p.W + sx;
+              const uint16_t* px = p.x + sp * Ci;
+#pragma unroll
+              for (int c = 0; c < kThinCinMax; ++c)
+                if (c < Ci) v[u][c] = px[c];
+              if (p.src_mask) mk[u] = p.src_mask[sp];
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int pix = q0 + u * NT;
+          if (pix < npix) {
+#pragma unroll
+            for (int c = 0; c < kThinCinMax; ++c)
+              if (c < Ci)
+                xs[pix * Ci + c] = p.src_mask ? f32_to_bf16(bf16_to_f32(v[u][c]) * mk[u]) : v[u][c];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // 16 reduction steps of 16 pixels: step s covers row s / 2, columns (s & 1) * 16 .. + 15
+    for (int sidx = 0; sidx < PX / 16; ++sidx) {
+      const int row = sidx >> 1, col0 = (sidx & 1) * 16 + half * 8;
+      // B: dy[px][co], 8 pixels of this lane's channel
+      uint16_t eb[8];
+      const unsigned char* dp = dys + (row * kThinCols + col0) * DYS + (nb * 32 + l32) * 2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) eb[j] = *reinterpret_cast<const uint16_t*>(dp + j * DYS);
+      const uint4 bf = make_uint4((uint32_t)eb[0] | ((uint32_t)eb[1] << 16), (uint32_t)eb[2] | ((uint32_t)eb[3] << 16),
+                                  (uint32_t)eb[4] | ((uint32_t)eb[5] << 16), (uint32_t)eb[6] | ((uint32_t)eb[7] << 16));
+      const int xbase = (row * st * PW + col0 * st) * Ci;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (((wave + 8 * i) >> 2) >= MB) break;   // wave-uniform
+        uint16_t ea[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ea[j] = ko[i] >= 0 ? xs[xbase + ko[i] + j * st * Ci] : (uint16_t)0;
+        const uint4 af = make_uint4((uint32_t)ea[0] | ((uint32_t)ea[1] << 16), (uint32_t)ea[2] | ((uint32_t)ea[3] << 16),
+                                    (uint32_t)ea[4] | ((uint32_t)ea[5] << 16), (uint32_t)ea[6] | ((uint32_t)ea[7] << 16));
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af),
+                                                         __builtin_bit_cast(bf16x8_t, bf), acc[i], 0, 0,
+                                                         0);
+      }
+    }
+  }
+  // partial slab of this workgroup: part[blockIdx][k][co]
+  float* slab = p.part + (int64_t)blockIdx.x * K * 128;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mb = (wave + 8 * i) >> 2;
+    if (mb >= MB) break;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = mb * 32 + (e >> 2) * 8 + half * 4 + (e & 3);
+      if (k < K) slab[(int64_t)k * 128 + nb * 32 + l32] = acc[i][e];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ thin-Cin forward
 // First layers (5 -> 128 7x7 s2 of the generator, 4 -> 128 4x4 s2 of the discriminator): K =
 // kh * kw * Cin <= 256 reduction elements, hundreds of MB of output -- store bound, but the
@@ -2177,7 +2365,7 @@ thin_cout_dgrad_kernel(const IgemmParams p) {
 // the (masked) input patch once and each of the 8 waves builds the im2col fragments of its two
 // rows with 16-bit LDS gathers through an offset table; full-line stores through the LDS
 // epilogue (two 64-channel halves per wave to keep its scratch small).  LDS is sized per layer.
-constexpr int kThinKMax = 256, kThinCinMax = 8, kThinFRows = 16, kThinFThreads = 512;
+constexpr int kThinFRows = 16, kThinFThreads = 512;
 struct ThinCinLds {
   int kp, ws, ph, pw;
   size_t xs_off, wk_off, koff_off, bytes;
@@ -2809,6 +2997,11 @@ static int wgrad_taps_splits(int n, int ho, int wo, int cin, int cout, int kh, i
   return best;
 }
 
+static bool thin_cin_wgrad_ok(int cin, int cout, int kh, int kw) {
+  return cin <= kThinCinMax && cout == 128 && kh * kw * cin <= kThinKMax && kh <= 7 && kw <= 7 &&
+         !getenv("SE3DS_NO_THIN_CIN_WGRAD");
+}
+
 size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int cout, int kh,
                                           int kw) {
   int tsteps = 0;
@@ -2819,7 +3012,11 @@ size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int co
                                 : (int64_t)kh * kw * ceil_div(cin, 128);
   int64_t tiles = row_tiles * ceil_div(cout, 128);
   int splits = wgrad_splits(L, tiles, (int64_t)kh * kw * cin * cout);
-  const size_t bytes = sizeof(float) * (size_t)splits * (size_t)kh * kw * cin * cout + 16;
+  size_t bytes = sizeof(float) * (size_t)splits * (size_t)kh * kw * cin * cout + 16;
+  if (thin_cin_wgrad_ok(cin, cout, kh, kw)) {   // one partial slab per persistent workgroup
+    const size_t thin = sizeof(float) * (size_t)256 * (size_t)kh * kw * cin * cout + 16;
+    bytes = bytes > thin ? bytes : thin;
+  }
   return bytes > taps_bytes ? bytes : taps_bytes;
 }
 
@@ -2856,6 +3053,28 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
                          (const float*)workspace, tsplits, tnel, accumulate, out_scale, dw);
       return check_launch("conv2d_wgrad(taps)");
     }
+  }
+  if (dtype == SE3DS_BF16 && stride <= 2 && thin_cin_wgrad_ok(cin, cout, kh, kw)) {
+    ThinCinWgradParams q;
+    q.x = (const uint16_t*)x; q.dy = (const uint16_t*)dy; q.part = (float*)workspace;
+    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.Ho = ho; q.Wo = wo; q.Cout = cout; q.kh = kh;
+    q.kw = kw; q.stride = stride; q.pad_t = pad_t; q.pad_l = pad_l; q.wrap_w = wrap_w;
+    q.src_mask = in_mask; q.row_scale = row_scale;
+    const size_t lds = thin_cin_wgrad_lds(kh, kw, cin, stride);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      if (hipFuncSetAttribute((const void*)thin_cin_wgrad_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SE3DS_E_LAUNCH;
+      lds_set = lds;
+    }
+    int64_t blocks = (int64_t)n * ceil_div(ho, kThinWRows) * ceil_div(wo, kThinCols);
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(thin_cin_wgrad_kernel, dim3((unsigned)blocks), dim3(kThinWThreads), lds, s, q);
+    const int64_t tnel = (int64_t)kh * kw * cin * cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(tnel, 256)), dim3(256), 0, s,
+                       (const float*)workspace, (int)blocks, tnel, accumulate, out_scale, dw);
+    return check_launch("conv2d_wgrad(thin cin)");
   }
   WgradParams p;
   p.x = x; p.H = h; p.W = w; p.Cin = cin; p.dy = dy; p.Ho = ho; p.Wo = wo; p.Cout = cout;
