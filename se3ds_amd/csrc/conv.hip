@@ -2178,6 +2178,109 @@ thin_cout_dgrad_kernel(const IgemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------ thin data gradient, 4x4 stride 2
+// dx (<= 4 channels) of the discriminator's first layer from dy (128 channels): 540 MB read,
+// 67 MB written per call.  The four output parity classes each see 2 x 2 of the 16 taps; for a
+// class the dy pixels under consecutive outputs are consecutive, so a class row is a plain
+// "thin-Cout forward" over a dy patch in LDS: MFMA A = the <= 4 weight rows W[(tap, ci)][co],
+// B = 16-byte patch reads.  Workgroup tile: 8 x 64 output pixels = 4 classes x 4 rows x 32
+// columns; wave w takes class row w of every class.
+constexpr int kThinSRows = 8, kThinSCols = 64, kThinSPH = 5, kThinSPW = 33;
+__global__ void __launch_bounds__(256)
+thin_s2_dgrad_kernel(const IgemmParams p) {
+  constexpr int C = 128, PB = C * 2 + 16;   // dy channels, bytes per patch pixel
+  __shared__ __attribute__((aligned(16))) unsigned char ds[kThinSPH * kThinSPW * PB];
+  __shared__ __attribute__((aligned(16))) uint16_t wl[16 * 4 * C];   // wn [(tap * Ci + ci)][co]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int Ci = p.oC;
+  const int tiles_x = ceil_div(p.oW, kThinSCols), tiles_y = ceil_div(p.oH, kThinSRows);
+  const int64_t n_tiles = (int64_t)p.N * tiles_y * tiles_x;
+  const uint16_t* __restrict__ dy = (const uint16_t*)p.src;
+  for (int i = tid; i < 16 * Ci * C / 8; i += 256)
+    reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(p.w)[i];
+  const float scale = p.scale ? *p.scale : 1.0f;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int64_t b = tile;
+    const int tx = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
+    const int y0 = ty * kThinSRows, x0 = tx * kThinSCols;
+    // first dy row / column any output of the tile reads (numerators y + pad - ky are even)
+    const int oyb = (y0 + p.pad_t - 2) >> 1, oxb = (x0 + p.pad_l - 2) >> 1;
+    __syncthreads();   // the previous tile's patch is consumed
+    {
+      constexpr int cpp = C / 8, total = kThinSPH * kThinSPW * cpp, kB = 6;
+      for (int i0 = tid; i0 < total; i0 += kB * 256) {
+        uint4 v[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int i = i0 + u * 256;
+          v[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (i < total) {
+            const int pix = i / cpp, c = i - pix * cpp;
+            const int r = pix / kThinSPW, q = pix - r * kThinSPW;
+            const int sy = oyb + r, sx = oxb + q;
+            if (sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW)
+              v[u] = *reinterpret_cast<const uint4*>(dy + (((int64_t)n * p.sH + sy) * p.sW + sx) * C + c * 8);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int i = i0 + u * 256;
+          if (i < total) {
+            const int pix = i / cpp, c = i - pix * cpp;
+            *reinterpret_cast<uint4*>(ds + pix * PB + c * 16) = v[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+      const int py = cls >> 1, px = cls & 1;
+      // taps of the class: ky = ky0, ky0 + 2 with (py + pad - ky0) even; the same for kx
+      const int ky0 = (py + p.pad_t) & 1, kx0 = (px + p.pad_l) & 1;
+      f32x16_t acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ky = ky0 + 2 * (t >> 1), kx = kx0 + 2 * (t & 1);
+        // output (y0 + py + 2 a, x0 + px + 2 b), a = wave, b = l32 reads dy pixel
+        // ((y + pad - ky) / 2, (x + pad - kx) / 2)
+        const int r = ((y0 + py + 2 * wave + p.pad_t - ky) >> 1) - oyb;
+        const int q = ((x0 + px + p.pad_l - kx) >> 1) - oxb;
+        const unsigned char* xrow = ds + (r * kThinSPW + q + l32) * PB + half * 16;
+        const uint16_t* wrow = wl + ((ky * 4 + kx) * Ci + (l32 < Ci ? l32 : 0)) * C + half * 8;
+#pragma unroll
+        for (int kc = 0; kc < C / 16; ++kc) {
+          const uint4 xf = *reinterpret_cast<const uint4*>(xrow + kc * 32);
+          uint4 wf = *reinterpret_cast<const uint4*>(wrow + kc * 16);
+          if (l32 >= Ci) wf = make_uint4(0u, 0u, 0u, 0u);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
+                                                        __builtin_bit_cast(bf16x8_t, xf), acc, 0, 0,
+                                                        0);
+        }
+      }
+      const int oy = y0 + py + 2 * wave, ox = x0 + px + 2 * l32;
+      if (half == 0 && oy < p.oH && ox < p.oW) {
+        const int64_t o = (((int64_t)n * p.oH + oy) * p.oW + ox) * Ci;
+        uint16_t* out = (uint16_t*)p.out + o;
+        const uint16_t* add = p.addend ? (const uint16_t*)p.addend + o : nullptr;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < Ci) {
+            float v = acc[c] * scale;
+            if (add) v = bf16_to_f32(f32_to_bf16(v)) + bf16_to_f32(add[c]);
+            out[c] = f32_to_bf16(v);
+          }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ thin-Cin weight gradient
 // dW[k][co] = sum over pixels of im2col(x)[px][k] * dy[px][co] for the same first layers
 // (K = kh * kw * Cin <= 256, Cout = 128): 32 K outputs, hundreds of MB of dy to read.  The
@@ -2797,6 +2900,15 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       !(mode == MODE_FWD && fwd_stats_rows(p, dtype, stride, kh, kw, glds) > 0))
     return SE3DS_E_UNSUPPORTED;   // callers ask se3ds_conv2d_fwd_stats_rows first
   p.stats = mode == MODE_FWD ? stats : nullptr;
+  if (mode == MODE_DGRAD && dtype == SE3DS_BF16 && kh == 4 && kw == 4 && stride == 2 && cin <= 4 &&
+      cout == 128 && src_mask == nullptr && row_a == nullptr && bias == nullptr && act == 0 &&
+      !wrap_w && (pad_t == 0 || pad_t == 2) && (pad_l == 0 || pad_l == 2) &&
+      !getenv("SE3DS_NO_THIN_S2_DGRAD")) {
+    int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinSRows) * ceil_div(p.oW, kThinSCols);
+    if (blocks > 2 * 256) blocks = 2 * 256;   // persistent, two workgroups per CU
+    hipLaunchKernelGGL(thin_s2_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return check_launch("conv2d_dgrad(thin s2)");
+  }
   if (mode == MODE_FWD && dtype == SE3DS_BF16 && cin <= kThinCinMax && (cout % 128) == 0 &&
       kh * kw * cin <= kThinKMax && kh <= 7 && kw <= 7 && stats == nullptr && addend == nullptr &&
       !getenv("SE3DS_NO_THIN_CIN")) {

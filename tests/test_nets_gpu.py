@@ -104,6 +104,8 @@ THIN_CIN_CASES = [
     ('plain', 4, 128, 4, 2, 'VALID', 2, False, True, False, 2, 34, 66),       # discriminator conv1
     ('plain', 4, 256, 3, 1, 'VALID', 1, True, False, False, 1, 12, 40),       # two channel groups, wrap
     ('spectral', 8, 128, 3, 2, 'VALID', 1, False, True, False, 3, 19, 45),    # ragged tiles
+    ('plain', 3, 128, 4, 2, 'VALID', 2, False, False, False, 1, 70, 130),     # stride-2 thin data gradient, 2 x 3 tiles
+    ('spectral', 4, 128, 4, 2, 'VALID', 0, False, True, False, 2, 20, 36),    # no padding
 ]
 
 
