@@ -2460,6 +2460,129 @@ thin_cin_wgrad_kernel(const ThinCinWgradParams p) {
   }
 }
 
+// ------------------------------------------------------------------ thin-Cout 3x3 weight gradient
+// dW[(tap, ci)][co] for the heads (Cout <= 4, stride 1, 'same'): the mirror image of the kernel
+// above -- dy is the thin operand (MFMA rows = output channels, only Cout of 32 populated), the
+// 9 * Cin / 32 column tiles (tap, 32 input channels) are dealt to the 8 waves, the x patch
+// (10 x 34 pixels, all channels) is staged once per 8 x 32 pixel tile and its fragments (8
+// pixels of one channel per lane) come from transposing LDS reads (ds_read_b64_tr_b16), as in the
+// tap-fused kernel.  1 GB of x per call.
+struct ThinCoutWgradParams {
+  const uint16_t* x; const uint16_t* dy; float* part;
+  int N, H, W, Cin, Cout, pad;
+};
+constexpr int kThinQRows = 8, kThinQSlabs = 256;   // 8 x 32 pixel tiles, one 8-wave workgroup per CU
+// (4-row tiles with two workgroups per CU measured slower: 895 vs 787 us)
+__host__ __device__ inline int thin_cw_pixel_bytes(int cin) { return cin * 2 + 32; }
+__host__ __device__ inline size_t thin_cout_wgrad_lds(int cin) {
+  return (size_t)(kThinQRows + 2) * (kThinCols + 2) * thin_cw_pixel_bytes(cin) +
+         (size_t)kThinQRows * kThinCols * 4 * 2;
+}
+__global__ void __launch_bounds__(kThinWThreads)
+thin_cout_wgrad_kernel(const ThinCoutWgradParams p) {
+  typedef __attribute__((address_space(3))) s16x4_t* lds_seg;
+  constexpr int NT = kThinWThreads, PX = kThinQRows * kThinCols;
+  constexpr int PH = kThinQRows + 2, PW = kThinCols + 2, MAXT = 5;   // tiles per wave (Cin <= 128: 36 / 8)
+  extern __shared__ __attribute__((aligned(16))) unsigned char tq_smem[];
+  const int Ci = p.Cin, Co = p.Cout, PB = thin_cw_pixel_bytes(Ci);
+  unsigned char* xs = tq_smem;                                                  // [PH * PW][PB]
+  uint16_t* dys = reinterpret_cast<uint16_t*>(tq_smem + (size_t)PH * PW * PB);  // [PX][Co]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int g16 = (lane >> 4) & 1, i16 = lane & 15, jrow = i16 >> 2, qcol = i16 & 3;
+  const int cblocks = Ci / 32, ntile = 9 * cblocks;
+  f32x16_t acc[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const int tiles_x = ceil_div(p.W, kThinCols), tiles_y = ceil_div(p.H, kThinQRows);
+  const int64_t n_tiles = (int64_t)p.N * tiles_y * tiles_x;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int64_t b = tile;
+    const int tx = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
+    const int oy0 = ty * kThinQRows, ox0 = tx * kThinCols;
+    __syncthreads();   // the previous tile's operands are consumed
+    for (int i = tid; i < PX * Co; i += NT) {
+      const int px = i / Co, c = i - px * Co;
+      const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
+      dys[i] = (oy < p.H && ox < p.W) ? p.dy[(((int64_t)n * p.H + oy) * p.W + ox) * Co + c] : (uint16_t)0;
+    }
+    {
+      const int cpp = Ci / 8, total = PH * PW * cpp;
+      constexpr int kB = 6;
+      for (int i0 = tid; i0 < total; i0 += kB * NT) {
+        uint4 v[kB];
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int i = i0 + u * NT;
+          v[u] = make_uint4(0u, 0u, 0u, 0u);
+          if (i < total) {
+            const int pix = i / cpp, c = i - pix * cpp;
+            const int r = pix / PW, q = pix - r * PW;
+            const int sy = oy0 - p.pad + r, sx = ox0 - p.pad + q;
+            if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+              v[u] = *reinterpret_cast<const uint4*>(p.x + (((int64_t)n * p.H + sy) * p.W + sx) * Ci + c * 8);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; ++u) {
+          const int i = i0 + u * NT;
+          if (i < total) {
+            const int pix = i / cpp, c = i - pix * cpp;
+            *reinterpret_cast<uint4*>(xs + pix * PB + c * 16) = v[u];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int sidx = 0; sidx < PX / 16; ++sidx) {
+      const int row = sidx >> 1, cs = (sidx & 1) * 16;
+      // A: dy[px][co], 8 pixels of this lane's output channel (rows co >= Cout are zero)
+      uint16_t ea[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        ea[j] = l32 < Co ? dys[(row * kThinCols + cs + half * 8 + j) * Co + l32] : (uint16_t)0;
+      const uint4 af = make_uint4((uint32_t)ea[0] | ((uint32_t)ea[1] << 16), (uint32_t)ea[2] | ((uint32_t)ea[3] << 16),
+                                  (uint32_t)ea[4] | ((uint32_t)ea[5] << 16), (uint32_t)ea[6] | ((uint32_t)ea[7] << 16));
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        const int t = wave + 8 * i;
+        if (t >= ntile) break;   // wave-uniform
+        const int tap = t / cblocks, cb = t - tap * cblocks;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        // B: x[pixel][ci], pixels (row + ky, cs + kx + half * 8 .. + 7), channel cb * 32 + l32:
+        // address lane (4 j + q) -> pixel + j, channels 4 q .. 4 q + 3 of the 16-channel group
+        const unsigned char* xp = xs + ((row + ky) * PW + cs + kx + half * 8 + jrow) * PB +
+                                  (cb * 32 + g16 * 16 + qcol * 4) * 2;
+        const uint2 b0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)xp));
+        const uint2 b1 = __builtin_bit_cast(
+            uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(xp + 4 * PB)));
+        const uint4 bf = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af),
+                                                         __builtin_bit_cast(bf16x8_t, bf), acc[i], 0, 0,
+                                                         0);
+      }
+    }
+  }
+  // lanes of half 0 hold co 0..3 of column (tap, cb * 32 + l32) in acc[.][0..3]
+  float* slab = p.part + (int64_t)blockIdx.x * 9 * Ci * Co;
+  if (half == 0) {
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = wave + 8 * i;
+      if (t >= ntile) break;
+      const int tap = t / cblocks, cb = t - tap * cblocks;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < Co) slab[((int64_t)tap * Ci + cb * 32 + l32) * Co + c] = acc[i][c];
+    }
+  }
+}
+
 // ------------------------------------------------------------------ thin-Cin forward
 // First layers (5 -> 128 7x7 s2 of the generator, 4 -> 128 4x4 s2 of the discriminator): K =
 // kh * kw * Cin <= 256 reduction elements, hundreds of MB of output -- store bound, but the
@@ -3242,7 +3365,10 @@ size_t se3ds_conv2d_wgrad_swapped_workspace_bytes(int n, int h, int w, int cin, 
   const int sp = wgrad_taps_thin_splits(n, h, w, cin, cout, k, &steps);
   const size_t b = sp ? (size_t)n * h * w * 16 + 256 + sizeof(float) * (size_t)sp * 9 * cin * cout + 64
                       : 0;
-  return a > b ? a : b;
+  // thin_cout_wgrad_kernel: one partial slab per persistent workgroup
+  const size_t c = (k == 3 && cout <= 4) ? sizeof(float) * (size_t)kThinQSlabs * 9 * cin * cout + 64 : 0;
+  const size_t ab = a > b ? a : b;
+  return ab > c ? ab : c;
 }
 
 int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dtype, int n, int h,
@@ -3250,6 +3376,30 @@ int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dty
                                void* workspace, size_t workspace_bytes, void* stream) {
   if (workspace_bytes < se3ds_conv2d_wgrad_swapped_workspace_bytes(n, h, w, cin, cout, k))
     return SE3DS_E_WORKSPACE;
+  if (dtype == SE3DS_BF16 && k == 3 && cout <= 4 && (cin % 32) == 0 && cin <= 128 &&
+      workspace_bytes >= sizeof(float) * (size_t)kThinQSlabs * 9 * cin * cout &&
+      !getenv("SE3DS_NO_THIN_COUT_WGRAD")) {
+    hipStream_t s = as_stream(stream);
+    ThinCoutWgradParams q;
+    q.x = (const uint16_t*)x; q.dy = (const uint16_t*)dy; q.part = (float*)workspace;
+    q.N = n; q.H = h; q.W = w; q.Cin = cin; q.Cout = cout; q.pad = pad;
+    const size_t lds = thin_cout_wgrad_lds(cin);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+      if (hipFuncSetAttribute((const void*)thin_cout_wgrad_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return SE3DS_E_LAUNCH;
+      lds_set = lds;
+    }
+    int64_t blocks = (int64_t)n * ceil_div(h, kThinQRows) * ceil_div(w, kThinCols);
+    if (blocks > kThinQSlabs) blocks = kThinQSlabs;
+    hipLaunchKernelGGL(thin_cout_wgrad_kernel, dim3((unsigned)blocks), dim3(kThinWThreads), lds, s, q);
+    const int64_t tnel = (int64_t)9 * cin * cout;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(tnel, 256)), dim3(256), 0, s,
+                       (const float*)workspace, (int)blocks, tnel, accumulate, (const float*)nullptr,
+                       dw);
+    return check_launch("conv2d_wgrad(thin cout)");
+  }
   if (dtype == SE3DS_BF16 && !g_disable_glds) {
     int tsteps = 0;
     const int tsplits = wgrad_taps_thin_splits(n, h, w, cin, cout, k, &tsteps);
