@@ -120,42 +120,58 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
   }
 }
 
-// sums[g][k][c] = sum_b partial[g][b][k][c].  Block = 32 columns x 8 partial-lanes, four
-// independent accumulators per lane so the (L2-resident) partial loads overlap.  Optional
-// direct outputs dst0 / dst1 (length C) receive row 0 / row 1 of group 0 (bias / affine
-// gradients written straight into the gradient arena).
+// sums[g][k][c] = sum_b partial[g][b][k][c].  Block = COLS columns x LANES partial-lanes
+// (COLS * LANES = 256), four independent accumulators per lane so the (L2-resident) partial loads
+// overlap.  Long partial lists use 8 x 32 (a lane then walks rblocks / 32 rows: the kernel is a
+// chain of dependent load rounds, and there are ~800 of these launches per step), short ones
+// 32 x 8.  Optional direct outputs dst0 / dst1 (length C) receive row 0 / row 1 of group 0 (bias
+// / affine gradients written straight into the gradient arena).
+template <int COLS, int LANES>
 __global__ void __launch_bounds__(256)
 norm_final_reduce_kernel(const float* __restrict__ partial, int rblocks, int C, int G,
                          float* __restrict__ sums, float* __restrict__ dst0,
                          float* __restrict__ dst1) {
-  __shared__ float sh[8][33];
+  static_assert(COLS * LANES == 256, "block shape");
+  __shared__ float sh[LANES][COLS + 1];
   const int g = blockIdx.y;
-  const int col = blockIdx.x * 32 + (threadIdx.x & 31);   // index into [2][C]
-  const int lane_b = threadIdx.x >> 5;
+  const int cl = threadIdx.x % COLS;
+  const int col = blockIdx.x * COLS + cl;   // index into [2][C]
+  const int lane_b = threadIdx.x / COLS;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (col < 2 * C) {
     const float* P = partial + (int64_t)g * rblocks * 2 * C + col;
     int b = lane_b;
-    for (; b + 24 < rblocks; b += 32) {
+    for (; b + 3 * LANES < rblocks; b += 4 * LANES) {
       s0 += P[(int64_t)b * 2 * C];
-      s1 += P[(int64_t)(b + 8) * 2 * C];
-      s2 += P[(int64_t)(b + 16) * 2 * C];
-      s3 += P[(int64_t)(b + 24) * 2 * C];
+      s1 += P[(int64_t)(b + LANES) * 2 * C];
+      s2 += P[(int64_t)(b + 2 * LANES) * 2 * C];
+      s3 += P[(int64_t)(b + 3 * LANES) * 2 * C];
     }
-    for (; b < rblocks; b += 8) s0 += P[(int64_t)b * 2 * C];
+    for (; b < rblocks; b += LANES) s0 += P[(int64_t)b * 2 * C];
   }
-  sh[lane_b][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
+  sh[lane_b][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (lane_b == 0 && col < 2 * C) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += sh[i][threadIdx.x & 31];
+    for (int i = 0; i < LANES; ++i) t += sh[i][cl];
     sums[(int64_t)g * 2 * C + col] = t;
     if (g == 0) {
       if (dst0 && col < C) dst0[col] = t;
       if (dst1 && col >= C) dst1[col - C] = t;
     }
   }
+}
+
+// launch helper: block shape by the length of the partial list
+inline void launch_final_reduce(hipStream_t s, const float* partial, int rblocks, int C, int G,
+                                float* sums, float* dst0, float* dst1) {
+  if (rblocks > 32)
+    hipLaunchKernelGGL((norm_final_reduce_kernel<8, 32>), dim3((unsigned)ceil_div(2 * C, 8), (unsigned)G),
+                       dim3(256), 0, s, partial, rblocks, C, G, sums, dst0, dst1);
+  else
+    hipLaunchKernelGGL((norm_final_reduce_kernel<32, 8>), dim3((unsigned)ceil_div(2 * C, 32), (unsigned)G),
+                       dim3(256), 0, s, partial, rblocks, C, G, sums, dst0, dst1);
 }
 
 // Per-(group, channel) scale/shift from sums.  Keras SyncBatchNormalization: mean = S1/cnt,
@@ -400,8 +416,7 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
   else
     hipLaunchKernelGGL((norm_partial_kernel<T, 1, MODE>), grid, dim3(256), 0, s, a, y, x, mean,
                        rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
-  hipLaunchKernelGGL(norm_final_reduce_kernel, dim3((unsigned)ceil_div(2 * C, 32), (unsigned)G),
-                     dim3(256), 0, s, ws, rb, C, G, sums, dst0, dst1);
+  launch_final_reduce(s, ws, rb, C, G, sums, dst0, dst1);
   return check_launch("norm_partial");
 }
 
@@ -436,10 +451,8 @@ int se3ds_norm_reduce_rows(const float* partial, int64_t rows, int c, float* sum
                            size_t workspace_bytes, void* stream) {
   if (rows <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
-  const dim3 cols((unsigned)ceil_div(2 * c, 32));
   if (rows <= 2048) {
-    hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(cols.x, 1), dim3(256), 0, s, partial,
-                       (int)rows, c, 1, sums, (float*)nullptr, (float*)nullptr);
+    launch_final_reduce(s, partial, (int)rows, c, 1, sums, nullptr, nullptr);
     return check_launch("norm_reduce_rows");
   }
   // two levels: groups of kChunk rows -> workspace[groups][2][c] -> sums
@@ -450,14 +463,11 @@ int se3ds_norm_reduce_rows(const float* partial, int64_t rows, int c, float* sum
     return SE3DS_E_WORKSPACE;
   float* mid = (float*)workspace;
   if (full)
-    hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(cols.x, (unsigned)full), dim3(256), 0, s,
-                       partial, kChunk, c, (int)full, mid, (float*)nullptr, (float*)nullptr);
+    launch_final_reduce(s, partial, kChunk, c, (int)full, mid, nullptr, nullptr);
   if (tail)
-    hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(cols.x, 1), dim3(256), 0, s,
-                       partial + full * kChunk * 2 * c, (int)tail, c, 1, mid + full * 2 * c,
-                       (float*)nullptr, (float*)nullptr);
-  hipLaunchKernelGGL(norm_final_reduce_kernel, dim3(cols.x, 1), dim3(256), 0, s, mid, (int)groups, c,
-                     1, sums, (float*)nullptr, (float*)nullptr);
+    launch_final_reduce(s, partial + full * kChunk * 2 * c, (int)tail, c, 1, mid + full * 2 * c,
+                        nullptr, nullptr);
+  launch_final_reduce(s, mid, (int)groups, c, 1, sums, nullptr, nullptr);
   return check_launch("norm_reduce_rows");
 }
 
