@@ -351,6 +351,12 @@ int se3ds_mean_clipped_norm(const float* sqnorm, int ntensors, float clip_norm, 
 int se3ds_multi_adam_keras(float* params, const float* grads, float* m, float* v, int64_t n,
                            float lr, float beta1, float beta2, float eps, int64_t step,
                            void* stream);
+/* The same, and the EMA copy of the parameters advanced in the same pass (ema may be NULL):
+ * ema -= (ema - params_new) * one_minus_decay  (utils/ema.py:54-88 applied to the trainable
+ * variables right where they are produced). */
+int se3ds_multi_adam_keras_ema(float* params, const float* grads, float* m, float* v, int64_t n,
+                               float lr, float beta1, float beta2, float eps, int64_t step,
+                               float* ema, float one_minus_decay, void* stream);
 /* ema -= (ema - vars) * one_minus_decay */
 int se3ds_multi_ema(float* ema, const float* vars, int64_t n, float one_minus_decay, void* stream);
 

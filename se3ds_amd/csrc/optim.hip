@@ -92,6 +92,24 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
   }
 }
 
+// The same with the generator's EMA copy advanced in the same pass (saves re-reading theta):
+// ema -= (ema - p_new) * omd, exactly what ema_kernel computes afterwards.
+__global__ void __launch_bounds__(kB)
+adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                float* __restrict__ v, int64_t n, float alpha, float b1, float b2, float eps,
+                float* __restrict__ ema, float omd) {
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)gridDim.x * kB) {
+    float gi = g[i];
+    float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+    m[i] = mi;
+    v[i] = vi;
+    const float pn = p[i] - (mi * alpha) / (sqrtf(vi) + eps);
+    p[i] = pn;
+    ema[i] = ema[i] - (ema[i] - pn) * omd;
+  }
+}
+
 __global__ void __launch_bounds__(kB)
 ema_kernel(float* __restrict__ ema, const float* __restrict__ var, int64_t n, float omd) {
   for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)gridDim.x * kB)
@@ -297,6 +315,20 @@ int se3ds_multi_adam_keras(float* params, const float* grads, float* m, float* v
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, kB)), dim3(kB), 0, as_stream(stream), params,
                      grads, m, v, n, alpha, beta1, beta2, eps);
   return check_launch("multi_adam_keras");
+}
+
+int se3ds_multi_adam_keras_ema(float* params, const float* grads, float* m, float* v, int64_t n,
+                               float lr, float beta1, float beta2, float eps, int64_t step,
+                               float* ema, float one_minus_decay, void* stream) {
+  if (ema == nullptr)
+    return se3ds_multi_adam_keras(params, grads, m, v, n, lr, beta1, beta2, eps, step, stream);
+  if (n <= 0) return SE3DS_OK;
+  float b1p = 1.0f, b2p = 1.0f;
+  for (int64_t i = 0; i < step; ++i) { b1p *= beta1; b2p *= beta2; }
+  float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_for(n, kB)), dim3(kB), 0, as_stream(stream), params,
+                     grads, m, v, n, alpha, beta1, beta2, eps, ema, one_minus_decay);
+  return check_launch("multi_adam_keras_ema");
 }
 
 int se3ds_multi_ema(float* ema, const float* vars, int64_t n, float one_minus_decay,

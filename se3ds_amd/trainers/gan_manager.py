@@ -5,6 +5,7 @@ pipelines, TensorFlow checkpoint bundles, TensorBoard
 logging and the FID evaluation loop of the reference are out of scope (SURVEY.md section 2.1);
 `train()` runs the same host loop on a synthetic (or user supplied) batch iterator."""
 import abc
+import os
 import random
 from typing import Optional
 
@@ -96,17 +97,18 @@ class AdamState:
         self.mean_norm.data_ptr(), _lib.stream()), 'se3ds_mean_clipped_norm')
     return self.mean_norm
 
-  def apply_gradients(self, group=None, world=1):
+  def apply_gradients(self, group=None, world=1, ema_theta=None, one_minus_decay=0.0):
     """Cross-replica SUM of the (already clipped, already 1/R-scaled) gradients, then the
-    Keras Adam update (reference se3ds_trainer.py:253-257)."""
+    Keras Adam update (reference se3ds_trainer.py:253-257).  With `ema_theta` (the EMA model's
+    trainable arena) the moving average of these variables is advanced in the same pass."""
     st = self.model.store
     if world > 1:
       dist_utils.allreduce_arena_sum(st.grad, group)
     self.iterations += 1
-    _lib.check(_lib.lib().se3ds_multi_adam_keras(
+    _lib.check(_lib.lib().se3ds_multi_adam_keras_ema(
         st.theta.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
         st.theta.numel(), self.lr, self.beta_1, self.beta_2, self.epsilon, self.iterations,
-        _lib.stream()), 'se3ds_multi_adam_keras')
+        _lib.ptr(ema_theta), float(one_minus_decay), _lib.stream()), 'se3ds_multi_adam_keras_ema')
     st.version += 1
 
 
@@ -346,12 +348,23 @@ class GANManager(abc.ABC):
       return self.load_state_dict({k: f[k] for k in f.files}, strict=strict)
 
   # ---------------------------------------------------------------------------------- EMA
-  def update_ema_model(self):
-    """reference :642-651."""
+  def ema_fused_args(self):
+    """(ema arena, 1 - decay) for AdamState.apply_gradients when this step's update_ema_model
+    will be a moving-average step (not the copy phase), else (None, 0)."""
+    if (os.environ.get('SE3DS_UNFUSED_EMA') != '1' and
+        self.global_step >= self.ema_init_step + self.num_batched_steps):
+      return self.ema_generator.store.theta, 1.0 - self.ema_decay
+    return None, 0.0
+
+  def update_ema_model(self, theta_done=False):
+    """reference :642-651.  theta_done: the trainable variables were already averaged by the
+    optimiser pass (ema_fused_args); only the non-trainable ones are left."""
     if self.global_step >= self.ema_init_step:
       if self.global_step >= self.ema_init_step + self.num_batched_steps:
-        ema.update_ema_variables(self.ema_generator, self.generator, self.ema_decay)
+        ema.update_ema_variables(self.ema_generator, self.generator, self.ema_decay,
+                                 skip_trainable=theta_done)
       else:
+        assert not theta_done
         self.assign_ema_model_first_time()
 
   def assign_ema_model_first_time(self):

@@ -249,12 +249,13 @@ class GAN(gan_manager.GANManager):
     push_rgb(d_rgb)
     push_depth(d_depth)
     # ---- clip per tensor (per replica), aggregate, apply (:238-257)
+    ema_theta, ema_omd = self.ema_fused_args()   # EMA of the trainable variables rides on Adam
     if sync is None:
       ctx_g.backward()
       G.spectral.backward_fixup()
       g_norm = self.g_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
       d_norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
-      self.g_optimizer.apply_gradients(group, R)
+      self.g_optimizer.apply_gradients(group, R, ema_theta, ema_omd)
       self.d_optimizer.apply_gradients(group, R)
     else:
       # a module's gradients are fixed up, clipped and handed to the side stream as soon as
@@ -271,12 +272,12 @@ class GAN(gan_manager.GANManager):
       ctx_g.on_segment = None
       g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
       sync.finish()
-      self.g_optimizer.apply_gradients(group, 1)
+      self.g_optimizer.apply_gradients(group, 1, ema_theta, ema_omd)
       self.d_optimizer.apply_gradients(group, 1)
     if self.global_step == 0:
       # builds the EMA model's variables in the reference (:258-259): a throw-away forward
       self.ema_generator.forward(self.ema_generator.make_ctx(training=True, group=group), inputs)
-    self.update_ema_model()
+    self.update_ema_model(theta_done=ema_theta is not None)
 
     # ---- metrics (:261-273); values are resolved when read
     lam_d = self.lambda_depth if self.predict_depth else 0.0

@@ -13,12 +13,13 @@ def assign_ema_vars_from_initial_values(ema_model, model):
   ema_model.store.version += 1
 
 
-def update_ema_variables(ema_model, model, ema_decay):
-  """ema_var -= (1 - ema_decay) * (ema_var - var)  (reference :54-88)."""
+def update_ema_variables(ema_model, model, ema_decay, skip_trainable=False):
+  """ema_var -= (1 - ema_decay) * (ema_var - var)  (reference :54-88).  skip_trainable: the
+  optimiser pass already advanced the trainable arena (se3ds_multi_adam_keras_ema)."""
   omd = 1.0 - ema_decay
   L = _lib.lib()
-  for e, v in ((ema_model.store.theta, model.store.theta),
-               (ema_model.store.state, model.store.state)):
+  pairs = ((ema_model.store.theta, model.store.theta), (ema_model.store.state, model.store.state))
+  for e, v in pairs[1:] if skip_trainable else pairs:
     _lib.check(L.se3ds_multi_ema(e.data_ptr(), v.data_ptr(), e.numel(), omd, _lib.stream()),
                'se3ds_multi_ema')
   ema_model.store.version += 1

@@ -535,10 +535,10 @@ def test_train_g_d_gradients_and_update_fp32():
   captured = {}
   for opt, tag in ((gan.g_optimizer, 'g'), (gan.d_optimizer, 'd')):
     orig = opt.apply_gradients
-    def wrap(group=None, world=1, _orig=orig, _opt=opt, _tag=tag):
+    def wrap(*args, _orig=orig, _opt=opt, _tag=tag, **kw):
       captured[_tag] = {n: _opt.model.store.grad_views[n].detach().cpu().numpy().copy()
                         for n in _opt.model.store.trainable_names}
-      return _orig(group, world)
+      return _orig(*args, **kw)
     opt.apply_gradients = wrap
   gan.train_g_d({k: v.to(DEV) for k, v in batch.items()})
   # Training-mode gradients of this toy network are noise-limited in fp32 (see fp64_oracle):
@@ -811,3 +811,22 @@ def test_partial_conv_fractional_mask_exact_path(cin):
   assert rel_err(xv.grad.cpu().numpy(), xo.grad.numpy()) < 1e-4
   assert rel_err(store.grad_views['c/kernel'].cpu().numpy(), p['c/kernel'].grad.numpy()) < 1e-4
   assert rel_err(store.grad_views['c/bias'].cpu().numpy(), p['c/bias'].grad.numpy()) < 1e-3
+
+
+def test_fused_adam_ema_is_bit_identical(monkeypatch):
+  """The generator's EMA advanced inside the Adam pass (se3ds_multi_adam_keras_ema) leaves exactly
+  the EMA copy that the separate se3ds_multi_ema pass produces."""
+  size = 64
+  batch = {k: v.to(DEV) for k, v in synth_batch(2, size, seed=91).items()}
+  res = {}
+  for mode in ('0', '1'):
+    monkeypatch.setenv('SE3DS_UNFUSED_EMA', mode)
+    gan = _make_gan(size, 8, '50', 3)
+    for _ in range(3):   # step 0 copies, steps 1 and 2 average
+      gan.train_g_d(batch)
+      gan.global_step += 1
+    res[mode] = (gan.ema_generator.store.theta.clone(), gan.ema_generator.store.state.clone(),
+                 gan.generator.store.theta.clone())
+  for a, b in zip(res['0'], res['1']):
+    assert torch.equal(a, b)
+  assert not torch.equal(res['0'][0], res['0'][2])   # the average lags the weights
