@@ -2770,11 +2770,7 @@ thin_cout_fwd_kernel(const IgemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
   const int tiles_x = ceil_div(p.oW, kThinCols), tiles_y = ceil_div(p.oH, kThinRows);
-  int b = blockIdx.x;
-  const int tx = b % tiles_x;
-  b /= tiles_x;
-  const int ty = b % tiles_y, n = b / tiles_y;
-  const int oy0 = ty * kThinRows, ox0 = tx * kThinCols;
+  const int64_t n_tiles = (int64_t)p.N * tiles_y * tiles_x;
   const uint16_t* __restrict__ src = (const uint16_t*)p.src;
   {
     const uint16_t* __restrict__ w = (const uint16_t*)p.w;   // wt [oC][K]
@@ -2785,36 +2781,52 @@ thin_cout_fwd_kernel(const IgemmParams p) {
           *reinterpret_cast<const uint4*>(w + (int64_t)co * K + c * 8);
     }
   }
-  {
-    const int cpp = C / 8;   // 16-byte chunks per pixel
-    const int total = kThinPH * kThinPW * cpp;
-    constexpr int kB = 7;    // loads in flight per thread (a 128-channel patch is two trips)
-    for (int i0 = tid; i0 < total; i0 += kB * 256) {
-      uint4 v[kB];
-      int dst[kB];
+  // Persistent workgroups; the next tile's patch is fetched into registers (NV 16-byte chunks
+  // per thread, Cin <= 128) while the current one is computed, and parked in LDS afterwards.
+  constexpr int NV = (kThinPH * kThinPW * 16 + 255) / 256;
+  const int cpp = C / 8;   // 16-byte chunks per pixel
+  const int total = kThinPH * kThinPW * cpp;
+  uint4 nxt[NV];
+  auto fetch = [&](int64_t tile) {
+    int64_t b = tile;
+    const int tx = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
+    const int oy0 = ty * kThinRows, ox0 = tx * kThinCols;
 #pragma unroll
-      for (int u = 0; u < kB; ++u) {
-        const int i = i0 + u * 256;
-        v[u] = make_uint4(0u, 0u, 0u, 0u);
-        dst[u] = -1;
-        if (i < total) {
-          const int pix = i / cpp, c = i - pix * cpp;
-          const int r = pix / kThinPW, q = pix - r * kThinPW;
-          const int sy = oy0 - p.pad_t + r;
-          int sx = ox0 - p.pad_l + q;
-          if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
-          dst[u] = pix * pstride + c * 16;
-          if (sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW)
-            v[u] = *reinterpret_cast<const uint4*>(
-                src + (((int64_t)n * p.sH + sy) * p.sW + sx) * C + c * 8);
-        }
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * 256;
+      nxt[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < total) {
+        const int pix = i / cpp, c = i - pix * cpp;
+        const int r = pix / kThinPW, q = pix - r * kThinPW;
+        const int sy = oy0 - p.pad_t + r;
+        int sx = ox0 - p.pad_l + q;
+        if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+        if (sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW)
+          nxt[u] = *reinterpret_cast<const uint4*>(
+              src + (((int64_t)n * p.sH + sy) * p.sW + sx) * C + c * 8);
       }
+    }
+  };
+  if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  int64_t b = tile;
+  const int tx = (int)(b % tiles_x);
+  b /= tiles_x;
+  const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
+  const int oy0 = ty * kThinRows, ox0 = tx * kThinCols;
+  __syncthreads();   // the previous tile's fragments are read (and, the first time, ws is written)
 #pragma unroll
-      for (int u = 0; u < kB; ++u)
-        if (dst[u] >= 0) *reinterpret_cast<uint4*>(xs + dst[u]) = v[u];
+  for (int u = 0; u < NV; ++u) {
+    const int i = tid + u * 256;
+    if (i < total) {
+      const int pix = i / cpp, c = i - pix * cpp;
+      *reinterpret_cast<uint4*>(xs + pix * pstride + c * 16) = nxt[u];
     }
   }
   __syncthreads();
+  if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
   f32x16_t acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -2854,6 +2866,7 @@ thin_cout_fwd_kernel(const IgemmParams p) {
         else if (p.act == 2) t = t > 0.f ? t : t * p.act_alpha;
         out[c] = f32_to_bf16(t);
       }
+  }
   }
 }
 
@@ -3059,7 +3072,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
     return check_launch("conv2d_dgrad(thin)");
   }
   if (mode == MODE_FWD && dtype == SE3DS_BF16 && kh == 3 && kw == 3 && stride == 1 && cout <= 4 &&
-      (cin % 64) == 0 && cin <= 256 && src_mask == nullptr && row_a == nullptr &&
+      (cin % 64) == 0 && cin <= 128 && src_mask == nullptr && row_a == nullptr &&
       stats == nullptr && addend == nullptr && !getenv("SE3DS_NO_THIN_FWD")) {
     const size_t lds = thin_lds_bytes(cin, cout);
     static size_t lds_set = 0;
@@ -3069,7 +3082,8 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
         return SE3DS_E_LAUNCH;
       lds_set = lds;
     }
-    const int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinRows) * ceil_div(p.oW, kThinCols);
+    int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinRows) * ceil_div(p.oW, kThinCols);
+    if (blocks > 2 * 256) blocks = 2 * 256;   // persistent: two workgroups per CU
     hipLaunchKernelGGL(thin_cout_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds, s, p);
     return check_launch("conv2d_fwd(thin)");
   }
