@@ -2499,6 +2499,30 @@ thin_cout_wgrad_kernel(const ThinCoutWgradParams p) {
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
   const int tiles_x = ceil_div(p.W, kThinCols), tiles_y = ceil_div(p.H, kThinQRows);
   const int64_t n_tiles = (int64_t)p.N * tiles_y * tiles_x;
+  // the next tile's x patch is fetched into registers while the current one is computed
+  constexpr int NV = (PH * PW * 16 + NT - 1) / NT;   // Cin <= 128: 16 chunks of 16 bytes per pixel
+  const int cpp = Ci / 8, total = PH * PW * cpp;
+  uint4 nxt[NV];
+  auto fetch = [&](int64_t tile) {
+    int64_t b = tile;
+    const int tx = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
+    const int oy0 = ty * kThinQRows, ox0 = tx * kThinCols;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * NT;
+      nxt[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < total) {
+        const int pix = i / cpp, c = i - pix * cpp;
+        const int r = pix / PW, q = pix - r * PW;
+        const int sy = oy0 - p.pad + r, sx = ox0 - p.pad + q;
+        if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
+          nxt[u] = *reinterpret_cast<const uint4*>(p.x + (((int64_t)n * p.H + sy) * p.W + sx) * Ci + c * 8);
+      }
+    }
+  };
+  if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     int64_t b = tile;
     const int tx = (int)(b % tiles_x);
@@ -2511,34 +2535,16 @@ thin_cout_wgrad_kernel(const ThinCoutWgradParams p) {
       const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
       dys[i] = (oy < p.H && ox < p.W) ? p.dy[(((int64_t)n * p.H + oy) * p.W + ox) * Co + c] : (uint16_t)0;
     }
-    {
-      const int cpp = Ci / 8, total = PH * PW * cpp;
-      constexpr int kB = 6;
-      for (int i0 = tid; i0 < total; i0 += kB * NT) {
-        uint4 v[kB];
 #pragma unroll
-        for (int u = 0; u < kB; ++u) {
-          const int i = i0 + u * NT;
-          v[u] = make_uint4(0u, 0u, 0u, 0u);
-          if (i < total) {
-            const int pix = i / cpp, c = i - pix * cpp;
-            const int r = pix / PW, q = pix - r * PW;
-            const int sy = oy0 - p.pad + r, sx = ox0 - p.pad + q;
-            if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
-              v[u] = *reinterpret_cast<const uint4*>(p.x + (((int64_t)n * p.H + sy) * p.W + sx) * Ci + c * 8);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kB; ++u) {
-          const int i = i0 + u * NT;
-          if (i < total) {
-            const int pix = i / cpp, c = i - pix * cpp;
-            *reinterpret_cast<uint4*>(xs + pix * PB + c * 16) = v[u];
-          }
-        }
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * NT;
+      if (i < total) {
+        const int pix = i / cpp, c = i - pix * cpp;
+        *reinterpret_cast<uint4*>(xs + pix * PB + c * 16) = nxt[u];
       }
     }
     __syncthreads();
+    if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
     for (int sidx = 0; sidx < PX / 16; ++sidx) {
       const int row = sidx >> 1, cs = (sidx & 1) * 16;
       // A: dy[px][co], 8 pixels of this lane's output channel (rows co >= Cout are zero)
