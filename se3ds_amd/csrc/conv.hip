@@ -2100,6 +2100,34 @@ thin_cout_dgrad_kernel(const IgemmParams p) {
     }
     wk[ci][k] = v;
   }
+  // dy patch: row r <-> sy = oy0 + pad_t - 2 + r, column q <-> sx = ox0 + pad_l - 2 + q; the
+  // next tile's patch (PH * PW * Cout <= 1360 values) is fetched into registers during the
+  // current tile's MFMAs and stores
+  constexpr int NV = (PH * PW * 4 + 255) / 256;
+  const int total = PH * PW * Co;
+  uint16_t nxt[NV];
+  auto fetch = [&](int64_t tile) {
+    int64_t b = tile;
+    const int tx = (int)(b % tiles_x);
+    b /= tiles_x;
+    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
+    const int oy0 = ty * kThinDRows, ox0 = tx * kThinCols;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * 256;
+      nxt[u] = 0;
+      if (i < total) {
+        const int pix = i / Co, c = i - pix * Co;
+        const int r = pix / PW, q = pix - r * PW;
+        const int sy = oy0 + p.pad_t - 2 + r;
+        int sx = ox0 + p.pad_l - 2 + q;
+        if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+        if (sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW)
+          nxt[u] = dy[(((int64_t)n * p.sH + sy) * p.sW + sx) * Co + c];
+      }
+    }
+  };
+  if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
   int64_t b = tile;
   const int tx = (int)(b % tiles_x);
@@ -2107,33 +2135,12 @@ thin_cout_dgrad_kernel(const IgemmParams p) {
   const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
   const int oy0 = ty * kThinDRows, ox0 = tx * kThinCols;
   __syncthreads();   // the previous tile's patch is consumed
-  // dy patch: row r <-> sy = oy0 + pad_t - 2 + r, column q <-> sx = ox0 + pad_l - 2 + q
-  {
-    constexpr int kB = 4;
-    const int total = PH * PW * Co;
-    for (int i0 = tid; i0 < total; i0 += kB * 256) {
-      uint16_t v[kB];
 #pragma unroll
-      for (int u = 0; u < kB; ++u) {
-        const int i = i0 + u * 256;
-        v[u] = 0;
-        if (i < total) {
-          const int pix = i / Co, c = i - pix * Co;
-          const int r = pix / PW, q = pix - r * PW;
-          const int sy = oy0 + p.pad_t - 2 + r;
-          int sx = ox0 + p.pad_l - 2 + q;
-          if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
-          if (sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW)
-            v[u] = dy[(((int64_t)n * p.sH + sy) * p.sW + sx) * Co + c];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kB; ++u)
-        if (i0 + u * 256 < total) dys[i0 + u * 256] = v[u];
-    }
-  }
+  for (int u = 0; u < NV; ++u)
+    if (tid + u * 256 < total) dys[tid + u * 256] = nxt[u];
+  __syncthreads();   // patch (and, the first time, the weights) are in place
+  if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
   for (int g = 0; g < Ci; g += NI * 32) {
-    if (g == 0) __syncthreads();   // patch (and, the first time, the weights) are in place
     f32x16_t acc[NI][2];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
