@@ -2,7 +2,11 @@
 
   python bench.py --gpus N --steps K --warmup W [--workload gan_step|warp]
 
-Prints ONE JSON line on rank 0 (contract in the task statement).  Workloads:
+Prints ONE JSON line on rank 0 (contract in the task statement).  With --gpus N > 1 and no
+torchrun environment, this process only LAUNCHES `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a child (before anything touches the GPU) and relays its
+output: one rank per GPU over RCCL, as the reference picks its strategy from the device count
+(main.py:55-63).  Under torchrun, WORLD_SIZE must equal --gpus.  Workloads:
   gan_step  (default) one G+D train step (train_g_d) at 512x1024 RGB-D, bf16 compute,
             random-init ResNet-101 G / multi-scale SN-PatchGAN D, synthetic panoramas.
             metric = panoramas/sec.  Data-parallel over ranks (weak scaling).
@@ -48,6 +52,22 @@ def _dist_setup(ngpus):
     else:
       dist.init_process_group(backend, rank=rank, world_size=world)
   return rank, world, local
+
+
+def _launch_ranks(n):
+  """--gpus N without a torchrun environment: start N ranks as a CHILD process (never exec: this
+  must also work from a process that has initialised the GPU) and relay its output."""
+  import socket
+  import subprocess
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + \
+      sys.argv[1:]
+  return subprocess.run(cmd, env=env).returncode
 
 
 def _barrier(world):
@@ -206,7 +226,12 @@ def main():
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   args = ap.parse_args()
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    sys.exit(_launch_ranks(args.gpus))
   rank, world, local = _dist_setup(args.gpus)
+  if world != args.gpus:
+    raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with '
+                     f'--nproc-per-node {args.gpus} (or without torchrun: bench.py spawns the ranks)')
   dev = torch.device('cuda', local)
   workload = args.workload
   if workload is None:

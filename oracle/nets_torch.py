@@ -420,10 +420,34 @@ def clip_by_norm(g, clip=5.0):
 
 
 def adam_keras(p, g, m, v, lr, b1, b2, step, eps=1e-7):
-  alpha = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
-  m = m + (g - m) * (1 - b1)
-  v = v + (g * g - v) * (1 - b2)
+  """Keras Adam (optimizer_v2/adam.py -> ResourceApplyAdam, training_ops.cc): hyper-parameters
+  are tensors of the VARIABLE's dtype, so 1 - beta and beta^t are taken in that dtype
+  (1 - 0.999f = 0.00100004673, not 0.001); alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t)."""
+  t = lambda x: torch.tensor(x, dtype=p.dtype)
+  b1t, b2t, lrt = t(b1), t(b2), t(lr)
+  alpha = lrt * torch.sqrt(1 - torch.pow(b2t, step)) / (1 - torch.pow(b1t, step))
+  m = m + (g - m) * (1 - b1t)
+  v = v + (g * g - v) * (1 - b2t)
   return p - (m * alpha) / (torch.sqrt(v) + eps), m, v
+
+
+def ema_update(ema_var, value, ema_decay):
+  """utils/ema.py:54-64: ema_var.assign_sub((ema_var - value) * (1.0 - ema_decay)); the Python
+  float `1.0 - ema_decay` is converted to the variable's dtype by the multiplication."""
+  one_minus_decay = 1.0 - ema_decay
+  return ema_var - (ema_var - value) * one_minus_decay
+
+
+def ema_step(ema_vars, new_values, global_step, ema_decay, ema_init_step, num_batched_steps):
+  """gan_manager.py:642-655 over dicts of ALL generator variables (trainable, BN moving
+  statistics, spectral u): hard copy while global_step < ema_init_step + num_batched_steps
+  (global_step only advances on the host once per cluster, :421), moving average afterwards;
+  untouched before ema_init_step."""
+  if global_step < ema_init_step:
+    return dict(ema_vars)
+  if global_step >= ema_init_step + num_batched_steps:
+    return {k: ema_update(ema_vars[k], new_values[k], ema_decay) for k in ema_vars}
+  return {k: new_values[k].clone() for k in ema_vars}
 
 
 def wc_loss(gen, real, mask):

@@ -6,6 +6,7 @@
 //   ema    utils/ema.py:54-64
 //   SN     models/layers.py:312-331 (power iteration), gradient through sigma = v W u^T
 #include "common.h"
+#include <cmath>
 
 namespace se3ds {
 namespace {
@@ -269,6 +270,15 @@ sn_fix_kernel(const int64_t* __restrict__ tab) {
 
 using namespace se3ds;
 
+// Keras Adam step size: lr * sqrt(1 - beta2^t) / (1 - beta1^t) with the powers taken by ONE pow
+// each (tf.pow in optimizer_v2/adam.py), not by a t-step product: O(1) host work at any step
+// count and no accumulated rounding drift.  Evaluated in double, rounded once per fp32 op.
+static float adam_alpha(float lr, float beta1, float beta2, int64_t step) {
+  float b1p = (float)pow((double)beta1, (double)step);
+  float b2p = (float)pow((double)beta2, (double)step);
+  return lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+}
+
 extern "C" {
 
 int se3ds_multi_sqnorm(const float* grads, const int64_t* chunks, int64_t nchunks,
@@ -308,10 +318,7 @@ int se3ds_multi_adam_keras(float* params, const float* grads, float* m, float* v
                            float lr, float beta1, float beta2, float eps, int64_t step,
                            void* stream) {
   if (n <= 0) return SE3DS_OK;
-  // alpha = lr * sqrt(1 - beta2^t) / (1 - beta1^t), computed in fp32 like the Keras optimizer
-  float b1p = 1.0f, b2p = 1.0f;
-  for (int64_t i = 0; i < step; ++i) { b1p *= beta1; b2p *= beta2; }
-  float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  float alpha = adam_alpha(lr, beta1, beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, kB)), dim3(kB), 0, as_stream(stream), params,
                      grads, m, v, n, alpha, beta1, beta2, eps);
   return check_launch("multi_adam_keras");
@@ -323,9 +330,7 @@ int se3ds_multi_adam_keras_ema(float* params, const float* grads, float* m, floa
   if (ema == nullptr)
     return se3ds_multi_adam_keras(params, grads, m, v, n, lr, beta1, beta2, eps, step, stream);
   if (n <= 0) return SE3DS_OK;
-  float b1p = 1.0f, b2p = 1.0f;
-  for (int64_t i = 0; i < step; ++i) { b1p *= beta1; b2p *= beta2; }
-  float alpha = lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  float alpha = adam_alpha(lr, beta1, beta2, step);
   hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_for(n, kB)), dim3(kB), 0, as_stream(stream), params,
                      grads, m, v, n, alpha, beta1, beta2, eps, ema, one_minus_decay);
   return check_launch("multi_adam_keras_ema");

@@ -203,7 +203,7 @@ class Ctx:
   """Per-call execution context: compute dtype, training flag, tape, replica group."""
 
   def __init__(self, device, dtype=torch.float32, training=False, record=False,
-               group=None):
+               group=None, world=None):
     self.device = torch.device(device)
     self.dtype = dtype
     self.code = _lib.dtype_code(torch.empty(0, dtype=dtype))
@@ -216,8 +216,12 @@ class Ctx:
     self.on_segment = None    # callback(name): a top-level module's parameter gradients are final
     self.batch_limit = None   # backward passes that only concern the first samples of the batch
     self.group = group
-    self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) \
-        else 1
+    # Replica count of the STRATEGY that built the model, never probed from global
+    # torch.distributed state: a one-device model inside an initialised process group must not
+    # all-reduce its batch-norm sums.  world=None with a group means "that group's size".
+    if world is None:
+      world = dist.get_world_size(group) if group is not None else 1
+    self.world = int(world)
     self._ws = {}
 
   def ws(self, key, nbytes):

@@ -56,9 +56,11 @@ class _Model:
   def variables(self):
     return [self.store[n] for n in self.store.trainable_names + self.store.state_names]
 
-  def make_ctx(self, training, record=False, group=None, dtype=None) -> Ctx:
+  def make_ctx(self, training, record=False, group=None, dtype=None, world=1) -> Ctx:
+    """`world` = strategy.num_replicas_in_sync (SyncBatchNormalization sums over that many
+    replicas of `group`; None = the default process group)."""
     return Ctx(self.device, dtype or self.dtype, training=bool(training), record=record,
-               group=group)
+               group=group, world=world)
 
 
 # --------------------------------------------------------------------------------- encoder

@@ -112,10 +112,6 @@ class InstanceNormalization:
     return nn.norm_act(ctx, x, self.norm, act=act, alpha=alpha)
 
 
-def _conv_cls(conv_fn):
-  return conv_fn
-
-
 class Bottleneck:
   """ResNet bottleneck block (reference :220-272)."""
 

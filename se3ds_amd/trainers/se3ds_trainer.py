@@ -111,10 +111,13 @@ class GAN(gan_manager.GANManager):
     if getattr(self, '_sync', None) is None:
       G = self.generator
       group = self.strategy.group
-      if R > 1 and os.environ.get('SE3DS_GRAD_SYNC_SHARED_COMM') != '1':
-        # own communicator: the 4.5 GB of gradient traffic must not queue ahead of the small
-        # SyncBN statistics all-reduces the backward pass is waiting on (same issue order on
-        # every rank, so the two communicators cannot cross)
+      if R > 1 and os.environ.get('SE3DS_GRAD_SYNC_OWN_COMM') == '1':
+        # opt-in: a second communicator keeps the 4.5 GB of gradient traffic from queueing ahead
+        # of the small SyncBN statistics all-reduces the backward pass waits on.  Two RCCL
+        # communicators in flight on one device are only safe when every rank issues them in the
+        # same order (true here: the program is deterministic) AND the device can co-schedule
+        # both kernels; until that is validated on an 8-GPU node the default is the shared
+        # communicator, where collectives simply serialise in issue order.
         group = dist_utils.clone_group(group)
         # build the communicator now, at a point every rank reaches together, instead of
         # lazily at the first bucket in the middle of the backward pass
@@ -157,7 +160,7 @@ class GAN(gan_manager.GANManager):
     sync = self._grad_sync()   # (first call builds the gradient communicator: do it up front)
 
     # ---- generator forward (both "tapes" of the reference share this forward)
-    ctx_g = G.make_ctx(training=True, record=True, group=group)
+    ctx_g = G.make_ctx(training=True, record=True, group=group, world=R)
     outs, (push_rgb, push_depth) = G.forward(ctx_g, inputs)
     depth_out, generated = outs[3], outs[6]
 
@@ -207,7 +210,7 @@ class GAN(gan_manager.GANManager):
                'se3ds_sample_sum')
 
     # ---- discriminator forward on [fake; real]
-    ctx_d = D.make_ctx(training=True, record=True, group=group)
+    ctx_d = D.make_ctx(training=True, record=True, group=group, world=R)
     x_all = self._disc_input(ctx_d, generated, depth_out, image, depth_t)
     logits = self._run_discriminator(ctx_d, x_all)
     n_dis = len(logits)
@@ -276,7 +279,7 @@ class GAN(gan_manager.GANManager):
       self.d_optimizer.apply_gradients(group, 1)
     if self.global_step == 0:
       # builds the EMA model's variables in the reference (:258-259): a throw-away forward
-      self.ema_generator.forward(self.ema_generator.make_ctx(training=True, group=group), inputs)
+      self.ema_generator.forward(self.ema_generator.make_ctx(training=True, group=group, world=R), inputs)
     self.update_ema_model(theta_done=ema_theta is not None)
 
     # ---- metrics (:261-273); values are resolved when read
@@ -316,10 +319,10 @@ class GAN(gan_manager.GANManager):
     group = self.strategy.group
     G, D = self.generator, self.discriminator
     # generator forward in training mode, outside any tape (:292-293)
-    ctx_g = G.make_ctx(training=True, record=False, group=group)
+    ctx_g = G.make_ctx(training=True, record=False, group=group, world=R)
     outs, _ = G.forward(ctx_g, inputs)
     depth_out, generated = outs[3], outs[6]
-    ctx_d = D.make_ctx(training=True, record=True, group=group)
+    ctx_d = D.make_ctx(training=True, record=True, group=group, world=R)
     x_all = self._disc_input(ctx_d, generated, depth_out, image, depth_t)
     logits = self._run_discriminator(ctx_d, x_all)
     coef_d = self.lambda_gan / (len(logits) * R)

@@ -1,6 +1,10 @@
 """Worker of tests/test_dist_gpu.py: two ranks share cuda:0 and talk over gloo (RCCL refuses two
-ranks on one device); the trainer path is the multi-replica one: SyncBN statistics all-reduce,
-per-module clip + side-stream gradient all-reduce on its own process group, Adam on the sum."""
+ranks on one device).  The trainer path is the multi-replica one -- SyncBN statistics all-reduce,
+per-module clip + side-stream gradient all-reduce, Adam on the sum -- and the PRODUCT's summed,
+per-replica-clipped gradient is compared with the R-replica oracle (statistics pooled
+over the replicas as SyncBatchNormalization does, per-replica loss / backward / per-tensor clip,
+then the sum; se3ds_trainer.py:230-257)."""
+import faulthandler
 import os
 import sys
 
@@ -9,15 +13,53 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import nets_torch as O  # noqa: E402
 from se3ds_amd import gin_lite  # noqa: E402
 from se3ds_amd.models import image_models  # noqa: E402
 from se3ds_amd.trainers import dist_utils, gan_manager, se3ds_trainer  # noqa: E402
 from tests.test_nets_gpu import synth_batch  # noqa: E402
 
 
+def _pooled_hook(world):
+  def pooled(name, s1, s2, cnt):   # SyncBN: statistics over all replicas
+    t = torch.stack([s1.detach(), s2.detach()])
+    dist.all_reduce(t)
+    # values of the cross-replica sum, gradient of the local contribution (as TF's tape sees
+    # the all-reduce inside SyncBatchNormalization)
+    return s1 + (t[0] - s1.detach()), s2 + (t[1] - s2.detach()), cnt * world
+  return pooled
+
+
+def _oracle_sum(gp, dp, shard, world, double):
+  cfg = dict(gen=dict(gen_dims=8, resnet_version='50', context_layer='convs', z_dim=4,
+                      stats_hook=_pooled_hook(world)),
+             dis=dict(n_dis=2, n_layers=3, kernel_size=4), lambda_gan=1.0, lambda_kld=10.0,
+             lambda_wc=10.0, lambda_depth=100.0, mask_blurred=True,
+             g_train=lambda k: not k.endswith(('/u', '/moving_mean', '/moving_variance')),
+             d_train=lambda k: not k.endswith('/u'))
+  if double:
+    torch.set_default_dtype(torch.float64)
+    conv = lambda d: {k: (v.double() if v.is_floating_point() else v) for k, v in d.items()}
+    gp, dp, shard = conv(gp), conv(dp), conv(shard)
+  try:
+    ref = O.train_g_d(gp, dp, shard, cfg, replicas=world)
+  finally:
+    torch.set_default_dtype(torch.float32)
+  out = {}
+  for key in ('g_grads', 'd_grads'):
+    names = list(ref[key])
+    flat = torch.cat([ref[key][k].reshape(-1) for k in names])
+    assert max(float(ref[key][k].norm()) for k in names) <= 5.0 + 1e-4   # clipped per replica
+    dist.all_reduce(flat)   # SUM of the per-replica clipped gradients
+    out[key] = (names, [tuple(ref[key][k].shape) for k in names], flat)
+  out['mm'] = ref['g_updates']['encoder/bn1/moving_mean']
+  return out
+
+
 def main():
-  import signal
-  signal.alarm(200)   # never outlive the test: a failed peer would leave this rank in a collective
+  # a hang must be visible: dump every thread's stack, then die with a non-zero status
+  faulthandler.enable()
+  faulthandler.dump_traceback_later(170, exit=True)
   dist.init_process_group('gloo')
   rank, world = dist.get_rank(), dist.get_world_size()
   dev = 'cuda:0'
@@ -39,13 +81,57 @@ image_models.SNMultiScaleDiscriminator.n_layers = 3
       discriminator_fn=image_models.SNMultiScaleDiscriminator, seed=0, compute_dtype=torch.float32)
   gan._create_obj()
   full = synth_batch(2 * world, 64, seed=91)
-  batch = {k: v.to(dev) for k, v in dist_utils.shard_batch(full, rank, world).items()}
+  shard = dist_utils.shard_batch(full, rank, world)
+  batch = {k: v.to(dev) for k, v in shard.items()}
+
+  # ---- R-replica oracle (fp32 and the fp64 yardstick) on the initial weights
+  gp = {k: v.detach().cpu().clone() for k, v in gan.generator.store.views.items()}
+  dp = {k: v.detach().cpu().clone() for k, v in gan.discriminator.store.views.items()}
+  ref32 = _oracle_sum(gp, dp, shard, world, False)
+  ref64 = _oracle_sum(gp, dp, shard, world, True)
+
+  # ---- product step; capture the summed gradient arenas as Adam consumes them
+  cap = {}
+  for opt, tag in ((gan.g_optimizer, 'g_grads'), (gan.d_optimizer, 'd_grads')):
+    orig = opt.apply_gradients
+    def wrap(*a, _orig=orig, _opt=opt, _tag=tag, **kw):
+      if _tag not in cap:
+        cap[_tag] = _opt.model.store.grad.detach().cpu().clone()
+      return _orig(*a, **kw)
+    opt.apply_gradients = wrap
   gan.train_g_d(batch)
+  torch.cuda.synchronize()
+  for key, model in (('g_grads', gan.generator), ('d_grads', gan.discriminator)):
+    names, shapes, f32 = ref32[key]
+    _, _, f64 = ref64[key]
+    st = model.store
+    assert set(names) == set(st.trainable_names)
+    hip = torch.cat([cap[key][st._off_tr[k][0]:st._off_tr[k][0] + st._off_tr[k][1]] for k in names])
+    e_hip = float((hip.double() - f64).norm() / f64.norm())
+    e_o32 = float((f32.double() - f64).norm() / f64.norm())
+    if rank == 0:
+      print(f'R={world} {key}: ||sum grad - f64|| / ||f64||: hip {e_hip:.3e}, fp32 oracle {e_o32:.3e}')
+    assert e_hip <= 5.0 * e_o32 + 1e-3, (key, e_hip, e_o32)
+    o = 0
+    gn = float(f64.norm())
+    for k, shp in zip(names, shapes):
+      cnt = int(np.prod(shp)) if len(shp) else 1
+      a, b32, b64 = hip[o:o + cnt].double(), f32[o:o + cnt].double(), f64[o:o + cnt]
+      o += cnt
+      if float(b64.norm()) < 1e-3 * gn:
+        continue   # tensors that carry none of the gradient: noise only
+      ea, eo = float((a - b64).norm() / b64.norm()), float((b32 - b64).norm() / b64.norm())
+      assert ea <= 5.0 * eo + 2e-3, (key, k, ea, eo)
+  # pooled batch statistics: the moving mean equals the R-replica oracle's
+  mm = gan.generator.store['encoder/bn1/moving_mean'].cpu().double()
+  assert float((mm - ref64['mm']).abs().max()) <= 1e-5 * float(ref64['mm'].abs().max()) + 1e-7
+
   gan.global_step += 1
   gan.train_d(batch)
   gan.train_g_d(batch)
   torch.cuda.synchronize()
-  assert gan._sync is not None and gan._sync.group is not gan.strategy.group
+  own = os.environ.get('SE3DS_GRAD_SYNC_OWN_COMM') == '1'
+  assert gan._sync is not None and (gan._sync.group is not gan.strategy.group) == own
   vecs = [gan.generator.store.theta, gan.discriminator.store.theta, gan.g_optimizer.v,
           gan.d_optimizer.m, gan.ema_generator.store.theta]
   sig = torch.stack([v.double().sum() for v in vecs] + [v.double().abs().sum() for v in vecs]).cpu()
@@ -63,6 +149,7 @@ image_models.SNMultiScaleDiscriminator.n_layers = 3
   assert abs(float(ls[0]) - float(ls[1])) > 0, 'both ranks report the same local loss'
   if rank == 0:
     print('DIST_GPU_OK', [float(x) for x in got[0][:5]])
+  faulthandler.cancel_dump_traceback_later()
   dist.destroy_process_group()
 
 

@@ -18,24 +18,32 @@ def _free_port():
   return p
 
 
-def test_two_replicas_share_one_gpu_over_gloo():
-  env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
-  r = None
-  for attempt in range(2):
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
-           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
-           os.path.join(ROOT, 'tests', '_dist_gpu_worker.py')]
+@pytest.mark.parametrize('own_comm', ['0', '1'])
+def test_two_replicas_share_one_gpu_over_gloo(own_comm):
+  """Product DP step on 2 replicas vs the R-replica oracle (see the worker).  own_comm=1 also runs
+  the opt-in second communicator for the gradient traffic.  A hang is a FAILURE: the workers dump
+  their stacks (faulthandler) and exit non-zero after 170 s."""
+  env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0',
+             SE3DS_GRAD_SYNC_OWN_COMM=own_comm)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+         os.path.join(ROOT, 'tests', '_dist_gpu_worker.py')]
+  r, hangs = None, []
+  for attempt in range(2):   # one retry: a gloo rendezvous on a fresh box has hung once in ~10 runs
+    cmd[cmd.index('--master-port') + 1] = str(_free_port())
     try:
-      r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+      r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired as e:
+      hangs.append(str(e.stdout)[-2000:] + str(e.stderr)[-4000:])
+      continue
+    if r.returncode == 0 or 'Timeout (' not in r.stderr:   # faulthandler's watchdog banner
       break
-    except subprocess.TimeoutExpired:
-      # seen once in ~10 runs on a fresh box: both ranks connected over gloo and then sat in the
-      # first collective; the workers kill themselves after 200 s (signal.alarm)
-      r = None
-  if r is None:
-    pytest.skip('two-process gloo rendezvous on one GPU hung twice (infrastructure)')
-  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    hangs.append(r.stdout[-2000:] + r.stderr[-4000:])
+  if r is None or (r.returncode != 0 and 'Timeout (' in r.stderr):
+    pytest.fail('two-replica step hung twice:\n' + '\n----\n'.join(hangs))
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
   assert 'DIST_GPU_OK' in r.stdout
+  print(r.stdout[-600:])
 
 
 def test_rccl_single_rank_api_paths():

@@ -830,3 +830,52 @@ def test_fused_adam_ema_is_bit_identical(monkeypatch):
   for a, b in zip(res['0'], res['1']):
     assert torch.equal(a, b)
   assert not torch.equal(res['0'][0], res['0'][2])   # the average lags the weights
+
+
+@pytest.mark.parametrize('num_batched_steps,steps', [(1, 3), (2, 5)])
+def test_adam_and_ema_recurrences_vs_oracle(num_batched_steps, steps):
+  """Keras Adam with non-zero slots (t = 1..steps, bias-corrected step size) and the EMA
+  copy-phase -> decay-phase switch (gan_manager.py:642-655: the copy lasts the whole first
+  cluster because global_step only advances per cluster) over ALL variables -- parameters, BN
+  moving statistics, spectral u -- against the oracle's recurrences (O.adam_keras, O.ema_step),
+  driven by the gradients each HIP step actually produced.  One fp32 ulp per step."""
+  size = 64
+  gan = _make_gan(size, 8, '50', 3)
+  gan.num_batched_steps = num_batched_steps
+  G, D = gan.generator, gan.discriminator
+  cpu = lambda model: {k: v.detach().cpu().clone() for k, v in model.store.views.items()}
+  p = {'g': cpu(G), 'd': cpu(D)}
+  ema = cpu(gan.ema_generator)
+  slots = {t: {k: (torch.zeros_like(p[t][k]), torch.zeros_like(p[t][k]))
+               for k in m.store.trainable_names} for t, m in (('g', G), ('d', D))}
+  cap = {}
+  for opt, tag in ((gan.g_optimizer, 'g'), (gan.d_optimizer, 'd')):
+    orig = opt.apply_gradients
+    def wrap(*a, _orig=orig, _opt=opt, _tag=tag, **kw):
+      cap[_tag] = {n: _opt.model.store.grad_views[n].detach().cpu().clone()
+                   for n in _opt.model.store.trainable_names}
+      return _orig(*a, **kw)
+    opt.apply_gradients = wrap
+  close = lambda a, b: torch.allclose(a, b, rtol=3e-7, atol=1e-9)
+  for step in range(steps):
+    batch = {k: v.to(DEV) for k, v in synth_batch(2, size, seed=200 + step).items()}
+    gs = gan.global_step
+    gan.train_g_d(batch)
+    if (step + 1) % num_batched_steps == 0:   # host loop, gan_manager.py:409-421
+      gan.global_step += num_batched_steps
+    for tag, model, opt, lr in (('g', G, gan.g_optimizer, 1e-4), ('d', D, gan.d_optimizer, 4e-4)):
+      assert opt.iterations == step + 1
+      for k in model.store.trainable_names:
+        m0, v0 = slots[tag][k]
+        newp, m1, v1 = O.adam_keras(p[tag][k], cap[tag][k], m0, v0, lr, 0.5, 0.999, step + 1)
+        o, cnt, shape = model.store._off_tr[k]
+        assert close(model.store[k].cpu(), newp), (step, tag, k)
+        assert close(opt.m[o:o + cnt].view(shape).cpu(), m1), (step, tag, k, 'm')
+        assert close(opt.v[o:o + cnt].view(shape).cpu(), v1), (step, tag, k, 'v')
+        p[tag][k], slots[tag][k] = newp, (m1, v1)
+    new_vals = cpu(G)   # BN moving statistics / u as the step left them
+    ema = O.ema_step(ema, new_vals, gs, gan.ema_decay, gan.ema_init_step, num_batched_steps)
+    for k, v in ema.items():
+      assert close(gan.ema_generator.store[k].cpu(), v), (step, k)
+    if gs >= num_batched_steps:   # decay phase: the average lags the weights
+      assert not torch.equal(gan.ema_generator.store.theta, G.store.theta)
