@@ -131,14 +131,16 @@ def bench_warp(args, rank, world, dev):
   tgt = torch.from_numpy(target).to(dev)
   P = h * w
 
+  M = views * P
+  mem_x = torch.empty((1, 4, M), dtype=torch.float32, device=dev)   # the point-cloud memory
+  mem_f = torch.empty((1, M, 3), dtype=torch.int32, device=dev)
+
   def step():
-    xs, fs = [], []
-    for rgb, depth, pos in g:
-      x, f = pano_utils.equirectangular_to_pointcloud(rgb, depth, -1, 20.0, position=pos)
-      xs.append(x)
-      fs.append(f)
-    mem_x = torch.cat(xs, 2)  # DtoD copies (memory concat, eval_metric.py:238-239)
-    mem_f = torch.cat(fs, 1)
+    # every view is unprojected straight into its window of the memory (the concat of
+    # eval_metric.py:238-239 / models.py:239-245 without a copy), then one target is rendered
+    for v, (rgb, depth, pos) in enumerate(g):
+      pano_utils.equirectangular_to_pointcloud(rgb, depth, -1, 20.0, position=pos,
+                                               out=(mem_x, mem_f, v * P))
     return pano_utils.project_feats_to_equirectangular(mem_f, mem_x, h, w, -1, 20.0, offset=tgt,
                                                        with_mask=True), (mem_x, mem_f)
 
@@ -163,7 +165,6 @@ def bench_warp(args, rank, world, dev):
   ev1.record()
   torch.cuda.synchronize()
   proj_ms = ev0.elapsed_time(ev1) / reps
-  M = views * P
   algo_bytes = 28 * M + 20 * P  # 28 B/point in, 16 B/px out + 4 B/px mask
   achieved = algo_bytes / (proj_ms * 1e-3) / 1e9
 
@@ -225,6 +226,8 @@ def main():
   ap.add_argument('--image-size', type=int, default=512)
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-warp', action='store_true',
+                  help='gan_step: skip the extra cfg5 warp measurement on the default line')
   args = ap.parse_args()
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
     sys.exit(_launch_ranks(args.gpus))
@@ -239,6 +242,16 @@ def main():
         else 'warp'
   out = bench_warp(args, rank, world, dev) if workload == 'warp' else \
       bench_gan_step(args, rank, world, dev)
+  if workload == 'gan_step' and world == 1 and not args.no_warp:
+    # the second half of the hot path, driver-observed on the default line: cfg5 warp
+    # (1024x2048, 2 views) throughput and the HBM roofline of its project+splat chain
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    wargs = argparse.Namespace(**vars(args))
+    wargs.steps, wargs.warmup, wargs.no_cpu_baseline = 50, 5, True
+    w = bench_warp(wargs, rank, world, dev)
+    out['warp'] = {k: w[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'config', 'roofline')}
   if rank == 0:
     print(json.dumps(out))
   if world > 1:

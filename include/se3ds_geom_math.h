@@ -180,6 +180,20 @@ SE3DS_HD float se3ds_atan_tab_f32(int j) {
   }
 }
 
+/* Reciprocal / square root of the SCREEN only: on the device the 1-ulp hardware approximations
+ * (v_rcp_f32 / v_sqrt_f32: one instruction instead of the ~10-instruction IEEE sequences), on the
+ * host the IEEE operations.  The screen's result never reaches an output -- it only decides
+ * whether a point may skip the exact chain -- so host and device need not agree bit for bit; both
+ * stay far inside the margin (host: tests/test_oracle_warp.py; device: the
+ * se3ds_debug_fast_fxy tap measured in tests/test_warp_gpu.py). */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SE3DS_SCREEN_RCP(x) __builtin_amdgcn_rcpf(x)
+#define SE3DS_SCREEN_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define SE3DS_SCREEN_RCP(x) (1.0f / (x))
+#define SE3DS_SCREEN_SQRT(x) __builtin_sqrtf(x)
+#endif
+
 /* fp32 atan2 for finite inputs, no signed-zero care (callers reject the degenerate cases). */
 SE3DS_HD float se3ds_atan2_fast(float y, float x) {
   float ay = y < 0.0f ? -y : y;
@@ -187,11 +201,11 @@ SE3DS_HD float se3ds_atan2_fast(float y, float x) {
   int swap = ay > ax;
   float a = swap ? ax : ay;
   float b = swap ? ay : ax;
-  float q = a / b; /* b == 0 -> NaN -> the caller's margin test fails */
+  float q = a * SE3DS_SCREEN_RCP(b); /* b == 0 -> NaN/inf -> the caller's margin test fails */
   int j = (int)(q * 8.0f + 0.5f);
   j = j > 8 ? 8 : (j < 0 ? 0 : j);
   float c = (float)j * 0.125f;
-  float t = __builtin_fmaf(-c, b, a) / __builtin_fmaf(c, a, b);
+  float t = __builtin_fmaf(-c, b, a) * SE3DS_SCREEN_RCP(__builtin_fmaf(c, a, b));
   float s = t * t;
   float p = -1.0f / 7.0f;
   p = __builtin_fmaf(p, s, 1.0f / 5.0f);
@@ -217,14 +231,16 @@ SE3DS_HD void se3ds_splat_fxy(float px, float py, float pz, int width, int heigh
  * the measured deviation. */
 SE3DS_HD void se3ds_equirect_fxy_fast(float x, float y, float z, int width, int height, float* fx,
                                       float* fy, float* pz) {
-  float rad = __builtin_sqrtf((x * x + y * y) + z * z);
+  float rad = __builtin_sqrtf((x * x + y * y) + z * z); /* IEEE: rad IS an output (depth) */
   *pz = rad;
   float heading = se3ds_atan2_fast(y, x);
   heading = SE3DS_F32_ONE_HALF_PI - heading;
   heading = heading + SE3DS_F32_TWO_PI * (heading <= 0.0f ? 1.0f : 0.0f);
   heading = heading - SE3DS_F32_TWO_PI * (heading > SE3DS_F32_TWO_PI ? 1.0f : 0.0f);
+  /* w must be the reference's individually rounded quotient: next to the poles acos amplifies
+   * its rounding error far beyond the margin, and the exact chain carries exactly that error */
   float w = z / rad;
-  float elevation = se3ds_atan2_fast(__builtin_sqrtf((1.0f - w) * (1.0f + w)), w);
+  float elevation = se3ds_atan2_fast(SE3DS_SCREEN_SQRT((1.0f - w) * (1.0f + w)), w);
   *fx = (heading * 0.159154943091895336f) * (float)width;  /* 1 / (2 pi) */
   *fy = (elevation * 0.318309886183790672f) * (float)height; /* 1 / pi */
 }

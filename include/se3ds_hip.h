@@ -56,6 +56,16 @@ int se3ds_unproject_equirect(const void* feats, int feat_dtype, const float* dep
                              int width, int channels, float void_class, float depth_scale,
                              float* xyz1, void* feats_out, void* stream);
 
+/* The same, written straight into a point-cloud MEMORY (the concat of models/models.py:239-245
+ * and utils/eval_metric.py:238-239 without the copy): xyz1 is (N,4,m_total) and feats_out
+ * (N,m_total,C); this view fills columns / rows [m_offset, m_offset + H*W). */
+int se3ds_unproject_equirect_into(const void* feats, int feat_dtype, const float* depth,
+                                  const float* sin_el, const float* cos_el, const float* sin_hd,
+                                  const float* cos_hd, const float* position, int n, int height,
+                                  int width, int channels, float void_class, float depth_scale,
+                                  float* xyz1, void* feats_out, int64_t m_total, int64_t m_offset,
+                                  void* stream);
+
 /* Scratch bytes for the two splat entry points below. */
 size_t se3ds_splat_workspace_bytes(int n, int64_t m, int height, int width, int channels);
 
@@ -87,6 +97,12 @@ int se3ds_project_to_feat(const float* coords, const void* feats, int feat_dtype
  * `workspace` (int32 per point: index inside the image v*W+u, or -1 = sink) and z. */
 int se3ds_splat_debug_indices(const void* workspace, int n, int64_t m, int32_t* idx_out,
                               float* z_out, void* stream);
+
+/* Debug/parity tap: the DEVICE evaluation of the fast index screen (se3ds_geom_math.h) on
+ * camera-relative xyz (3,M): fx, fy as the screen computes them and its verdict per point
+ * (>= -1: decided index v*W+u or -1 = not a valid splat; -2: left to the exact chain). */
+int se3ds_debug_fast_fxy(const float* xyz, int64_t m, int width, int height, float* fx, float* fy,
+                         int32_t* verdict, void* stream);
 
 /* get_filtered_coords_and_feats -- reference utils/point_cloud_utils.py:32-87 (perspective,
  * 90 deg HFOV).  feats (N,H,W,C) int32, depth (N,H,W) fp32; xs (W), ys (H) are the fp32
@@ -304,6 +320,14 @@ int se3ds_copy_channels(const void* src, int src_dtype, int src_c, int src_c0, v
                         int dst_dtype, int dst_c, int dst_c0, int ncopy, int64_t rows,
                         void* stream);
 int se3ds_fill(void* p, int dtype, int64_t n, float value, void* stream);
+/* SE3DSModel quantisation glue -- models/models.py:198 (int / 255 -> fp32), :289-291
+ * (proj_rgb / 255 clipped to [0,1]), :325-331 (int32(g * 255) clipped to [-1,255];
+ * int32(clip(g,0,1) * 255)), :353,:359 (casts to uint8): out = Q(clamp?(in) * mul / div) with one
+ * rounding per op; float outputs are clamped to [lo,hi], integer outputs truncate toward zero
+ * (tf.cast) and are then clamped to [lo,hi].  dtypes: SE3DS_F32 / SE3DS_I32 / SE3DS_U8. */
+int se3ds_quantize(const void* in, int in_dtype, int64_t n, int pre_clamp, float pre_lo,
+                   float pre_hi, float mul, float div, float lo, float hi, void* out, int out_dtype,
+                   void* stream);
 /* PadLayer as a standalone op -- models/layers.py:22-97: pad H and W by `pad`; mode 0
  * CONSTANT(value) / 1 REFLECT / 2 SYMMETRIC; wrap_w != 0: W is padded circularly. */
 int se3ds_pad2d(const void* x, int dtype, int n, int h, int w, int c, int pad, int mode, int wrap_w,

@@ -103,16 +103,14 @@ class SE3DSModelOracle:
     if add_preds_to_memory:
       pred_rgb_mem, pred_semantic_mem, pred_depth_mem = pc_rgb, pred_semantic, pred_depth
       if use_projected_rgb:
-        # :339-344 (TF itself refuses float32 + int32 here; the promoted arithmetic is restated)
-        pred_rgb = proj_rgb + pred_rgb_mem
-        pred_semantic = proj_semantic + pred_semantic_mem
-        pred_depth = proj_depth + pred_depth_mem
-        generated = (np.clip(pred_rgb_mem, 0, 255) / 255).astype(F32)
+        # :339-344: `proj_rgb + pred_rgb_mem` adds a float32 and an int32 tensor; TensorFlow has no
+        # implicit promotion and raises InvalidArgumentError -- the branch cannot run in the reference
+        raise TypeError('models.py:340 adds float32 proj_rgb to int32 predictions')
       self.prev_rgb_frame = generated
       self.add_to_memory(pred_rgb_mem, pred_semantic_mem[..., None], pred_depth_mem, position)
-    pred_rgb_u8 = np.trunc(pred_rgb).astype(np.int64).astype(np.uint8)   # tf.cast(., uint8)
+    pred_rgb_u8 = pred_rgb.astype(np.uint8)   # tf.cast(., uint8); values are in [0, 255]
     return dict(proj_semantic=proj_semantic, pred_semantic=pred_semantic,
                 proj_rgb=np.trunc(proj_rgb * F32(255)).astype(np.uint8),
-                pred_rgb=pred_rgb_u8, pred_rgb_i32=pred_rgb if pred_rgb.dtype == np.int32 else None,
+                pred_rgb=pred_rgb_u8,
                 proj_depth=proj_depth, pred_depth=pred_depth, mu=mu, logvar=logvar,
                 proj_mask=proj_mask, generated=generated, pc_rgb=pc_rgb)

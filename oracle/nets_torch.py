@@ -122,6 +122,36 @@ def leaky_relu(x, alpha):
   return torch.where(x > 0, x, x * alpha)
 
 
+class CrossReplicaSum(torch.autograd.Function):
+  """tf.distribute ReplicaContext.all_reduce(SUM, .) as Keras SyncBatchNormalization uses it for
+  its batch statistics: differentiable, and the gradient of an all-reduce is the all-reduce of the
+  upstream gradients -- a replica's activations also receive the sensitivity of the OTHER
+  replicas' losses to the shared statistics.  Needs an initialised torch.distributed group; every
+  replica must run the same graph (forward and backward collectives then pair up in order)."""
+
+  @staticmethod
+  def forward(ctx, t):
+    import torch.distributed as dist
+    out = t.detach().clone()
+    dist.all_reduce(out)
+    return out
+
+  @staticmethod
+  def backward(ctx, g):
+    import torch.distributed as dist
+    out = g.detach().clone().contiguous()
+    dist.all_reduce(out)
+    return out
+
+
+def pooled_stats_hook(world):
+  """stats_hook for Net.sync_bn: (sum, sum of squares, count) over all replicas."""
+  def pooled(name, s1, s2, cnt):
+    t = CrossReplicaSum.apply(torch.stack([s1, s2]))
+    return t[0], t[1], cnt * world
+  return pooled
+
+
 class Net:
   """Parameter access + side-effect bookkeeping (BN moving stats, spectral u)."""
 

@@ -20,12 +20,15 @@ _SIGS = {
     'se3ds_last_error': (ctypes.c_char_p, []),
     'se3ds_unproject_equirect': (c_int, [c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int,
                                          c_int, c_int, c_f, c_f, c_p, c_p, c_p]),
+    'se3ds_unproject_equirect_into': (c_int, [c_p, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int,
+                                              c_int, c_int, c_f, c_f, c_p, c_p, c_i64, c_i64, c_p]),
     'se3ds_splat_workspace_bytes': (c_sz, [c_int, c_i64, c_int, c_int, c_int]),
     'se3ds_project_equirect': (c_int, [c_p, c_p, c_p, c_int, c_int, c_i64, c_int, c_int, c_int,
                                        c_f, c_f, c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
     'se3ds_project_to_feat': (c_int, [c_p, c_p, c_int, c_int, c_i64, c_int, c_int, c_int, c_f, c_f,
                                       c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
     'se3ds_splat_debug_indices': (c_int, [c_p, c_int, c_i64, c_p, c_p, c_p]),
+    'se3ds_debug_fast_fxy': (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p, c_p, c_p]),
     'se3ds_unproject_perspective': (c_int, [c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_int,
                                             c_f, c_p, c_p, c_p]),
     'se3ds_interp_bilinear': (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_p,

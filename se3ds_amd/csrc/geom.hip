@@ -38,7 +38,8 @@ unproject_equirect_kernel(const T* __restrict__ feats, const float* __restrict__
                           const float* __restrict__ sin_hd, const float* __restrict__ cos_hd,
                           const float* __restrict__ position, int height, int width, int channels,
                           float void_class, float depth_scale, float* __restrict__ xyz1,
-                          T* __restrict__ feats_out) {
+                          T* __restrict__ feats_out, int64_t m_total, int64_t m_offset) {
+  // outputs are windows [m_offset, m_offset + H*W) of a (N,4,m_total) / (N,m_total,C) memory
   const int b = blockIdx.y;
   const int64_t p = (int64_t)height * width;
   float pos_x = 0.f, pos_y = 0.f, pos_z = 0.f;
@@ -48,7 +49,7 @@ unproject_equirect_kernel(const T* __restrict__ feats, const float* __restrict__
     pos_z = position[b * 3 + 2];
   }
   const T vc = FeatIO<T>::cast_void(void_class);
-  float* X = xyz1 + (int64_t)b * 4 * p;
+  float* X = xyz1 + (int64_t)b * 4 * m_total + m_offset;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p;
        i += (int64_t)gridDim.x * kBlock) {
     int r = (int)(i / width);
@@ -67,11 +68,11 @@ unproject_equirect_kernel(const T* __restrict__ feats, const float* __restrict__
       z = z + pos_z;
     }
     X[i] = x;
-    X[p + i] = y;
-    X[2 * p + i] = z;
-    X[3 * p + i] = 1.0f;
+    X[m_total + i] = y;
+    X[2 * m_total + i] = z;
+    X[3 * m_total + i] = 1.0f;
     const T* fi = feats + ((int64_t)b * p + i) * channels;
-    T* fo = feats_out + ((int64_t)b * p + i) * channels;
+    T* fo = feats_out + ((int64_t)b * m_total + m_offset + i) * channels;
     for (int k = 0; k < channels; ++k) fo[k] = valid ? fi[k] : vc;
   }
 }
@@ -354,6 +355,24 @@ splat_finalize_kernel(float* __restrict__ depth, float* __restrict__ feat,
       all_ok = all_ok && (v != mask_void);
     }
     if (mask) mask[i] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+  }
+}
+
+// Parity tap of the DEVICE fast screen (se3ds_geom_math.h: v_rcp_f32 / v_sqrt_f32 inside): fx, fy
+// and the screen's verdict per point (decided: idx >= -1, undecided: -2), so that the tests can
+// bound its deviation from the exact chain on the real hardware.
+__global__ void __launch_bounds__(kBlock)
+debug_fast_fxy_kernel(const float* __restrict__ xyz, int64_t m, int width, int height,
+                      float* __restrict__ fx, float* __restrict__ fy, int32_t* __restrict__ verdict) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m;
+       i += (int64_t)gridDim.x * kBlock) {
+    const float x = xyz[i], y = xyz[m + i], z = xyz[2 * m + i];
+    float gx, gy, pz;
+    se3ds_equirect_fxy_fast(x, y, z, width, height, &gx, &gy, &pz);
+    fx[i] = gx;
+    fy[i] = gy;
+    int32_t idx = -1;
+    verdict[i] = se3ds_equirect_index_fast(x, y, z, width, height, 1, &idx, &pz) ? idx : -2;
   }
 }
 
@@ -1374,38 +1393,52 @@ using namespace se3ds;
 
 extern "C" {
 
-int se3ds_unproject_equirect(const void* feats, int feat_dtype, const float* depth,
-                             const float* sin_el, const float* cos_el, const float* sin_hd,
-                             const float* cos_hd, const float* position, int n, int height,
-                             int width, int channels, float void_class, float depth_scale,
-                             float* xyz1, void* feats_out, void* stream) {
+int se3ds_unproject_equirect_into(const void* feats, int feat_dtype, const float* depth,
+                                  const float* sin_el, const float* cos_el, const float* sin_hd,
+                                  const float* cos_hd, const float* position, int n, int height,
+                                  int width, int channels, float void_class, float depth_scale,
+                                  float* xyz1, void* feats_out, int64_t m_total, int64_t m_offset,
+                                  void* stream) {
   if (n <= 0 || height <= 0 || width <= 0 || channels <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
   int64_t p = (int64_t)height * width;
+  if (m_offset < 0 || m_offset + p > m_total) return SE3DS_E_BADSHAPE;
   dim3 grid((unsigned)grid_for(p, kBlock), (unsigned)n);
   switch (feat_dtype) {
     case SE3DS_F32:
       hipLaunchKernelGGL(unproject_equirect_kernel<float>, grid, dim3(kBlock), 0, s,
                          (const float*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position,
-                         height, width, channels, void_class, depth_scale, xyz1, (float*)feats_out);
+                         height, width, channels, void_class, depth_scale, xyz1, (float*)feats_out,
+                         m_total, m_offset);
       break;
     case SE3DS_I32:
       hipLaunchKernelGGL(unproject_equirect_kernel<int32_t>, grid, dim3(kBlock), 0, s,
                          (const int32_t*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position,
                          height, width, channels, void_class, depth_scale, xyz1,
-                         (int32_t*)feats_out);
+                         (int32_t*)feats_out, m_total, m_offset);
       break;
     case SE3DS_U8:
       if (void_class < 0.0f) return SE3DS_E_BADDTYPE;  // pano_utils.py:193-197
       hipLaunchKernelGGL(unproject_equirect_kernel<uint8_t>, grid, dim3(kBlock), 0, s,
                          (const uint8_t*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position,
                          height, width, channels, void_class, depth_scale, xyz1,
-                         (uint8_t*)feats_out);
+                         (uint8_t*)feats_out, m_total, m_offset);
       break;
     default:
       return SE3DS_E_BADDTYPE;
   }
   return check_launch("unproject_equirect");
+}
+
+int se3ds_unproject_equirect(const void* feats, int feat_dtype, const float* depth,
+                             const float* sin_el, const float* cos_el, const float* sin_hd,
+                             const float* cos_hd, const float* position, int n, int height,
+                             int width, int channels, float void_class, float depth_scale,
+                             float* xyz1, void* feats_out, void* stream) {
+  return se3ds_unproject_equirect_into(feats, feat_dtype, depth, sin_el, cos_el, sin_hd, cos_hd,
+                                       position, n, height, width, channels, void_class,
+                                       depth_scale, xyz1, feats_out, (int64_t)height * width, 0,
+                                       stream);
 }
 
 size_t se3ds_splat_workspace_bytes(int n, int64_t m, int height, int width, int channels) {
@@ -1442,6 +1475,14 @@ int se3ds_splat_debug_indices(const void* workspace, int n, int64_t m, int32_t* 
   hipLaunchKernelGGL(splat_debug_copy_kernel, dim3(grid_for(total, kBlock)), dim3(kBlock), 0,
                      as_stream(stream), ws, total, idx_out, z_out);
   return check_launch("splat_debug_indices");
+}
+
+int se3ds_debug_fast_fxy(const float* xyz, int64_t m, int width, int height, float* fx, float* fy,
+                         int32_t* verdict, void* stream) {
+  if (m <= 0) return SE3DS_OK;
+  hipLaunchKernelGGL(debug_fast_fxy_kernel, dim3(grid_for(m, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), xyz, m, width, height, fx, fy, verdict);
+  return check_launch("debug_fast_fxy");
 }
 
 int se3ds_unproject_perspective(const int32_t* feats, const float* depth, const float* xs,

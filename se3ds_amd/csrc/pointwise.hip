@@ -4,6 +4,7 @@
 // accumulate, output heads (tanh -> [0,1], clip) and the loss reductions / gradients of
 // trainers/se3ds_trainer.py:39-71,148-234.
 #include "common.h"
+#include <type_traits>
 
 namespace se3ds {
 namespace {
@@ -431,6 +432,32 @@ hinge_kernel(const T* __restrict__ logits, int64_t half, float cd, float cg,
 
 using namespace se3ds;
 
+// ---------------------------------------------------------- SE3DSModel quantisation steps
+// models/models.py:289-291 (proj_rgb / 255, clip), :325-331 (int32(g * 255), clip(-1, 255);
+// int32(clip(g, 0, 1) * 255)), :198 (int / 255), :353 (cast to uint8): one rounding per reference
+// op -- optional pre-clamp, * mul, / div (IEEE division), then either a float clamp or
+// truncation toward zero (tf.cast float -> int) followed by an integer clamp.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(kB)
+quantize_kernel(const TI* __restrict__ in, int64_t n, int pre_clamp, float pre_lo, float pre_hi,
+                float mul, float div, float lo, float hi, TO* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)gridDim.x * kB) {
+    float v = (float)in[i];
+    if (pre_clamp) v = fminf(fmaxf(v, pre_lo), pre_hi);
+    v = v * mul;
+    v = v / div;
+    if constexpr (std::is_floating_point<TO>::value) {
+      out[i] = (TO)fminf(fmaxf(v, lo), hi);
+    } else {
+      int t = (int)v;
+      const int ilo = (int)lo, ihi = (int)hi;
+      t = t < ilo ? ilo : (t > ihi ? ihi : t);
+      out[i] = (TO)t;
+    }
+  }
+}
+
+
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
   if ((dtype) == SE3DS_F32) { CALL_F32; } else if ((dtype) == SE3DS_BF16) { CALL_BF16; } \
   else return SE3DS_E_BADDTYPE;
@@ -584,6 +611,34 @@ int se3ds_fill(void* p, int dtype, int64_t n, float value, void* stream) {
   DISPATCH_T(dtype, hipLaunchKernelGGL(fill_kernel<float>, g, dim3(kB), 0, s, (float*)p, n, value),
              hipLaunchKernelGGL(fill_kernel<uint16_t>, g, dim3(kB), 0, s, (uint16_t*)p, n, value))
   return check_launch("fill");
+}
+
+int se3ds_quantize(const void* in, int in_dtype, int64_t n, int pre_clamp, float pre_lo,
+                   float pre_hi, float mul, float div, float lo, float hi, void* out, int out_dtype,
+                   void* stream) {
+  if (n <= 0) return SE3DS_OK;
+  if (div == 0.f) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+  dim3 g(grid_for(n, kB));
+#define Q(TI, TO) hipLaunchKernelGGL((quantize_kernel<TI, TO>), g, dim3(kB), 0, s, (const TI*)in, n, \
+                                     pre_clamp, pre_lo, pre_hi, mul, div, lo, hi, (TO*)out)
+  if (in_dtype == SE3DS_F32) {
+    if (out_dtype == SE3DS_F32) Q(float, float);
+    else if (out_dtype == SE3DS_I32) Q(float, int32_t);
+    else if (out_dtype == SE3DS_U8) Q(float, uint8_t);
+    else return SE3DS_E_BADDTYPE;
+  } else if (in_dtype == SE3DS_I32) {
+    if (out_dtype == SE3DS_F32) Q(int32_t, float);
+    else if (out_dtype == SE3DS_I32) Q(int32_t, int32_t);
+    else if (out_dtype == SE3DS_U8) Q(int32_t, uint8_t);
+    else return SE3DS_E_BADDTYPE;
+  } else if (in_dtype == SE3DS_U8) {
+    if (out_dtype == SE3DS_F32) Q(uint8_t, float);
+    else if (out_dtype == SE3DS_I32) Q(uint8_t, int32_t);
+    else return SE3DS_E_BADDTYPE;
+  } else return SE3DS_E_BADDTYPE;
+#undef Q
+  return check_launch("quantize");
 }
 
 int se3ds_pad2d(const void* x, int dtype, int n, int h, int w, int c, int pad, int mode, int wrap_w,

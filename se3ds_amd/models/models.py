@@ -15,6 +15,21 @@ from se3ds_amd.models import image_models
 from se3ds_amd.utils import pano_utils
 
 
+def _quantize(x: torch.Tensor, out_dtype, mul=1.0, div=1.0, lo=0.0, hi=0.0, pre=None):
+  """libse3ds_hip.so `se3ds_quantize`: Q(clamp?(x) * mul / div), clamped to [lo, hi]; integer
+  outputs truncate toward zero like tf.cast (reference :198,:289-291,:325-331,:353)."""
+  from se3ds_amd import hipops  # noqa: F401  (registers the signature)
+  _lib.require_cuda(x)
+  x = x.contiguous()
+  out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+  _lib.check(_lib.lib().se3ds_quantize(
+      x.data_ptr(), _lib.dtype_code(x), x.numel(), 0 if pre is None else 1,
+      0.0 if pre is None else float(pre[0]), 0.0 if pre is None else float(pre[1]), float(mul),
+      float(div), float(lo), float(hi), out.data_ptr(), _lib.dtype_code(out), _lib.stream()),
+      'se3ds_quantize')
+  return out
+
+
 class PanoData(NamedTuple):
   position: torch.Tensor
   rgb: torch.Tensor
@@ -129,9 +144,11 @@ class SE3DSModel(object):
     assert pano_rgb.dtype in [torch.uint8, torch.int32]
     assert pano_semantic.dtype in [torch.uint8, torch.int32]
     _lib.require_cuda(pano_rgb, pano_semantic, pano_depth, position)
-    pano_rgb = pano_rgb.to(torch.int32)
-    pano_semantic = pano_semantic.to(torch.uint8)
-    self.prev_rgb_frame = pano_rgb.to(torch.float32) / 255
+    if pano_rgb.dtype != torch.int32:
+      pano_rgb = _quantize(pano_rgb, torch.int32, lo=0, hi=255)          # tf.cast(uint8 -> int32)
+    if pano_semantic.dtype != torch.uint8:
+      pano_semantic = _quantize(pano_semantic, torch.uint8, lo=0, hi=255)  # tf.cast(int32 -> uint8)
+    self.prev_rgb_frame = _quantize(pano_rgb, torch.float32, div=255.0, lo=-1.0, hi=1.0)
     if mask_blurred:
       pano_rgb = pano_utils.mask_pano(pano_rgb, masked_region_value=constants.INVALID_RGB_VALUE)
     position = position.to(torch.float32)
@@ -168,8 +185,8 @@ class SE3DSModel(object):
         self.depth_scale, offset=position, with_mask=True,
         mask_void=constants.INVALID_RGB_VALUE)
     proj_mask = proj_mask[..., None]
-    proj_semantic = proj_semantic[..., 0].to(torch.uint8)
-    proj_rgb = torch.clamp(proj_rgb / 255, 0, 1)   # quantisation glue on (N,H,W,3)
+    proj_semantic = _quantize(proj_semantic[..., 0], torch.uint8, lo=0, hi=255)
+    proj_rgb = _quantize(proj_rgb, torch.float32, div=255.0, lo=0.0, hi=1.0)   # clip(x / 255, 0, 1)
     assert self.prev_rgb_frame is not None
     inputs = {
         'prev_image': self.prev_rgb_frame, 'proj_image': proj_rgb,
@@ -179,22 +196,25 @@ class SE3DSModel(object):
     }
     (mu, logvar, _, pred_depth, pred_semantic, _, generated_pred_rgb) = self.model(
         inputs=[inputs, None], sample_noise=sample_noise, training=False)
-    pred_depth = torch.clamp(pred_depth[..., 0], 0, 1)
-    pc_rgb_tensor = torch.clamp((generated_pred_rgb * 255).to(torch.int32),
-                                constants.INVALID_RGB_VALUE, 255)   # truncation, as tf.cast
-    pred_rgb = (torch.clamp(generated_pred_rgb, 0, 1) * 255).to(torch.int32)
+    pred_depth = _quantize(pred_depth[..., 0], torch.float32, lo=0.0, hi=1.0)
+    # int32(g * 255) clipped to [-1, 255] (memory RGB, :327-329); int32(clip(g, 0, 1) * 255) (:330-331)
+    pc_rgb_tensor = _quantize(generated_pred_rgb, torch.int32, mul=255.0,
+                              lo=constants.INVALID_RGB_VALUE, hi=255)
+    pred_rgb = _quantize(generated_pred_rgb, torch.int32, mul=255.0, lo=0, hi=255, pre=(0.0, 1.0))
+    # tf.argmax over the all-zero segmentation logits (image_models.py:191-193) is class 0
     pred_semantic = torch.zeros(pred_semantic.shape[:-1], dtype=torch.uint8, device=self.device)
     if add_preds_to_memory:
       pred_rgb_mem, pred_semantic_mem, pred_depth_mem = pc_rgb_tensor, pred_semantic, pred_depth
       if use_projected_rgb:
-        pred_rgb = proj_rgb + pred_rgb_mem
-        pred_semantic = proj_semantic + pred_semantic_mem
-        pred_depth = proj_depth + pred_depth_mem
-        generated_pred_rgb = torch.clamp(pred_rgb_mem, 0, 255).to(torch.float32) / 255
+        # reference :339-344 adds a float32 and an int32 tensor, which TensorFlow itself rejects
+        # (no implicit promotion): the branch cannot run there, so it is not offered here either
+        raise TypeError('use_projected_rgb with add_preds_to_memory adds float32 proj_rgb to int32 '
+                        'predictions (models.py:340): TensorFlow raises on the dtype mismatch')
       self.prev_rgb_frame = generated_pred_rgb
       self.add_to_memory(pred_rgb_mem, pred_semantic_mem[..., None], pred_depth_mem, position)
-    pred_rgb = pred_rgb.to(torch.uint8)
+    pred_rgb = _quantize(pred_rgb, torch.uint8, lo=0, hi=255)   # in [0, 255] already: a cast
     return OutputData(proj_semantic=proj_semantic, pred_semantic=pred_semantic,
-                      proj_rgb=(proj_rgb * 255).to(torch.uint8), pred_rgb=pred_rgb,
+                      proj_rgb=_quantize(proj_rgb, torch.uint8, mul=255.0, lo=0, hi=255),
+                      pred_rgb=pred_rgb,
                       proj_depth=proj_depth, pred_depth=pred_depth, mu=mu, logvar=logvar,
                       proj_mask=proj_mask)

@@ -69,13 +69,17 @@ def project_feats_to_equirectangular(feats: torch.Tensor, xyz1: torch.Tensor, he
 def equirectangular_to_pointcloud(feats: torch.Tensor, depth: torch.Tensor, void_class: float,
                                   depth_scale: float, size_mult: float = 1.0,
                                   interpolation_method: str = 'nearest',
-                                  position: Optional[torch.Tensor] = None
+                                  position: Optional[torch.Tensor] = None,
+                                  out: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None
                                   ) -> Tuple[torch.Tensor, torch.Tensor]:
   """Equirect image + depth -> point cloud (reference :164-242).
 
   feats (N,H,W) or (N,H,W,C) [uint8 / int32 / float32], depth (N,H,W) in [0,1].  Returns xyz1
   (N,4,H*W) and filtered feats (N,H*W[,C]); invalid-depth pixels get xyz (0,0,0,1) and
-  void_class.  `position` (N,3), optional, is added to xyz (models.py:225-226)."""
+  void_class.  `position` (N,3), optional, is added to xyz (models.py:225-226).  `out` =
+  (memory_xyz1 (N,4,M), memory_feats (N,M,C), offset): write the points straight into columns
+  [offset, offset + H*W) of a preallocated memory instead of new tensors (the concat of
+  models.py:239-245 without the copy); returns views of the written windows."""
   if feats.dim() != 3 and feats.dim() != 4:
     raise ValueError('feats should have shape (N, H, W) or (N, H, W, C),'
                      f' got {tuple(feats.shape)} instead.')
@@ -99,18 +103,30 @@ def equirectangular_to_pointcloud(feats: torch.Tensor, depth: torch.Tensor, void
   dev = depth.device
   tab = _host_tables.equirect_tables(h, w, dev)
   base = tab.data_ptr()
-  xyz1 = torch.empty((n, 4, h * w), dtype=torch.float32, device=dev)
-  out = torch.empty((n, h * w, c), dtype=feats.dtype, device=dev)
   if position is not None:
     position = position.to(torch.float32).contiguous()
-  rc = _lib.lib().se3ds_unproject_equirect(
+  if out is not None:
+    mem_x, mem_f, off = out
+    m_total = mem_x.shape[2]
+    if (mem_x.dtype != torch.float32 or not mem_x.is_contiguous() or not mem_f.is_contiguous() or
+        mem_f.dtype != feats.dtype or tuple(mem_x.shape[:2]) != (n, 4) or
+        tuple(mem_f.shape) != (n, m_total, c) or off < 0 or off + h * w > m_total):
+      raise ValueError('out = (xyz1 (N,4,M) fp32, feats (N,M,C) of the input dtype, offset)')
+    xyz1, res = mem_x, mem_f
+  else:
+    m_total, off = h * w, 0
+    xyz1 = torch.empty((n, 4, h * w), dtype=torch.float32, device=dev)
+    res = torch.empty((n, h * w, c), dtype=feats.dtype, device=dev)
+  rc = _lib.lib().se3ds_unproject_equirect_into(
       _lib.ptr(feats), _lib.dtype_code(feats), _lib.ptr(depth), base, base + 4 * h,
       base + 8 * h, base + 8 * h + 4 * w, _lib.ptr(position), n, h, w, c, float(void_class),
-      float(depth_scale), _lib.ptr(xyz1), _lib.ptr(out), _lib.stream())
+      float(depth_scale), _lib.ptr(xyz1), _lib.ptr(res), m_total, off, _lib.stream())
   _lib.check(rc, 'se3ds_unproject_equirect')
+  if out is not None:
+    xyz1, res = xyz1[:, :, off:off + h * w], res[:, off:off + h * w]
   if is_scalar:
-    out = out[..., 0]
-  return xyz1, out
+    res = res[..., 0]
+  return xyz1, res
 
 
 def mask_pano(pano: torch.Tensor, proportion: float = 0.125, masked_region_value=0):

@@ -126,3 +126,18 @@ def splat_debug_indices(n: int, m: int, device) -> Tuple[torch.Tensor, torch.Ten
                                             _lib.stream())
   _lib.check(rc, 'se3ds_splat_debug_indices')
   return idx, z
+
+
+def debug_fast_fxy(xyz: torch.Tensor, height: int, width: int):
+  """Parity tap: (fx, fy, verdict) of the device's fast index screen on camera-relative xyz (3,M)
+  (verdict >= -1: decided flat index or -1; -2: left to the exact binary64 chain)."""
+  _lib.require_cuda(xyz)
+  xyz = xyz.to(torch.float32).contiguous()
+  m = xyz.shape[1]
+  fx = torch.empty(m, dtype=torch.float32, device=xyz.device)
+  fy = torch.empty_like(fx)
+  verdict = torch.empty(m, dtype=torch.int32, device=xyz.device)
+  rc = _lib.lib().se3ds_debug_fast_fxy(_lib.ptr(xyz), m, width, height, _lib.ptr(fx), _lib.ptr(fy),
+                                       _lib.ptr(verdict), _lib.stream())
+  _lib.check(rc, 'se3ds_debug_fast_fxy')
+  return fx, fy, verdict

@@ -122,41 +122,49 @@ def test_cfg1_lowres_train_g_d_fp32_and_bf16():
   print(f'cfg1 oracle fp32: {time.time() - t0:.1f} s')
   cap = _capture_step(gan, batch)
 
-  # ---- fp32 gradients, tensor by tensor
-  misses = []
-  worst = 0.0
+  # ---- fp32 gradients, tensor by tensor.  At these dimensions (200+ layers, training-mode batch
+  # statistics over as few as 64 samples per channel, random initialisation) the backward pass is
+  # ill-conditioned in fp32: the fp32 ORACLE's gradients sit 20-30 % from an fp64 run of itself,
+  # so no fp32 implementation (TF included) can agree with another to 1e-3 here.  The forward pass
+  # is well-conditioned (losses agree to 1e-3 below).  Gate: every tensor either matches the oracle
+  # to 1e-3 directly, or is as close to the fp64 run as the fp32 oracle is (factor 5) -- no cosine
+  # fallback; strict per-tensor 1e-3 on the same widths is
+  # test_cfg1_generator_gradients_well_conditioned.
+  torch.set_default_dtype(torch.float64)
+  try:
+    f64 = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v)
+                     for k, v in d.items()}
+    t0 = time.time()
+    ref64 = O.train_g_d(f64(gp), f64(dp), f64(batch), cfg)
+    print(f'cfg1 oracle fp64: {time.time() - t0:.1f} s')
+  finally:
+    torch.set_default_dtype(torch.float32)
   for tag, model, key in (('g', gan.generator, 'g_grads'), ('d', gan.discriminator, 'd_grads')):
     st = model.store
     assert set(ref[key]) == set(st.trainable_names)
-    gmax = max(float(g.abs().max()) for g in ref[key].values())
+    gmax = max(float(g.abs().max()) for g in ref64[key].values())
+    direct_ok, worst_ratio, med = 0, 0.0, []
     for name in st.trainable_names:
       go = ref[key][name].numpy()
       gh = _grad_view(st, cap[tag + '_grad'], name).numpy()
+      r64 = ref64[key][name].numpy()
       # relative to the tensor's largest entry, floored at 1e-4 of the model's largest gradient
       # entry (tensors whose true gradient is ~0, e.g. biases in front of a batch norm)
-      e = float(np.abs(gh - go).max() / max(np.abs(go).max(), 1e-4 * gmax))
-      worst = max(worst, e)
-      if e >= 1e-3:
-        misses.append((tag, name, e))
-  print(f'cfg1 fp32: worst per-tensor gradient error {worst:.2e}; {len(misses)} tensors above 1e-3')
-  if misses:
-    # fp64 yardstick (training-mode batch statistics over few samples amplify fp32 noise)
-    torch.set_default_dtype(torch.float64)
-    try:
-      f64 = lambda d: {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v)
-                       for k, v in d.items()}
-      ref64 = O.train_g_d(f64(gp), f64(dp), f64(batch), cfg)
-    finally:
-      torch.set_default_dtype(torch.float32)
-    for tag, name, e in misses:
-      model = gan.generator if tag == 'g' else gan.discriminator
-      key = 'g_grads' if tag == 'g' else 'd_grads'
-      r64 = ref64[key][name].numpy()
-      gh = _grad_view(model.store, cap[tag + '_grad'], name).numpy()
-      e_hip, e_o32 = rel_err(gh, r64), rel_err(ref[key][name].numpy(), r64)
-      print(f'  {tag}:{name}: direct {e:.2e}; vs fp64: hip {e_hip:.2e}, fp32 oracle {e_o32:.2e}')
-      assert e_hip <= 5.0 * e_o32 + 1e-3, (tag, name, e_hip, e_o32)
-    del ref64
+      den = max(np.abs(r64).max(), 1e-4 * gmax)
+      e_direct = float(np.abs(gh - go).max() / den)
+      if e_direct < 1e-3:
+        direct_ok += 1
+        continue
+      e_hip = float(np.abs(gh - r64).max() / den)
+      e_o32 = float(np.abs(go - r64).max() / den)
+      med.append((e_hip, e_o32))
+      worst_ratio = max(worst_ratio, e_hip / (5.0 * e_o32 + 1e-3))
+      assert e_hip <= 5.0 * e_o32 + 1e-3, (tag, name, e_direct, e_hip, e_o32)
+    if med:
+      mh, mo = np.median([a for a, _ in med]), np.median([b for _, b in med])
+      print(f'cfg1 fp32 {tag}: {direct_ok} tensors within 1e-3 of the oracle, {len(med)} judged against '
+            f'fp64 (median error: hip {mh:.2e}, fp32 oracle {mo:.2e}; worst hip/(5*oracle+1e-3) '
+            f'{worst_ratio:.2f})')
 
   # ---- Adam at t = 1 on ALL parameters (Keras form, gan_manager.py:175-183)
   for tag, opt, lr in (('g', gan.g_optimizer, gan.g_lr), ('d', gan.d_optimizer, gan.d_lr)):
@@ -181,10 +189,14 @@ def test_cfg1_lowres_train_g_d_fp32_and_bf16():
   # ---- EMA: hard copy in the first cluster (gan_manager.py:642-655)
   assert torch.equal(gan.ema_generator.store.theta, gan.generator.store.theta)
   m32 = gan._save_metrics_to_dict()
-  for key in ('gen/gen_gan_loss', 'dis/disc_loss', 'gen/depth_loss', 'gen/wc_loss', 'gen/gen_loss',
-              'gen/grad_norm', 'dis/grad_norm'):
-    r = ref['metrics'][key]
+  for key in ('gen/gen_gan_loss', 'dis/disc_loss', 'gen/depth_loss', 'gen/wc_loss', 'gen/gen_loss'):
+    r = ref['metrics'][key]   # forward quantities: well-conditioned, direct 1e-3
     assert abs(float(m32[key]) - r) <= 1e-3 * max(1.0, abs(r)), (key, float(m32[key]), r)
+  for key in ('gen/grad_norm', 'dis/grad_norm'):   # functions of the gradients: fp64 yardstick
+    r64, r32 = ref64['metrics'][key], ref['metrics'][key]
+    assert abs(float(m32[key]) - r64) <= 5.0 * abs(r32 - r64) + 1e-3 * max(1.0, abs(r64)), \
+        (key, float(m32[key]), r32, r64)
+  del ref64
 
   # ---- bf16 path on the same initial weights
   theta_g, state_g = cap['g_theta0'], {k: gp[k] for k in gan.generator.store.state_names}
@@ -213,6 +225,48 @@ def test_cfg1_lowres_train_g_d_fp32_and_bf16():
     print(f'cfg1 bf16 {tag}: gradient cosine {cos:.4f}, ||diff||/||ref|| {rel:.3f}')
     assert cos > 0.95, (tag, cos, rel)
   assert bool(torch.isfinite(gan.generator.store.theta).all())
+
+
+def test_cfg1_generator_gradients_well_conditioned():
+  """Every generator parameter gradient at cfg1's real dimensions (gen_dims 128, ResNet-101,
+  128x256, batch 2) vs oracle autograd to 1e-3 per tensor, in the well-conditioned setting: zero
+  padding (training flag) but batch norm on (randomised) moving statistics, random affine / bias
+  values, random cotangents on rgb and depth.  No batch-statistics amplification, so fp32
+  implementations agree (compare test_cfg1_lowres_train_g_d_fp32_and_bf16)."""
+  gin_lite.clear_config()
+  G = image_models.ResNetGenerator(image_size=128, gen_dims=128, resnet_version='101', device=DEV,
+                                   seed=-3, dtype=torch.float32)
+  _randomise_inference_state(G)
+  batch = synth_batch(2, 128, seed=55)
+  p = {k: v.detach().cpu().clone().requires_grad_(k in G.store.trainable_names)
+       for k, v in G.store.views.items()}
+  t0 = time.time()
+  outs_o, _ = O.generator_forward(p, batch, True, gen_dims=128, resnet_version='101', z_dim=128,
+                                  bn_training=False)
+  gen = torch.Generator().manual_seed(6)
+  w_rgb = torch.randn(outs_o[6].shape, generator=gen)
+  w_d = torch.randn(outs_o[3].shape, generator=gen)
+  ((outs_o[6] * w_rgb).sum() + (outs_o[3] * w_d).sum()).backward()
+  print(f'oracle generator fwd+bwd: {time.time() - t0:.1f} s')
+  ctx = G.make_ctx(True, record=True)
+  ctx.bn_use_moving = True
+  outs, (push_rgb, push_depth) = G.forward(ctx, {k: v.to(DEV) for k, v in batch.items()})
+  assert rel_err(outs[6].cpu().numpy(), outs_o[6].detach().numpy()) < 1e-4
+  assert rel_err(outs[3].cpu().numpy(), outs_o[3].detach().numpy()) < 1e-4
+  push_rgb(w_rgb.to(DEV))
+  push_depth(w_d.to(DEV))
+  ctx.backward()
+  G.spectral.backward_fixup()
+  gmax = max(float(p[k].grad.abs().max()) for k in G.store.trainable_names)
+  errs = []
+  for k in G.store.trainable_names:
+    go = p[k].grad.numpy()
+    gh = G.store.grad_views[k].cpu().numpy()
+    err = float(np.abs(gh - go).max() / max(np.abs(go).max(), 1e-4 * gmax))
+    errs.append(err)
+    assert err < 1e-3, (k, err)
+  print(f'{len(errs)} tensors: max {max(errs):.2e}, median {np.median(errs):.2e}')
+  assert np.median(errs) < 1e-4
 
 
 # ======================================================================================= cfg2
@@ -390,9 +444,47 @@ def test_cfg5_warp_1024x2048_two_views_bit_exact(depth_kind):
     xs_o.append(xo); fs_o.append(fo); xs_g.append(xg); fs_g.append(fg)
   mem_x, mem_f = np.concatenate(xs_o, 2), np.concatenate(fs_o, 1)
   d_o, f_o = warp_c.project_feats_to_equirectangular(mem_f, mem_x, h, w, -1, 20.0, offset=target)
+  # the views are unprojected straight into their windows of one memory (no concat copy)
+  gx = torch.empty((1, 4, views * h * w), dtype=torch.float32, device=DEV)
+  gf = torch.empty((1, views * h * w, 3), dtype=torch.int32, device=DEV)
+  for v, (rgb, depth, pos) in enumerate(panos):
+    pano_utils.equirectangular_to_pointcloud(t(rgb), t(depth), -1, 20.0, position=t(pos),
+                                             out=(gx, gf, v * h * w))
+  assert torch.equal(gx, torch.cat(xs_g, 2)) and torch.equal(gf, torch.cat(fs_g, 1))
   d_g, f_g, m_g = pano_utils.project_feats_to_equirectangular(
-      torch.cat(fs_g, 1), torch.cat(xs_g, 2), h, w, -1, 20.0, offset=t(target), with_mask=True)
+      gf, gx, h, w, -1, 20.0, offset=t(target), with_mask=True)
   np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
   np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
   np.testing.assert_array_equal(m_g.cpu().numpy()[..., None], warp_np.proj_mask(d_o, f_o, -1))
   assert 0.2 < float(m_g.mean()) <= 1.0
+
+
+def test_quantize_steps_bit_exact():
+  """models.py:198,:289-291,:325-331,:353 through se3ds_quantize vs the NumPy statement order."""
+  rng = np.random.default_rng(3)
+  g = rng.uniform(-0.01, 1.01, (1, 64, 128, 3)).astype(F32)
+  g.reshape(-1)[:512] = (np.arange(512) / 255.0).astype(F32)[:512]   # values on the integer grid
+  g.reshape(-1)[512:520] = [0.0, 1.0, -0.0, 0.999999, 1.0000001, -1e-9, 0.5, 1 / 255]
+  t = torch.from_numpy(g).to(DEV)
+  q = models._quantize
+  np.testing.assert_array_equal(
+      q(t, torch.int32, mul=255.0, lo=-1, hi=255).cpu().numpy(),
+      np.clip(np.trunc(g * F32(255)).astype(np.int32), -1, 255))
+  np.testing.assert_array_equal(
+      q(t, torch.int32, mul=255.0, lo=0, hi=255, pre=(0.0, 1.0)).cpu().numpy(),
+      np.trunc(np.clip(g, 0, 1) * F32(255)).astype(np.int32))
+  np.testing.assert_array_equal(q(t[..., 0], torch.float32, lo=0.0, hi=1.0).cpu().numpy(),
+                                np.clip(g[..., 0], 0, 1))
+  proj = rng.integers(-1, 256, (1, 64, 128, 3)).astype(F32)
+  pr = np.clip((proj / F32(255)).astype(F32), 0, 1)
+  got = q(torch.from_numpy(proj).to(DEV), torch.float32, div=255.0, lo=0.0, hi=1.0)
+  np.testing.assert_array_equal(got.cpu().numpy(), pr)
+  np.testing.assert_array_equal(q(got, torch.uint8, mul=255.0, lo=0, hi=255).cpu().numpy(),
+                                np.trunc(pr * F32(255)).astype(np.uint8))
+  rgb = rng.integers(0, 256, (1, 64, 128, 3)).astype(np.int32)
+  np.testing.assert_array_equal(
+      q(torch.from_numpy(rgb).to(DEV), torch.float32, div=255.0, lo=-1.0, hi=1.0).cpu().numpy(),
+      (rgb / 255).astype(F32))   # int / int: float64 true division, then cast (tf.cast(x / 255))
+  u8 = rgb.astype(np.uint8)
+  np.testing.assert_array_equal(q(torch.from_numpy(u8).to(DEV), torch.int32, lo=0, hi=255).cpu().numpy(),
+                                rgb)

@@ -74,14 +74,7 @@ def _worker(rank, world, port, mode, out):
       gp, dp = _toy_params()
       full = _batch(2, 64, 5)
       shard = dist_utils.shard_batch(full, rank, world)
-      def pooled(name, s1, s2, cnt):   # SyncBN: statistics over all replicas
-        t = torch.stack([s1.detach(), s2.detach()])
-        dist.all_reduce(t)
-        # keep autograd: replace the values, keep the local graph contribution (as TF does
-        # with the cross-replica sum inside the tape)
-        s1 = s1 + (t[0] - s1.detach())
-        s2 = s2 + (t[1] - s2.detach())
-        return s1, s2, cnt * world
+      pooled = O.pooled_stats_hook(world)   # SyncBN: differentiable cross-replica sums
       torch.manual_seed(0)
       cfg = _cfg()
       # the oracle's generator takes the hook through a patched Net

@@ -856,7 +856,10 @@ def test_adam_and_ema_recurrences_vs_oracle(num_batched_steps, steps):
                    for n in _opt.model.store.trainable_names}
       return _orig(*a, **kw)
     opt.apply_gradients = wrap
-  close = lambda a, b: torch.allclose(a, b, rtol=3e-7, atol=1e-9)
+  # parameters: 3e-5 of the step size (the update's own fp32 noise: fused vs separate multiply-
+  # add in the slot recurrences) + 2.5 ulp; slots / averages: 1e-5 of the tensor's scale
+  close_p = lambda a, b, lr: torch.allclose(a, b, rtol=3e-7, atol=3e-5 * lr)
+  close = lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=1e-6 * float(b.abs().max()) + 1e-30)
   for step in range(steps):
     batch = {k: v.to(DEV) for k, v in synth_batch(2, size, seed=200 + step).items()}
     gs = gan.global_step
@@ -869,7 +872,7 @@ def test_adam_and_ema_recurrences_vs_oracle(num_batched_steps, steps):
         m0, v0 = slots[tag][k]
         newp, m1, v1 = O.adam_keras(p[tag][k], cap[tag][k], m0, v0, lr, 0.5, 0.999, step + 1)
         o, cnt, shape = model.store._off_tr[k]
-        assert close(model.store[k].cpu(), newp), (step, tag, k)
+        assert close_p(model.store[k].cpu(), newp, lr), (step, tag, k)
         assert close(opt.m[o:o + cnt].view(shape).cpu(), m1), (step, tag, k, 'm')
         assert close(opt.v[o:o + cnt].view(shape).cpu(), v1), (step, tag, k, 'v')
         p[tag][k], slots[tag][k] = newp, (m1, v1)

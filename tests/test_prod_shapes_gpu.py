@@ -112,6 +112,7 @@ def _oracle(case, n):
   if bias:
     p['c/bias'] = b.clone().requires_grad_(True)
   ys, dxs, ums = [], [], []
+  db64 = torch.zeros(cout, dtype=torch.float64) if (bias and kind.startswith('partial')) else None
   for c0 in range(0, n, chunk):
     xo = x[c0:c0 + chunk].clone().requires_grad_(True)
     net = O.Net(p, training=True)
@@ -123,6 +124,16 @@ def _oracle(case, n):
         m_in = O.pad_layer(m, pad, circular_pad=False, training=True) if pad else m
       yo, umo = net.partial_conv(xin, m_in, 'c', stride, padding, spectral=kind == 'partial_spectral')
       ums.append(umo.detach())
+      if db64 is not None:
+        # y = ((conv - b) * ratio + b) * um  =>  dy/db = (1 - ratio) * um (layers.py:199-203).  Where
+        # the window is full, 1 - ratio is ~1e-6 and autograd's fp32 "sum(dy um) - sum(dy um ratio)"
+        # cancels to noise (15 % off on the 1x1 bottlenecks); the derivative is evaluated in
+        # binary64 from the oracle's own fp32 ratio / update_mask instead.
+        ones = torch.ones((chunk if m_in is None else m_in.shape[0], xin.shape[1], xin.shape[2], 1))
+        raw = O.tf_conv2d(ones if m_in is None else m_in, torch.ones((k, k, 1, 1)), stride, padding)
+        ratio = (k * k) / (raw + 1e-6) * torch.clamp(raw, 0, 1)
+        wgt = (1.0 - ratio.double()) * umo.detach().double()
+        db64 += (gy[c0:c0 + chunk].double() * wgt).sum(dim=(0, 1, 2))
     elif kind == 'spectral':
       yo = net.spectral_conv(xin, 'c', stride, padding)
     else:
@@ -131,7 +142,7 @@ def _oracle(case, n):
     ys.append(yo.detach())
     dxs.append(xo.grad)
   res = dict(y=torch.cat(ys).numpy(), dx=torch.cat(dxs).numpy(), dk=ko.grad.numpy(),
-             db=p['c/bias'].grad.numpy() if bias else None,
+             db=(db64.numpy() if db64 is not None else p['c/bias'].grad.numpy()) if bias else None,
              um=torch.cat(ums).numpy()[..., 0] if ums else None)
   _ORACLE_CACHE.clear()   # keep one entry: the fp32 and bf16 variants of a case run back to back
   _ORACLE_CACHE[key] = res

@@ -311,3 +311,48 @@ def test_splat_banded_tiles_bit_exact():
                      env=env, cwd=root, capture_output=True, text=True, timeout=600)
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
   assert ' passed' in r.stdout
+
+
+@pytest.mark.parametrize('h', [64, 1024])
+def test_device_fast_screen_error_bound(h):
+  """The fast index screen as the DEVICE evaluates it (hardware reciprocal / square root inside,
+  include/se3ds_geom_math.h): every index it decides equals the exact chain's, and its deviation
+  from the exact (fx, fy) stays >= 8x below the margin -- over 4.4 M points incl. the wrap, the
+  poles, the equator, denormal-scale clouds and exact ties."""
+  rng = np.random.default_rng(50 + h)
+  w, m = 2 * h, 400_000
+  clouds = [rng.standard_normal((3, m)) * rng.uniform(0.01, 20, (1, m)) for _ in range(5)]
+  for axis, scale in [(0, 1e-4), (1, 1e-4), (2, 1e-5)]:
+    v = rng.standard_normal((3, m))
+    v[axis] *= scale
+    clouds.append(v)
+  v = rng.standard_normal((3, m))
+  v[:2] *= 1e-3
+  clouds.append(v)
+  clouds.append(rng.standard_normal((3, m)) * 1e-18)
+  clouds.append(rng.integers(-3, 4, (3, m)).astype(np.float64))
+  margin = 4.0e-6   # SE3DS_FAST_MARGIN
+  decided_total = 0
+  for c in clouds:
+    xyz = c.astype(F32)
+    proj = warp_c.equirect_project_coords(np.concatenate([xyz, np.ones((1, m), F32)])[None])[0]
+    px, py, pz = proj[0], proj[1], proj[2]
+    with np.errstate(divide='ignore', invalid='ignore'):
+      vx = np.where(pz == 0, F32(0), px / pz).astype(F32)
+      vy = np.where(pz == 0, F32(0), py / pz).astype(F32)
+    fx = ((vx + F32(1)) / F32(2) * F32(w)).astype(F32)
+    fy = ((vy + F32(1)) / F32(2) * F32(h)).astype(F32)
+    ok = (fx > -1) & (fx < w) & (fy > -1) & (fy < h) & (pz > 0)
+    idx = np.where(ok, np.trunc(fy).astype(np.int64) * w + np.trunc(fx).astype(np.int64), -1)
+    gx, gy, verdict = point_cloud_utils.debug_fast_fxy(t(xyz), h, w)
+    gx, gy, verdict = gx.cpu().numpy(), gy.cpu().numpy(), verdict.cpu().numpy()
+    dec = verdict >= -1
+    decided_total += int(dec.sum())
+    np.testing.assert_array_equal(verdict[dec], idx[dec])
+    fin = np.isfinite(fx) & np.isfinite(gx) & np.isfinite(fy) & np.isfinite(gy) & (pz > 0)
+    dx = np.abs(gx[fin].astype(np.float64) - fx[fin]) / w
+    dy = np.abs(gy[fin].astype(np.float64) - fy[fin]) / h
+    dx = dx[dx < 0.99]   # the heading wrap: both chains sit on an integer, the screen abstains
+    assert dx.size == 0 or dx.max() <= margin / 8, dx.max()
+    assert dy.size == 0 or dy.max() <= margin / 8, dy.max()
+  assert decided_total > 0.5 * len(clouds) * m
