@@ -396,6 +396,26 @@ int se3ds_spectral_vpart_len(void);
 int se3ds_spectral_power_iter(const int64_t* table, int nlayers, int training, void* stream);
 int se3ds_spectral_bwd_fixup(const int64_t* table, int nlayers, void* stream);
 
+/* ======================================================================================
+ * Input pipeline, device-side half
+ * ====================================================================================== */
+
+/* datasets/indoor_datasets.py:263-375 (_transform_fn) + :553-597 (_train_batch_transform_fn) on
+ * decoded frames resident in HBM: convert_image_dtype (:185-228), band masking of proj_mask
+ * (:281-304), bilinear (image) / nearest (everything else) resize to (rh, rw) (:312-314), roll by
+ * `roll` and optional flip along W (:34-61), crop at (crop_y, crop_x) to (h, w) (:326-330),
+ * proj_image *= proj_mask and proj_depth *= proj_mask (:577-585).  Raw frames are (N,H0,W0[,3]);
+ * iparams [N][8] = rh, rw, roll, flip, crop_y, crop_x, hmode (0 none / 1 start<x<end / 2 x>start
+ * or x<end), vmode (0 / 1); fparams [N][4] = hstart, hend, vstart, vend (raw-grid pixels).
+ * Outputs are the step's batch dict entries, fp32 (N,h,w,C) and int32 segmentation. */
+int se3ds_input_transform(const uint8_t* image, const uint8_t* proj_image, const uint16_t* depth,
+                          const uint16_t* proj_depth, const uint8_t* proj_mask,
+                          const uint8_t* blurred_mask, const uint8_t* segmentation,
+                          const int32_t* iparams, const float* fparams, int n, int h0, int w0, int h,
+                          int w, float* o_image, float* o_proj_image, float* o_proj_mask,
+                          float* o_proj_depth, float* o_depth, float* o_blurred, int32_t* o_seg,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

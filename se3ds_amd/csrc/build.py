@@ -18,6 +18,7 @@ COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-
 # the contraction kernels are free to fuse.
 PER_FILE = {
     'geom.hip': ['-ffp-contract=off'],
+    'input.hip': ['-ffp-contract=off'],
 }
 
 
