@@ -85,6 +85,17 @@ int se3ds_project_equirect(const float* xyz1, const float* offset, const void* f
                            float* feat, float* mask, float mask_void, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* The same over the first `m` points of a preallocated point-cloud MEMORY of `capacity` points
+ * per image -- xyz1 (N,4,capacity), feats (N,capacity,C) -- so that a trajectory appends frames in
+ * place (se3ds_unproject_equirect_into) and renders without ever concatenating or copying the
+ * memory (utils/eval_metric.py:162-165,236-239; trainers/gan_manager.py:476-485,540-541). */
+int se3ds_project_equirect_memory(const float* xyz1, const float* offset, const void* feats,
+                                  int feat_dtype, int n, int64_t m, int64_t capacity, int channels,
+                                  int height, int width, float depth_scale, float input_void,
+                                  float output_void, float* depth, float* feat, float* mask,
+                                  float mask_void, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+
 /* project_to_feat -- reference utils/point_cloud_utils.py:90-183 on already transformed
  * coordinates (N,4,M) = (x, y, z, 1).  Same outputs/semantics as above. */
 int se3ds_project_to_feat(const float* coords, const void* feats, int feat_dtype, int n, int64_t m,
@@ -136,6 +147,27 @@ int se3ds_perspective_coords(const float* rays, const float* w2i, int64_t q, int
  * (two fp32 3x3 products per pixel, in that order); out (height*width, 2) = (u, v). */
 int se3ds_persp_from_equirect_coords(const float* kinv_t, const float* rot, int height, int width,
                                      int eq_h, int eq_w, float* out, void* stream);
+
+/* Fused perspective paths (notebooks/SE3DS_RE10K_Colab.ipynb cells 15, 17).
+ * se3ds_perspective_to_pointcloud = project_perspective_image(image) and (depth)
+ * (utils/pano_utils.py:344-417, constant padding `pad_value`), int32(image * 255), and
+ * equirectangular_to_pointcloud (:164-242, + optional position (3)) without the two equirect
+ * intermediates: image (ih,iw,C<=4) fp32, depth (ih,iw) fp32, rays (3,H*W) = equirectangular
+ * pixel rays, w2i (3,3) = get_world_to_image_transform; outputs xyz1 (1,4,H*W), feats (1,H*W,C)
+ * int32.  se3ds_perspective_guidance = the three get_perspective_from_equirectangular_image
+ * calls (:443-476) of cell 17 on the splat outputs pred_rgb (H,W,3) / pred_depth (H,W) -- RGB,
+ * depth, and the mask (depth != 0, != 1, all(rgb != 0)) -- with the glue: rgb / 255 clipped,
+ * mask == 1, products with the mask: proj_image (h,w,3), proj_depth (h,w), proj_mask (h,w). */
+int se3ds_perspective_to_pointcloud(const float* image, const float* depth, int ih, int iw,
+                                    int channels, const float* rays, const float* w2i,
+                                    int round_nearest, float pad_value, const float* sin_el,
+                                    const float* cos_el, const float* sin_hd, const float* cos_hd,
+                                    const float* position, int height, int width, float void_class,
+                                    float depth_scale, float* xyz1, int32_t* feats_out, void* stream);
+int se3ds_perspective_guidance(const float* pred_rgb, const float* pred_depth, int eq_h, int eq_w,
+                               const float* kinv_t, const float* rot, int height, int width,
+                               float* proj_image, float* proj_depth, float* proj_mask,
+                               void* stream);
 
 /* mask_pano -- utils/pano_utils.py:245-265: rows [mh, H-mh] kept, others := value. */
 int se3ds_mask_pano(const void* pano, int dtype, int n, int height, int width, int channels,
@@ -341,7 +373,8 @@ int se3ds_head_bwd(const float* dy, const float* y, const void* x, int dtype, in
  * Losses -- trainers/se3ds_trainer.py:39-71,148-234 (fp32)
  * ====================================================================================== */
 /* out[n] = per-sample sum; mode 0: sum(a); 1: sum(|a-b|*m[p]); 2: count(0<a<1);
- * 3: sum(a*(1-b)).  a,b: (n,p,c); m: (n,p). */
+ * 3: sum(a*(1-b)); 4: sum((a-b)^2 * 1[0<b<1]) (depth RMSE numerator, utils/eval_metric.py:225-231).
+ * a,b: (n,p,c); m: (n,p). */
 int se3ds_sample_sum(const float* a, const float* b, const float* m, int n, int64_t p, int c,
                      int mode, float* out, float* workspace /* n*256 floats */, void* stream);
 /* grad = coef[n]*sign(a-b)*w; mode 0: w = 1[0<b<1] (depth L1); mode 1: w = m*(1-m2) (wc). */

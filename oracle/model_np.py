@@ -114,3 +114,63 @@ class SE3DSModelOracle:
                 pred_rgb=pred_rgb_u8,
                 proj_depth=proj_depth, pred_depth=pred_depth, mu=mu, logvar=logvar,
                 proj_mask=proj_mask, generated=generated, pc_rgb=pc_rgb)
+
+
+def generated_rollout(params, gen_cfg, inputs, eval_seq_len, predict_depth=True,
+                      unproject_void_class=INVALID_RGB_VALUE, feedback=None):
+  """utils/eval_metric.py `_get_generated_pool.step_fn` :144-239 (without the Inception half) /
+  trainers/gan_manager.py `_get_image_grid` :458-541, statement by statement on NumPy arrays.
+  inputs: image (N,T,H,W,3), depth (N,T,H,W,1), position (N,T,3), depth_scale (N,).
+  `feedback[k] = (generated, depth_out)`: when given, THESE arrays (another implementation's
+  generator outputs) are fed back into the memory instead of this oracle's own, so that the warp /
+  quantisation half of every later frame can be compared bit for bit."""
+  image, depth, position = (np.asarray(inputs[k], F32) for k in ('image', 'depth', 'position'))
+  n, _, h, w, _ = image.shape
+  depth_scale = float(np.asarray(inputs['depth_scale'])[0])
+  memory_coords = np.zeros((n, 4, 0), F32)
+  memory_feats = np.zeros((n, 0, 3), np.int32)
+  out = dict(generated=[], pred_depth=[], projected=[], proj_mask=[], proj_depth=[], depth_rmse=[],
+             depth_out=[])
+  for k in range(eval_seq_len):
+    target_depth = depth[:, k]
+    rgb_tensor = image[:, k]
+    depth_tensor = depth[:, k]
+    rel = position[:, k]
+    pred_depth, pred_rgb = warp_c.project_feats_to_equirectangular(
+        memory_feats, memory_coords, h, w, INVALID_RGB_VALUE, depth_scale, offset=rel)
+    pred_mask = warp_np.proj_mask(pred_depth, pred_rgb, INVALID_RGB_VALUE)
+    pred_depth = pred_depth[..., None]
+    pred_rgb = np.clip((pred_rgb / F32(255)).astype(F32), 0, 1)
+    cond = {'proj_image': torch.from_numpy(pred_rgb), 'proj_mask': torch.from_numpy(pred_mask),
+            'proj_depth': torch.from_numpy(pred_depth.copy()),
+            'blurred_mask': torch.zeros(pred_depth.shape)}
+    with torch.no_grad():
+      outs, _ = O.generator_forward(params, cond, False, **gen_cfg)
+    depth_out, generated = outs[3].numpy(), outs[6].numpy()
+    out['depth_out'].append(depth_out)
+    own_generated = generated
+    if feedback is not None:
+      generated, depth_out = feedback[k]
+    if k == 0:
+      rgb_tensor = warp_np.mask_pano(rgb_tensor, masked_region_value=INVALID_RGB_VALUE)
+    else:
+      rgb_tensor = generated
+      if predict_depth and depth_out is not None:
+        depth_tensor = depth_out
+    m = ((target_depth > 0) & (target_depth < 1)).astype(F32)
+    diff = ((depth_tensor - target_depth) ** 2 * m).sum(axis=(1, 2, 3)) / np.maximum(
+        m.sum(axis=(1, 2, 3)), 1)
+    out['depth_rmse'].append(np.sqrt(diff))
+    pc_rgb = np.clip(np.trunc(rgb_tensor * F32(255)).astype(np.int32), INVALID_RGB_VALUE, 255)
+    xyz1, feats = warp_np.equirectangular_to_pointcloud(pc_rgb, depth_tensor[..., 0],
+                                                        unproject_void_class, depth_scale)
+    xyz1 = (xyz1 + np.concatenate([rel, np.zeros((n, 1), F32)], 1)[:, :, None]).astype(F32)
+    memory_coords = np.concatenate([memory_coords, xyz1], axis=2)
+    memory_feats = np.concatenate([memory_feats, feats.astype(np.int32)], axis=1)
+    out['generated'].append(own_generated)
+    out['pred_depth'].append(depth_tensor)
+    out['projected'].append(pred_rgb)
+    out['proj_mask'].append(pred_mask)
+    out['proj_depth'].append(pred_depth)
+  out['memory_coords'], out['memory_feats'] = memory_coords, memory_feats
+  return out

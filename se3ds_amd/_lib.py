@@ -25,6 +25,8 @@ _SIGS = {
     'se3ds_splat_workspace_bytes': (c_sz, [c_int, c_i64, c_int, c_int, c_int]),
     'se3ds_project_equirect': (c_int, [c_p, c_p, c_p, c_int, c_int, c_i64, c_int, c_int, c_int,
                                        c_f, c_f, c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
+    'se3ds_project_equirect_memory': (c_int, [c_p, c_p, c_p, c_int, c_int, c_i64, c_i64, c_int, c_int,
+                                              c_int, c_f, c_f, c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
     'se3ds_project_to_feat': (c_int, [c_p, c_p, c_int, c_int, c_i64, c_int, c_int, c_int, c_f, c_f,
                                       c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
     'se3ds_splat_debug_indices': (c_int, [c_p, c_int, c_i64, c_p, c_p, c_p]),
@@ -37,6 +39,10 @@ _SIGS = {
     'se3ds_perspective_coords': (c_int, [c_p, c_p, c_i64, c_int, c_f, c_p, c_p]),
     'se3ds_persp_from_equirect_coords': (c_int, [c_p, c_p, c_int, c_int, c_int, c_int, c_p, c_p]),
     'se3ds_input_transform': (c_int, [c_p] * 9 + [c_int] * 5 + [c_p] * 8),
+    'se3ds_perspective_to_pointcloud': (c_int, [c_p, c_p, c_int, c_int, c_int, c_p, c_p, c_int, c_f, c_p, c_p,
+                                                c_p, c_p, c_p, c_int, c_int, c_f, c_f, c_p, c_p, c_p]),
+    'se3ds_perspective_guidance': (c_int, [c_p, c_p, c_int, c_int, c_p, c_p, c_int, c_int, c_p, c_p, c_p,
+                                           c_p]),
     'se3ds_mask_pano': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_f, c_p, c_p]),
     'se3ds_compact_workspace_bytes': (c_sz, [c_i64]),
     'se3ds_compact_valid': (c_int, [c_p, c_p, c_int, c_int, c_i64, c_int, c_f, c_p, c_p, c_p, c_p,

@@ -172,11 +172,12 @@ splat_init_kernel(float* __restrict__ zmin, float* __restrict__ feat, int64_t np
 template <typename T, bool EQUIRECT>
 __global__ void __launch_bounds__(kBlock)
 splat_zmin_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
-                  const T* __restrict__ feats, int64_t m, int channels, int height, int width,
-                  float input_void, float* __restrict__ zmin, SplatWs ws) {
+                  const T* __restrict__ feats, int64_t m, int64_t ld, int channels, int height,
+                  int width, float input_void, float* __restrict__ zmin, SplatWs ws) {
+  // ld: capacity (in points) of the memory the first m points of every image live in
   const int b = blockIdx.y;
   const int64_t hw = (int64_t)height * width;
-  const float* X = coords + (int64_t)b * 4 * m;
+  const float* X = coords + (int64_t)b * 4 * ld;
   float ox = 0.f, oy = 0.f, oz = 0.f;
   if (EQUIRECT && offset) {
     ox = offset[b * 3 + 0];
@@ -187,7 +188,7 @@ splat_zmin_kernel(const float* __restrict__ coords, const float* __restrict__ of
   for (int64_t i0 = (int64_t)blockIdx.x * kBlock; i0 < m; i0 += (int64_t)gridDim.x * kBlock) {
     int64_t i = i0 + threadIdx.x;
     if (i < m) {
-      float x = X[i], y = X[m + i], z = X[2 * m + i];
+      float x = X[i], y = X[ld + i], z = X[2 * ld + i];
       float px, py, pz;
       if (EQUIRECT) {
         if (offset) {
@@ -201,7 +202,7 @@ splat_zmin_kernel(const float* __restrict__ coords, const float* __restrict__ of
         py = y;
         pz = z;
       }
-      const T* f = feats + ((int64_t)b * m + i) * channels;
+      const T* f = feats + ((int64_t)b * ld + i) * channels;
       int fv = 1;
       for (int k = 0; k < channels; ++k) fv &= (FeatIO<T>::load(f + k) != input_void);
       int32_t idx = se3ds_splat_index(px, py, pz, width, height, fv);
@@ -270,8 +271,9 @@ splat_sink_feat_kernel(SplatWs ws, int nparts, int channels) {
 // K2: survivors (z < zmin + 0.1) scatter-max their features; the rest go to the sink.
 template <typename T, bool ORDERED>
 __global__ void __launch_bounds__(kBlock)
-splat_resolve_kernel(const T* __restrict__ feats, int64_t m, int channels, int height, int width,
-                     const float* __restrict__ zmin, float* __restrict__ feat, SplatWs ws) {
+splat_resolve_kernel(const T* __restrict__ feats, int64_t m, int64_t ld, int channels, int height,
+                     int width, const float* __restrict__ zmin, float* __restrict__ feat,
+                     SplatWs ws) {
   const int b = blockIdx.y;
   const int64_t hw = (int64_t)height * width;
   constexpr int kMaxC = 4;  // wave-reduced sink channels per pass
@@ -290,7 +292,7 @@ splat_resolve_kernel(const T* __restrict__ feats, int64_t m, int channels, int h
         float zm = zmin[fl];
         if (fl == 0 && have_sink_z) zm = sink_z < zm ? sink_z : zm;
         bool keep = (idx >= 0) && (z < zm + 0.1f);
-        const T* f = feats + ((int64_t)b * m + i) * channels;
+        const T* f = feats + ((int64_t)b * ld + i) * channels;
 #pragma unroll
         for (int k = 0; k < kMaxC; ++k) {
           if (c0 + k < channels) {
@@ -520,14 +522,14 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* s_
 template <typename T, bool EQUIRECT>
 __global__ void __launch_bounds__(kChunkThreads)
 splat_bin_count_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
-                       const T* __restrict__ feats, int64_t m, int64_t per, int channels,
+                       const T* __restrict__ feats, int64_t m, int64_t ld, int64_t per, int channels,
                        int height, int width, uint64_t wmagic, float input_void, int ntiles,
                        int tiles_x, SplatWs ws, BinWs bw) {
   extern __shared__ uint32_t s_hist[];   // [ntiles]
   const int b = blockIdx.y;
   for (int t = threadIdx.x; t < ntiles; t += kChunkThreads) s_hist[t] = 0u;
   __syncthreads();
-  const float* X = coords + (int64_t)b * 4 * m;
+  const float* X = coords + (int64_t)b * 4 * ld;
   float ox = 0.f, oy = 0.f, oz = 0.f;
   if (EQUIRECT && offset) {
     ox = offset[b * 3 + 0];
@@ -560,14 +562,14 @@ splat_bin_count_kernel(const float* __restrict__ coords, const float* __restrict
   };
   auto load = [&](int64_t i, float* x, float* y, float* z, int* fv) {
     *x = X[i];
-    *y = X[m + i];
-    *z = X[2 * m + i];
+    *y = X[ld + i];
+    *z = X[2 * ld + i];
     if (EQUIRECT && offset) {
       *x = *x - ox;
       *y = *y - oy;
       *z = *z - oz;
     }
-    const T* f = feats + ((int64_t)b * m + i) * channels;
+    const T* f = feats + ((int64_t)b * ld + i) * channels;
     int v = 1;
     for (int k = 0; k < channels; ++k) v &= (FeatIO<T>::load(f + k) != input_void);
     *fv = v;
@@ -668,7 +670,7 @@ splat_bin_colscan_kernel(BinWs bw, int chunks, int ntiles, int nb) {
 // points feed the sink.
 template <typename T>
 __global__ void __launch_bounds__(kChunkThreads)
-splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int64_t per, int channels,
+splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int64_t ld, int64_t per, int channels,
                          int width, uint64_t wmagic, int ntiles, int tiles_x, SplatWs ws,
                          BinWs bw) {
   extern __shared__ uint32_t s_base[];   // [ntiles] next free record of this chunk, per tile
@@ -703,7 +705,7 @@ splat_bin_scatter_kernel(const T* __restrict__ feats, int64_t m, int64_t per, in
   const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
   const int32_t* I = ws.idx + (int64_t)b * m;
   const float* Z = ws.z + (int64_t)b * m;
-  const T* F = feats + (int64_t)b * m * channels;
+  const T* F = feats + (int64_t)b * ld * channels;
   for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += kU * kChunkThreads) {
     int32_t idx[kU];
     float z[kU], f[kU][kMaxC];
@@ -1018,6 +1020,7 @@ splat_sink_feat2_kernel(SplatWs ws, BinWs bw, int nparts, int nb, int channels, 
 
 template <typename T, bool EQUIRECT>
 int launch_splat_binned(const float* coords, const float* offset, const T* feats, int n, int64_t m,
+                        int64_t ld,
                         int channels, int height, int width, float depth_scale, float input_void,
                         float output_void, float* depth, float* feat, float* mask, float mask_void,
                         void* workspace, hipStream_t stream) {
@@ -1032,12 +1035,12 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
   const dim3 g_pt((unsigned)cg.chunks, (unsigned)n);
   const int nparts = cg.chunks * n;
   hipLaunchKernelGGL((splat_bin_count_kernel<T, EQUIRECT>), g_pt, dim3(kChunkThreads), 4 * ntiles,
-                     stream, coords, offset, feats, m, cg.per, channels, height, width, wmagic,
+                     stream, coords, offset, feats, m, ld, cg.per, channels, height, width, wmagic,
                      input_void, ntiles, tiles_x, ws, bw);
   hipLaunchKernelGGL(splat_bin_colscan_kernel, dim3(ceil_div(nb, 64)), dim3(64 * kScanWaves), 0,
                      stream, bw, cg.chunks, ntiles, nb);
   hipLaunchKernelGGL((splat_bin_scatter_kernel<T>), g_pt, dim3(kChunkThreads), 4 * ntiles, stream,
-                     feats, m, cg.per, channels, width, wmagic, ntiles, tiles_x, ws, bw);
+                     feats, m, ld, cg.per, channels, width, wmagic, ntiles, tiles_x, ws, bw);
   const size_t tile_lds = 4 * (size_t)kTilePx * (1 + channels);
   const uint32_t slice = slice_records();
   const int items = (int)resolve_items_max(nb, (int64_t)n * m, slice);
@@ -1060,6 +1063,7 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
 
 template <typename T, bool EQUIRECT>
 int launch_splat(const float* coords, const float* offset, const T* feats, int n, int64_t m,
+                 int64_t ld,
                  int channels, int height, int width, float depth_scale, float input_void,
                  float output_void, float* depth, float* feat, float* mask, float mask_void,
                  void* workspace, hipStream_t stream) {
@@ -1069,7 +1073,7 @@ int launch_splat(const float* coords, const float* offset, const T* feats, int n
     if (!no_bin && m > 0 && channels <= kMaxBinChannels && ntiles <= kMaxTiles &&
         (int64_t)n * m < ((int64_t)1 << 31) &&
         (int64_t)height * width * width < ((int64_t)1 << 40))
-      return launch_splat_binned<T, EQUIRECT>(coords, offset, feats, n, m, channels, height, width,
+      return launch_splat_binned<T, EQUIRECT>(coords, offset, feats, n, m, ld, channels, height, width,
                                               depth_scale, input_void, output_void, depth, feat,
                                               mask, mask_void, workspace, stream);
   }
@@ -1087,14 +1091,14 @@ int launch_splat(const float* coords, const float* offset, const T* feats, int n
     dim3 g_pt = point_grid(m, n, kBlock);
     const int nparts = (int)(g_pt.x * g_pt.y);
     hipLaunchKernelGGL((splat_zmin_kernel<T, EQUIRECT>), g_pt, dim3(kBlock), 0, stream, coords,
-                       offset, feats, m, channels, height, width, input_void, depth, ws);
+                       offset, feats, m, ld, channels, height, width, input_void, depth, ws);
     hipLaunchKernelGGL(splat_sink_z_kernel, dim3(1), dim3(kBlock), 0, stream, ws, nparts);
     if (ordered)
       hipLaunchKernelGGL((splat_resolve_kernel<T, true>), g_pt, dim3(kBlock), 0, stream, feats, m,
-                         channels, height, width, depth, feat, ws);
+                         ld, channels, height, width, depth, feat, ws);
     else
       hipLaunchKernelGGL((splat_resolve_kernel<T, false>), g_pt, dim3(kBlock), 0, stream, feats, m,
-                         channels, height, width, depth, feat, ws);
+                         ld, channels, height, width, depth, feat, ws);
     hipLaunchKernelGGL(splat_sink_feat_kernel, dim3(1), dim3(kBlock), 0, stream, ws, nparts,
                        channels);
   }
@@ -1110,10 +1114,10 @@ int launch_splat(const float* coords, const float* offset, const T* feats, int n
 
 template <bool EQUIRECT>
 int dispatch_splat(const float* coords, const float* offset, const void* feats, int feat_dtype,
-                   int n, int64_t m, int channels, int height, int width, float depth_scale,
+                   int n, int64_t m, int64_t ld, int channels, int height, int width, float depth_scale,
                    float input_void, float output_void, float* depth, float* feat, float* mask,
                    float mask_void, void* workspace, size_t workspace_bytes, void* stream) {
-  if (n <= 0 || m < 0 || channels <= 0 || channels > 60 || height <= 0 || width <= 0)
+  if (n <= 0 || m < 0 || ld < m || channels <= 0 || channels > 60 || height <= 0 || width <= 0)
     return SE3DS_E_BADSHAPE;
   if ((int64_t)n * height * width >= (int64_t)1 << 31) return SE3DS_E_BADSHAPE;
   if (workspace_bytes < se3ds_splat_workspace_bytes(n, m, height, width, channels))
@@ -1121,15 +1125,15 @@ int dispatch_splat(const float* coords, const float* offset, const void* feats, 
   hipStream_t s = as_stream(stream);
   switch (feat_dtype) {
     case SE3DS_F32:
-      return launch_splat<float, EQUIRECT>(coords, offset, (const float*)feats, n, m, channels,
+      return launch_splat<float, EQUIRECT>(coords, offset, (const float*)feats, n, m, ld, channels,
                                            height, width, depth_scale, input_void, output_void,
                                            depth, feat, mask, mask_void, workspace, s);
     case SE3DS_I32:
-      return launch_splat<int32_t, EQUIRECT>(coords, offset, (const int32_t*)feats, n, m, channels,
+      return launch_splat<int32_t, EQUIRECT>(coords, offset, (const int32_t*)feats, n, m, ld, channels,
                                              height, width, depth_scale, input_void, output_void,
                                              depth, feat, mask, mask_void, workspace, s);
     case SE3DS_U8:
-      return launch_splat<uint8_t, EQUIRECT>(coords, offset, (const uint8_t*)feats, n, m, channels,
+      return launch_splat<uint8_t, EQUIRECT>(coords, offset, (const uint8_t*)feats, n, m, ld, channels,
                                              height, width, depth_scale, input_void, output_void,
                                              depth, feat, mask, mask_void, workspace, s);
     default:
@@ -1246,6 +1250,153 @@ persp_from_equirect_coords_kernel(const float* __restrict__ kinv_t, const float*
     float lat = se3ds_asinf(yn);
     out[i * 2 + 0] = (lon / SE3DS_F32_TWO_PI + 0.5f) * (float)(eq_w - 1);
     out[i * 2 + 1] = (lat / SE3DS_F32_PI + 0.5f) * (float)(eq_h - 1);
+  }
+}
+
+// ---------------------------------------------------------------- fused perspective paths
+// SURVEY 8f-4 (RE10K use case, notebooks/SE3DS_RE10K_Colab.ipynb cells 15 / 17).  The op-by-op
+// chains write two 1024x2048 equirect intermediates (RGB 25 MB, depth 8 MB) just to read them back
+// once; the fused kernels below evaluate the same arithmetic per output element (one rounding
+// per reference op, same order) and never materialise them.
+
+// tfa.image.interpolate_bilinear on one query (indexing 'xy': query = (x, y)) of a virtual
+// (hp, wp) grid; returns the corner indices and the clamped weights exactly as
+// interp_bilinear_kernel computes them.
+__device__ __forceinline__ void bilinear_setup(float qx, float qy, int hp, int wp, int* iy, int* ix,
+                                               float* ay, float* ax) {
+  float fy = fminf(fmaxf(0.0f, floorf(qy)), (float)(hp - 2));
+  float fx = fminf(fmaxf(0.0f, floorf(qx)), (float)(wp - 2));
+  *iy = (int)fy;
+  *ix = (int)fx;
+  float a = qy - fy, b = qx - fx;
+  *ay = (a != a) ? a : fminf(fmaxf(0.0f, a), 1.0f);
+  *ax = (b != b) ? b : fminf(fmaxf(0.0f, b), 1.0f);
+}
+__device__ __forceinline__ float bilerp(float tl, float tr, float bl, float br, float ax, float ay) {
+  float top = ax * (tr - tl) + tl;
+  float bot = ax * (br - bl) + bl;
+  return ay * (bot - top) + top;
+}
+
+// Cell 15: project_perspective_image(rgb) and (depth) [pano_utils.py:344-417, constant padding],
+// int32(rgb * 255), equirectangular_to_pointcloud [:164-242] (+ position) in one pass over the
+// equirect grid.  image (h,w,C<=4) fp32, depth (h,w) fp32; rays (3,Q); w2i = K.R (3x3).
+__global__ void __launch_bounds__(kBlock)
+perspective_to_pointcloud_kernel(const float* __restrict__ image, const float* __restrict__ depth,
+                                 int ih, int iw, int channels, const float* __restrict__ rays,
+                                 const float* __restrict__ w2i, int round_nearest, float pad_value,
+                                 const float* __restrict__ sin_el, const float* __restrict__ cos_el,
+                                 const float* __restrict__ sin_hd, const float* __restrict__ cos_hd,
+                                 const float* __restrict__ position, int height, int width,
+                                 float void_class, float depth_scale, float* __restrict__ xyz1,
+                                 int32_t* __restrict__ feats_out) {
+  float m[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) m[i] = w2i[i];
+  const int64_t q = (int64_t)height * width;
+  const int hp = ih + 2, wp = iw + 2;
+  float pos_x = 0.f, pos_y = 0.f, pos_z = 0.f;
+  if (position) { pos_x = position[0]; pos_y = position[1]; pos_z = position[2]; }
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < q;
+       i += (int64_t)gridDim.x * kBlock) {
+    const float r0 = rays[i], r1 = rays[q + i], r2 = rays[2 * q + i];
+    const float x = (m[0] * r0 + m[1] * r1) + m[2] * r2;
+    const float y = (m[3] * r0 + m[4] * r1) + m[5] * r2;
+    const float z = (m[6] * r0 + m[7] * r1) + m[8] * r2;
+    float cx = z > 0.0f ? x / z : -1.0f;
+    float cy = z > 0.0f ? y / z : -1.0f;
+    if (round_nearest) { cx = rintf(cx); cy = rintf(cy); }
+    cx = cx + 1.0f;   // account for the 1-pixel constant padding
+    cy = cy + 1.0f;
+    int iy, ix;
+    float ay, ax;
+    bilinear_setup(cx, cy, hp, wp, &iy, &ix, &ay, &ax);
+    // taps of the virtual padded image
+    auto inside = [&](int yy, int xx) { return yy >= 1 && yy <= ih && xx >= 1 && xx <= iw; };
+    const bool in00 = inside(iy, ix), in01 = inside(iy, ix + 1);
+    const bool in10 = inside(iy + 1, ix), in11 = inside(iy + 1, ix + 1);
+    const int64_t o00 = (int64_t)(iy - 1) * iw + (ix - 1);
+    const float d = bilerp(in00 ? depth[o00] : pad_value, in01 ? depth[o00 + 1] : pad_value,
+                           in10 ? depth[o00 + iw] : pad_value, in11 ? depth[o00 + iw + 1] : pad_value,
+                           ax, ay);
+    const bool valid = (d > 0.0f) && (d < 1.0f);
+    const float mask = valid ? 1.0f : 0.0f;
+    const int r = (int)(i / width), col = (int)(i - (int64_t)r * width);
+    const float rad = (d * depth_scale) * mask;
+    const float rs = rad * sin_el[r];
+    float px = rs * cos_hd[col], py = rs * sin_hd[col], pz = rad * cos_el[r];
+    if (position) { px = px + pos_x; py = py + pos_y; pz = pz + pos_z; }
+    xyz1[i] = px;
+    xyz1[q + i] = py;
+    xyz1[2 * q + i] = pz;
+    xyz1[3 * q + i] = 1.0f;
+    for (int c = 0; c < channels; ++c) {
+      const float v = bilerp(in00 ? image[o00 * channels + c] : pad_value,
+                             in01 ? image[(o00 + 1) * channels + c] : pad_value,
+                             in10 ? image[(o00 + iw) * channels + c] : pad_value,
+                             in11 ? image[(o00 + iw + 1) * channels + c] : pad_value, ax, ay);
+      // tf.cast(rgb * 255, tf.int32): truncation
+      feats_out[i * channels + c] = valid ? (int32_t)(v * 255.0f) : (int32_t)void_class;
+    }
+  }
+}
+
+// Cell 17: three get_perspective_from_equirectangular_image calls [pano_utils.py:443-476] -- RGB,
+// depth and the validity mask (depth != 0, != 1, all(rgb != 0)) -- plus the guidance glue:
+// rgb / 255 clipped to [0,1], mask == 1, products with the mask.  pred_rgb (H,W,3), pred_depth
+// (H,W) are the splat outputs; outputs are the generator's proj_image / proj_depth / proj_mask.
+__global__ void __launch_bounds__(kBlock)
+perspective_guidance_kernel(const float* __restrict__ pred_rgb, const float* __restrict__ pred_depth,
+                            int eq_h, int eq_w, const float* __restrict__ kinv_t,
+                            const float* __restrict__ rot, int height, int width,
+                            float* __restrict__ proj_image, float* __restrict__ proj_depth,
+                            float* __restrict__ proj_mask) {
+  float k[9], r[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { k[i] = kinv_t[i]; r[i] = rot[i]; }
+  const int64_t total = (int64_t)height * width;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kBlock) {
+    const float px = (float)(i % width), py = (float)(i / width), pz = 1.0f;
+    const float a0 = (px * k[0] + py * k[3]) + pz * k[6];
+    const float a1 = (px * k[1] + py * k[4]) + pz * k[7];
+    const float a2 = (px * k[2] + py * k[5]) + pz * k[8];
+    const float x = (a0 * r[0] + a1 * r[3]) + a2 * r[6];
+    const float y = (a0 * r[1] + a1 * r[4]) + a2 * r[7];
+    const float z = (a0 * r[2] + a1 * r[5]) + a2 * r[8];
+    const float norm = __builtin_sqrtf((x * x + y * y) + z * z);
+    const float xn = x / norm, yn = y / norm, zn = z / norm;
+    const float lon = se3ds_atan2f(xn, zn);
+    const float lat = se3ds_asinf(yn);
+    const float u = (lon / SE3DS_F32_TWO_PI + 0.5f) * (float)(eq_w - 1);
+    const float v = (lat / SE3DS_F32_PI + 0.5f) * (float)(eq_h - 1);
+    int iy, ix;
+    float ay, ax;
+    bilinear_setup(u, v, eq_h, eq_w, &iy, &ix, &ay, &ax);
+    const int64_t o = (int64_t)iy * eq_w + ix;
+    const int64_t taps[4] = {o, o + 1, o + eq_w, o + eq_w + 1};
+    float dt[4], mk[4], rgb[4][3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      dt[t] = pred_depth[taps[t]];
+      bool ok = (dt[t] != 1.0f) && (dt[t] != 0.0f);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        rgb[t][c] = pred_rgb[taps[t] * 3 + c];
+        ok = ok && (rgb[t][c] != 0.0f);
+      }
+      mk[t] = ok ? 1.0f : 0.0f;
+    }
+    const float gm = bilerp(mk[0], mk[1], mk[2], mk[3], ax, ay);
+    const float pm = (gm == 1.0f) ? 1.0f : 0.0f;
+    const float gd = bilerp(dt[0], dt[1], dt[2], dt[3], ax, ay);
+    proj_mask[i] = pm;
+    proj_depth[i] = pm * gd;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float g = bilerp(rgb[0][c], rgb[1][c], rgb[2][c], rgb[3][c], ax, ay);
+      proj_image[i * 3 + c] = pm * fminf(fmaxf(g / 255.0f, 0.0f), 1.0f);
+    }
   }
 }
 
@@ -1452,9 +1603,20 @@ int se3ds_project_equirect(const float* xyz1, const float* offset, const void* f
                            float depth_scale, float input_void, float output_void, float* depth,
                            float* feat, float* mask, float mask_void, void* workspace,
                            size_t workspace_bytes, void* stream) {
-  return dispatch_splat<true>(xyz1, offset, feats, feat_dtype, n, m, channels, height, width,
+  return dispatch_splat<true>(xyz1, offset, feats, feat_dtype, n, m, m, channels, height, width,
                               depth_scale, input_void, output_void, depth, feat, mask, mask_void,
                               workspace, workspace_bytes, stream);
+}
+
+int se3ds_project_equirect_memory(const float* xyz1, const float* offset, const void* feats,
+                                  int feat_dtype, int n, int64_t m, int64_t capacity, int channels,
+                                  int height, int width, float depth_scale, float input_void,
+                                  float output_void, float* depth, float* feat, float* mask,
+                                  float mask_void, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  return dispatch_splat<true>(xyz1, offset, feats, feat_dtype, n, m, capacity, channels, height,
+                              width, depth_scale, input_void, output_void, depth, feat, mask,
+                              mask_void, workspace, workspace_bytes, stream);
 }
 
 int se3ds_project_to_feat(const float* coords, const void* feats, int feat_dtype, int n, int64_t m,
@@ -1462,7 +1624,7 @@ int se3ds_project_to_feat(const float* coords, const void* feats, int feat_dtype
                           float input_void, float output_void, float* depth, float* feat,
                           float* mask, float mask_void, void* workspace, size_t workspace_bytes,
                           void* stream) {
-  return dispatch_splat<false>(coords, nullptr, feats, feat_dtype, n, m, channels, height, width,
+  return dispatch_splat<false>(coords, nullptr, feats, feat_dtype, n, m, m, channels, height, width,
                                depth_scale, input_void, output_void, depth, feat, mask, mask_void,
                                workspace, workspace_bytes, stream);
 }
@@ -1531,6 +1693,33 @@ int se3ds_persp_from_equirect_coords(const float* kinv_t, const float* rot, int 
                      dim3(grid_for((int64_t)height * width, kBlock)), dim3(kBlock), 0,
                      as_stream(stream), kinv_t, rot, height, width, eq_h, eq_w, out);
   return check_launch("persp_from_equirect_coords");
+}
+
+int se3ds_perspective_to_pointcloud(const float* image, const float* depth, int ih, int iw,
+                                    int channels, const float* rays, const float* w2i,
+                                    int round_nearest, float pad_value, const float* sin_el,
+                                    const float* cos_el, const float* sin_hd, const float* cos_hd,
+                                    const float* position, int height, int width, float void_class,
+                                    float depth_scale, float* xyz1, int32_t* feats_out, void* stream) {
+  if (ih <= 0 || iw <= 0 || channels <= 0 || channels > 4 || height <= 0 || width != 2 * height)
+    return SE3DS_E_BADSHAPE;
+  hipLaunchKernelGGL(perspective_to_pointcloud_kernel,
+                     dim3(grid_for((int64_t)height * width, kBlock)), dim3(kBlock), 0,
+                     as_stream(stream), image, depth, ih, iw, channels, rays, w2i, round_nearest,
+                     pad_value, sin_el, cos_el, sin_hd, cos_hd, position, height, width, void_class,
+                     depth_scale, xyz1, feats_out);
+  return check_launch("perspective_to_pointcloud");
+}
+
+int se3ds_perspective_guidance(const float* pred_rgb, const float* pred_depth, int eq_h, int eq_w,
+                               const float* kinv_t, const float* rot, int height, int width,
+                               float* proj_image, float* proj_depth, float* proj_mask,
+                               void* stream) {
+  if (eq_h < 2 || eq_w < 2 || height <= 0 || width <= 0) return SE3DS_E_BADSHAPE;
+  hipLaunchKernelGGL(perspective_guidance_kernel, dim3(grid_for((int64_t)height * width, kBlock)),
+                     dim3(kBlock), 0, as_stream(stream), pred_rgb, pred_depth, eq_h, eq_w, kinv_t,
+                     rot, height, width, proj_image, proj_depth, proj_mask);
+  return check_launch("perspective_guidance");
 }
 
 int se3ds_mask_pano(const void* pano, int dtype, int n, int height, int width, int channels,

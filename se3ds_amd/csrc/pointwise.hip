@@ -342,6 +342,7 @@ __device__ __forceinline__ float block_sum(float v) {
 // mode 1: sum(|a - b| * m[p])        (a, b: (N,P,C); m: (N,P))
 // mode 2: sum(1[0 < a < 1])          (valid-depth pixel count, se3ds_trainer.py:148-152)
 // mode 3: sum(m[p] * (1 - m2[p]))    (wc mask, :176-178) a=m, b=m2
+// mode 4: sum((a - b)^2 * 1[0 < b < 1]) (depth RMSE numerator, utils/eval_metric.py:225-231)
 __global__ void __launch_bounds__(kB)
 sample_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
                   const float* __restrict__ m, int64_t P, int C, int mode,
@@ -356,6 +357,10 @@ sample_sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
     if (mode == 0) s += a[idx];
     else if (mode == 1) s += fabsf(a[idx] - b[idx]) * (m ? m[(int64_t)n * P + i / C] : 1.0f);
     else if (mode == 2) s += (a[idx] > 0.f && a[idx] < 1.f) ? 1.f : 0.f;
+    else if (mode == 4) {
+      const float d = a[idx] - b[idx];
+      s += (d * d) * ((b[idx] > 0.f && b[idx] < 1.f) ? 1.f : 0.f);
+    }
     else s += a[idx] * (1.0f - b[idx]);
   }
   s = block_sum(s);

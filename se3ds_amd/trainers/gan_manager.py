@@ -281,6 +281,22 @@ class GANManager(abc.ABC):
       output_dict[key] = r
     return output_dict
 
+  # ----------------------------------------------------------------------- evaluation loop
+  def _get_image_grid(self, inputs, modes=('normal', 'ema')):
+    """Video branch of the reference's `_get_image_grid` (:458-541): for the training and the EMA
+    generator, roll a trajectory out autoregressively -- project the memory, generate, feed the
+    frame back (utils/eval_metric.generated_rollout; unprojection with void_class 0 as :536-539
+    does).  inputs: image (N,T,H,W,3), depth (N,T,H,W,1), position (N,T,3), depth_scale (N,).
+    Returns {mode: RolloutOutput}; composing / writing the TensorBoard grid stays out of scope."""
+    from se3ds_amd.utils import eval_metric
+    res = {}
+    for mode in modes:
+      gen = self.ema_generator if mode == 'ema' else self.generator
+      res[mode] = eval_metric.generated_rollout(gen, inputs, self.eval_seq_len,
+                                                predict_depth=self.predict_depth,
+                                                unproject_void_class=0)
+    return res
+
   # -------------------------------------------------------------------------- checkpoint
   # The reference keeps tf.train.Checkpoint(generator, discriminator, ema_generator, g_optimizer,
   # d_optimizer) (:333-349).  TensorFlow's bundle format cannot be read or written here; the same

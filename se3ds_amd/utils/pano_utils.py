@@ -276,3 +276,71 @@ def compact_valid_points(xyz1: torch.Tensor, feats: torch.Tensor, void_class: fl
   _lib.check(rc, 'se3ds_compact_valid')
   k = int(cnt.item())
   return xo[:, :, :k].contiguous(), fo[:, :k].contiguous()
+
+
+# ------------------------------------------------------------------ fused perspective paths
+def _np32(x):
+  return np.asarray(x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else x, F32)
+
+
+def perspective_to_pointcloud(image: torch.Tensor, depth: torch.Tensor, output_height: int,
+                              void_class: float, depth_scale: float, fov=None,
+                              camera_intrinsics=None, rotations=None, rotation_matrix=None,
+                              pad_value: float = 0.0, round_to_nearest: bool = True,
+                              position: Optional[torch.Tensor] = None
+                              ) -> Tuple[torch.Tensor, torch.Tensor]:
+  """RE10K notebook cell 15 in one kernel: project_perspective_image(image) and
+  (depth) (reference :344-417, constant padding), `tf.cast(rgb * 255, tf.int32)`, and
+  equirectangular_to_pointcloud (:164-242) -- the 1024x2048 equirect RGB / depth intermediates are
+  never written.  image (h,w,C) fp32 in [0,1], depth (h,w) fp32 in [0,1].  Returns xyz1
+  (1,4,H*2H) fp32 and feats (1,H*2H,C) int32, bit-identical to the op-by-op chain."""
+  _lib.require_cuda(image, depth, position)
+  image = image.to(torch.float32).contiguous()
+  depth = depth.to(torch.float32).contiguous()
+  ih, iw, c = image.shape
+  if tuple(depth.shape) != (ih, iw):
+    raise ValueError(f'depth {tuple(depth.shape)} does not match the image {(ih, iw)}')
+  dev = image.device
+  h, w = output_height, 2 * output_height
+  w2i = get_world_to_image_transform((ih, iw), fov, camera_intrinsics=camera_intrinsics,
+                                     rotations=rotations, rotation_matrix=rotation_matrix).to(dev)
+  rays = _host_tables.pixel_rays(h, dev)
+  tab = _host_tables.equirect_tables(h, w, dev)
+  base = tab.data_ptr()
+  xyz1 = torch.empty((1, 4, h * w), dtype=torch.float32, device=dev)
+  feats = torch.empty((1, h * w, c), dtype=torch.int32, device=dev)
+  if position is not None:
+    position = position.to(torch.float32).contiguous()
+  rc = _lib.lib().se3ds_perspective_to_pointcloud(
+      _lib.ptr(image), _lib.ptr(depth), ih, iw, c, _lib.ptr(rays), _lib.ptr(w2i),
+      1 if round_to_nearest else 0, float(pad_value), base, base + 4 * h, base + 8 * h,
+      base + 8 * h + 4 * w, _lib.ptr(position), h, w, float(void_class), float(depth_scale),
+      _lib.ptr(xyz1), _lib.ptr(feats), _lib.stream())
+  _lib.check(rc, 'se3ds_perspective_to_pointcloud')
+  return xyz1, feats
+
+
+def perspective_guidance(pred_rgb: torch.Tensor, pred_depth: torch.Tensor, camera_intrinsics,
+                         rotation_matrix, height: int, width: int):
+  """RE10K notebook cell 17 after the splat, in one kernel: the three
+  get_perspective_from_equirectangular_image gathers (reference :443-476) of the projected RGB
+  (H,W,3), depth (H,W) and validity mask (depth != 0, != 1, all(rgb != 0)), `rgb / 255` clipped to
+  [0,1], `mask == 1`, and the products with the mask.  Returns the generator's proj_image
+  (1,h,w,3), proj_depth (1,h,w,1), proj_mask (1,h,w,1)."""
+  _lib.require_cuda(pred_rgb, pred_depth)
+  pred_rgb = pred_rgb.to(torch.float32).contiguous()
+  pred_depth = pred_depth.to(torch.float32).contiguous()
+  eq_h, eq_w, c = pred_rgb.shape
+  if c != 3 or tuple(pred_depth.shape) != (eq_h, eq_w):
+    raise ValueError('pred_rgb (H,W,3) and pred_depth (H,W) expected')
+  dev = pred_rgb.device
+  k = np.asarray(_np32(camera_intrinsics), np.float64)
+  kinv_t = torch.from_numpy(np.ascontiguousarray(np.linalg.inv(k).astype(F32).T)).to(dev)
+  rot = torch.from_numpy(np.ascontiguousarray(_np32(rotation_matrix))).to(dev)
+  f = lambda ch: torch.empty((1, height, width, ch), dtype=torch.float32, device=dev)
+  proj_image, proj_depth, proj_mask = f(3), f(1), f(1)
+  rc = _lib.lib().se3ds_perspective_guidance(
+      _lib.ptr(pred_rgb), _lib.ptr(pred_depth), eq_h, eq_w, _lib.ptr(kinv_t), _lib.ptr(rot), height,
+      width, _lib.ptr(proj_image), _lib.ptr(proj_depth), _lib.ptr(proj_mask), _lib.stream())
+  _lib.check(rc, 'se3ds_perspective_guidance')
+  return proj_image, proj_depth, proj_mask

@@ -141,3 +141,83 @@ def debug_fast_fxy(xyz: torch.Tensor, height: int, width: int):
                                        _lib.ptr(verdict), _lib.stream())
   _lib.check(rc, 'se3ds_debug_fast_fxy')
   return fx, fy, verdict
+
+
+class PointCloudMemory:
+  """The growing point-cloud memory of the trajectory loops -- `memory_coords (N,4,M)` /
+  `memory_feats (N,M,C)` of utils/eval_metric.py:144-239, trainers/gan_manager.py:462-541 -- kept
+  in preallocated HBM buffers: frames are unprojected straight into the next free window
+  (`se3ds_unproject_equirect_into`) and rendered from the first M points
+  (`se3ds_project_equirect_memory`), so the reference's `tf.concat` per frame (a copy of the whole
+  memory, O(T^2) traffic over a trajectory) never happens.  Capacity doubles when exhausted."""
+
+  def __init__(self, batch_size: int, channels: int, dtype=torch.int32, device='cuda:0',
+               capacity: int = 0):
+    self.n, self.c, self.dtype, self.device = batch_size, channels, dtype, torch.device(device)
+    self.m = 0
+    self._x = torch.empty((batch_size, 4, 0), dtype=torch.float32, device=self.device)
+    self._f = torch.empty((batch_size, 0, channels), dtype=dtype, device=self.device)
+    if capacity:
+      self.reserve(capacity)
+
+  @property
+  def capacity(self) -> int:
+    return self._x.shape[2]
+
+  @property
+  def coords(self) -> torch.Tensor:
+    """(N,4,M) view of the valid part."""
+    return self._x[:, :, :self.m]
+
+  @property
+  def feats(self) -> torch.Tensor:
+    return self._f[:, :self.m]
+
+  def reserve(self, capacity: int):
+    if capacity <= self.capacity:
+      return
+    cap = max(capacity, 2 * self.capacity)
+    x = torch.empty((self.n, 4, cap), dtype=torch.float32, device=self.device)
+    f = torch.empty((self.n, cap, self.c), dtype=self.dtype, device=self.device)
+    if self.m:
+      x[:, :, :self.m].copy_(self._x[:, :, :self.m])
+      f[:, :self.m].copy_(self._f[:, :self.m])
+    self._x, self._f = x, f
+
+  def append_equirect(self, feats: torch.Tensor, depth: torch.Tensor, void_class: float,
+                      depth_scale: float, position: Optional[torch.Tensor] = None):
+    """equirectangular_to_pointcloud(feats, depth) (+ position) appended in place."""
+    from se3ds_amd.utils import pano_utils
+    p = depth.shape[1] * depth.shape[2]
+    self.reserve(self.m + p)
+    if feats.dim() == 3:
+      feats = feats[..., None]
+    pano_utils.equirectangular_to_pointcloud(feats, depth, void_class, depth_scale,
+                                             position=position, out=(self._x, self._f, self.m))
+    self.m += p
+
+  def project(self, height: int, width: int, void_class: float, depth_scale: float,
+              position: Optional[torch.Tensor] = None, with_mask: bool = False,
+              mask_void: float = constants.INVALID_RGB_VALUE, output_void_class: float = 0):
+    """project_feats_to_equirectangular(memory_feats, memory_coords - position, ...)."""
+    _lib.require_cuda(position)
+    dev = self.device
+    n, c = self.n, self.c
+    depth = torch.empty((n, height, width), dtype=torch.float32, device=dev)
+    out = torch.empty((n, height, width, c), dtype=torch.float32, device=dev)
+    mask = torch.empty((n, height, width), dtype=torch.float32, device=dev) if with_mask else None
+    L = _lib.lib()
+    ws = _workspace(L.se3ds_splat_workspace_bytes(n, self.m, height, width, c), dev)
+    if position is not None:
+      position = position.to(torch.float32).contiguous()
+    x, f = self._x, self._f
+    if self.capacity == 0:   # empty memory: any valid pointer pair will do (m = 0)
+      x = torch.empty((n, 4, 1), dtype=torch.float32, device=dev)
+      f = torch.empty((n, 1, c), dtype=self.dtype, device=dev)
+    rc = L.se3ds_project_equirect_memory(
+        _lib.ptr(x), _lib.ptr(position), _lib.ptr(f), _lib.dtype_code(f), n, self.m, x.shape[2], c,
+        height, width, float(depth_scale), float(void_class), float(output_void_class),
+        _lib.ptr(depth), _lib.ptr(out), _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(),
+        _lib.stream())
+    _lib.check(rc, 'se3ds_project_equirect_memory')
+    return (depth, out, mask) if with_mask else (depth, out)

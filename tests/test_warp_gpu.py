@@ -356,3 +356,49 @@ def test_device_fast_screen_error_bound(h):
     assert dx.size == 0 or dx.max() <= margin / 8, dx.max()
     assert dy.size == 0 or dy.max() <= margin / 8, dy.max()
   assert decided_total > 0.5 * len(clouds) * m
+
+
+@pytest.mark.parametrize('eq_h', [128, 1024])
+def test_fused_perspective_paths_match_the_op_chain(eq_h):
+  """SURVEY 8f-4 (RE10K notebook cells 15 / 17): the fused perspective -> point cloud and
+  equirect -> perspective-guidance kernels are bit-identical to the chain of the individual ops
+  (project_perspective_image x2, cast, equirectangular_to_pointcloud; project + 3 x
+  get_perspective_from_equirectangular_image + the mask / clip glue), each of which is tested
+  against the oracle on its own (test_perspective_and_rotation_paths)."""
+  from se3ds_amd.models.models import _quantize
+  rng = np.random.default_rng(60 + eq_h)
+  ph, pw = 64, 64
+  k = np.array([[32., 0., 32.], [0., 32., 32.], [0., 0., 1.]], F32)
+  rot = np.array([[0.99992853, -0.01185191, 0.00158339], [0.01187317, 0.9998291, -0.01416931],
+                  [-0.00141519, 0.01418709, 0.9998984]], F32)
+  rgb_u8 = rng.integers(1, 256, (ph, pw, 3)).astype(np.uint8)
+  depth = rng.uniform(0.02, 0.2, (ph, pw)).astype(F32)
+  rgb = _quantize(t(rgb_u8), torch.float32, mul=float(F32(1.0 / 255.0)), lo=0.0, hi=1.0)
+  # ---- cell 15, op by op
+  rgb_eq = pano_utils.project_perspective_image(rgb, None, eq_h, camera_intrinsics=k,
+                                                rotation_matrix=rot, round_to_nearest=True)
+  depth_eq = pano_utils.project_perspective_image(t(depth)[..., None], None, eq_h, camera_intrinsics=k,
+                                                  rotation_matrix=rot, round_to_nearest=True)
+  feats_eq = _quantize(rgb_eq, torch.int32, mul=255.0, lo=-1e9, hi=1e9)
+  xyz_c, f_c = pano_utils.equirectangular_to_pointcloud(feats_eq[None], depth_eq[None, ..., 0], -1, 20.0)
+  # ---- fused
+  xyz_f, f_f = pano_utils.perspective_to_pointcloud(rgb, t(depth), eq_h, -1, 20.0, camera_intrinsics=k,
+                                                    rotation_matrix=rot, round_to_nearest=True)
+  assert torch.equal(xyz_c, xyz_f) and torch.equal(f_c, f_f)
+  assert int((f_f[0, :, 0] >= 0).sum()) > 0.02 * eq_h * 2 * eq_h   # the frustum covers part of the pano
+  # ---- cell 17: move, splat, then back to the perspective view
+  rel = t(np.array([[0.0, 0.01, 0.0]], F32))
+  ang = 15.0 / 180.0 * np.pi
+  new_rot = (rot.astype(np.float64) @ np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0],
+                                                [-np.sin(ang), 0, np.cos(ang)]])).astype(F32)
+  pred_depth, pred_rgb = pano_utils.project_feats_to_equirectangular(f_f, xyz_f, eq_h, 2 * eq_h, -1,
+                                                                     20.0, offset=rel)
+  g_rgb = pano_utils.get_perspective_from_equirectangular_image(pred_rgb[0], k, new_rot, ph, pw)
+  g_rgb = torch.clamp(g_rgb / 255, 0, 1)[None]
+  g_d = pano_utils.get_perspective_from_equirectangular_image(pred_depth[0][..., None], k, new_rot, ph, pw)[None]
+  m_eq = ((pred_depth != 1.0) & (pred_depth != 0.0) & torch.all(pred_rgb != 0.0, dim=-1)).float()
+  g_m = pano_utils.get_perspective_from_equirectangular_image(m_eq[0][..., None], k, new_rot, ph, pw)
+  pm = (g_m[None] == 1.0).float()
+  pi_f, pd_f, pm_f = pano_utils.perspective_guidance(pred_rgb[0], pred_depth[0], k, new_rot, ph, pw)
+  assert torch.equal(pm_f, pm) and torch.equal(pd_f, pm * g_d) and torch.equal(pi_f, pm * g_rgb)
+  assert 0.05 < float(pm_f.mean()) <= 1.0
