@@ -74,7 +74,8 @@ def test_unproject_errors():
 
 
 @pytest.mark.parametrize('n,h,views', [(1, 16, 1), (2, 32, 2), (1, 128, 2), (1, 256, 1)])
-def test_project_equirect_bit_exact(n, h, views):
+def test_project_equirect_bit_exact(n, h, views, monkeypatch):
+  monkeypatch.setenv('SE3DS_SPLAT_DEBUG', '1')   # the single-pass binning kernel writes the (idx, z) tap
   rng = np.random.default_rng(11 + h)
   w = 2 * h
   coords, feats = [], []
@@ -297,14 +298,21 @@ def test_bilinear_and_resampling_paths():
   assert (np.abs(e_g.cpu().numpy() - e_o).max(-1) <= 1e-4).mean() > 0.995
 
 
-def test_splat_banded_tiles_bit_exact():
-  """Tiles with many records are cut into bands of rows (splat_tile_resolve_kernel); with a tiny
-  slice size every tile of the small parity images is banded.  The switch is read once per
-  process, so the splat parity tests are re-run in a child process."""
+@pytest.mark.parametrize('env_extra', [
+    dict(SE3DS_SPLAT_SLICE='48'),                          # every tile banded
+    dict(SE3DS_SPLAT_CAP='64'),                            # bins overflow into the overflow list
+    dict(SE3DS_SPLAT_CAP='64', SE3DS_SPLAT_SLICE='48'),    # both
+    dict(SE3DS_SPLAT_FUSED='0'),                           # three-pass version (count / scan / scatter)
+], ids=['banded', 'overflow', 'banded+overflow', 'three-pass'])
+def test_splat_banded_tiles_bit_exact(env_extra):
+  """The splat parity tests re-run in a child process under switches that are read once per
+  process: tiny slices (every tile of the small parity images is cut into bands of rows,
+  splat_tile_resolve_kernel), tiny bin capacities (records spill into the overflow list of the
+  single-pass binning kernel), and the three-pass binning version."""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  env = dict(os.environ, SE3DS_SPLAT_SLICE='48', PYTHONPATH=root)
+  env = dict(os.environ, PYTHONPATH=root, **env_extra)
   env.pop('SE3DS_SPLAT_SCATTER', None)
   r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_warp_gpu.py'),
                       '-q', '-x', '-m', 'gpu', '-k', 'project and not banded'],
@@ -394,7 +402,8 @@ def test_fused_perspective_paths_match_the_op_chain(eq_h):
   pred_depth, pred_rgb = pano_utils.project_feats_to_equirectangular(f_f, xyz_f, eq_h, 2 * eq_h, -1,
                                                                      20.0, offset=rel)
   g_rgb = pano_utils.get_perspective_from_equirectangular_image(pred_rgb[0], k, new_rot, ph, pw)
-  g_rgb = torch.clamp(g_rgb / 255, 0, 1)[None]
+  # (tensor / tensor: IEEE division as tf.truediv; torch turns `x / 255` into x * (1 / 255))
+  g_rgb = torch.clamp(g_rgb / torch.full_like(g_rgb, 255.0), 0, 1)[None]
   g_d = pano_utils.get_perspective_from_equirectangular_image(pred_depth[0][..., None], k, new_rot, ph, pw)[None]
   m_eq = ((pred_depth != 1.0) & (pred_depth != 0.0) & torch.all(pred_rgb != 0.0, dim=-1)).float()
   g_m = pano_utils.get_perspective_from_equirectangular_image(m_eq[0][..., None], k, new_rot, ph, pw)
