@@ -688,13 +688,12 @@ splat_bin_count_kernel(const float* __restrict__ coords, const float* __restrict
 // 8192 points instead of one per point); (3) the records go out at bin + reserved base + rank.
 // Against the three-pass version this drops the (idx, z) round trip (16 B per point), the second
 // read of the coordinates' validity and the column scan.
-constexpr int kFusedPts = 16;
-template <typename T, bool EQUIRECT, bool DEBUG>
-__global__ void __launch_bounds__(kChunkThreads)
+template <typename T, bool EQUIRECT, bool DEBUG, int kFusedPts>
+__global__ void __launch_bounds__(kChunkThreads, kFusedPts <= 8 ? 4 : 2)
 splat_bin_fused_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
                        const T* __restrict__ feats, int64_t m, int64_t ld, int64_t per, int channels,
                        int height, int width, uint64_t wmagic, float input_void, int ntiles,
-                       int tiles_x, SplatWs ws, BinWs bw) {
+                       int tiles_x, uint32_t slice_records, SplatWs ws, BinWs bw) {
   extern __shared__ uint32_t s_dyn[];   // hist[ntiles], base[ntiles]
   uint32_t* s_hist = s_dyn;
   uint32_t* s_base = s_dyn + ntiles;
@@ -808,7 +807,14 @@ splat_bin_fused_kernel(const float* __restrict__ coords, const float* __restrict
     // reserve this batch's run in every touched tile
     for (int t = threadIdx.x; t < ntiles; t += kChunkThreads) {
       const uint32_t c = s_hist[t];
-      s_base[t] = c ? atomicAdd(&bw.tile_count[(int64_t)b * ntiles + t], c) : 0u;
+      uint32_t old = 0u;
+      if (c) {
+        old = atomicAdd(&bw.tile_count[(int64_t)b * ntiles + t], c);
+        // a tile that grows past one slice will be resolved in bands: tell the resolve kernel
+        // that item != tile (it then scans the tile counts for its (tile, band))
+        if (old + c > slice_records && old <= slice_records) atomicOr(&bw.ovf_count[1], 1u);
+      }
+      s_base[t] = old;
     }
     __syncthreads();
 #pragma unroll
@@ -1053,7 +1059,16 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
   // so bands never exchange anything.  item -> (tile, band) by a scan of the bands per tile.
   const uint32_t item = blockIdx.x;
   if (threadIdx.x == 0) s_item[0] = -1;
-  {
+  // single-pass layout without a banded tile (the usual case): item == tile, no scan needed
+  const bool direct = bw.cap != 0 && bw.ovf_count[1] == 0u;
+  if (direct) {
+    if (threadIdx.x == 0 && item < (uint32_t)nb) {
+      s_item[0] = (int)item;
+      s_item[1] = 0;
+      s_item[2] = 0;
+      s_r0 = 0u;
+    }
+  } else {
     const int per = ceil_div(nb, kResolveThreads);
     const int t0 = threadIdx.x * per, t1 = t0 + per < nb ? t0 + per : nb;
     uint32_t sum_s = 0, sum_c = 0;
@@ -1338,14 +1353,15 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
     if (hipMemsetAsync(bw.tile_count, 0, 4 * ((size_t)nb + 4), stream) != hipSuccess)
       return SE3DS_E_LAUNCH;
     const char* e_dbg = getenv("SE3DS_SPLAT_DEBUG");
-    if (e_dbg && atoi(e_dbg) != 0)
-      hipLaunchKernelGGL((splat_bin_fused_kernel<T, EQUIRECT, true>), g_pt, dim3(kChunkThreads),
-                         8 * ntiles, stream, coords, offset, feats, m, ld, cg.per, channels, height,
-                         width, wmagic, input_void, ntiles, tiles_x, ws, bw);
-    else
-      hipLaunchKernelGGL((splat_bin_fused_kernel<T, EQUIRECT, false>), g_pt, dim3(kChunkThreads),
-                         8 * ntiles, stream, coords, offset, feats, m, ld, cg.per, channels, height,
-                         width, wmagic, input_void, ntiles, tiles_x, ws, bw);
+    const bool dbg = e_dbg && atoi(e_dbg) != 0;
+    const int pts = e_fused ? atoi(e_fused) : 8;   // points per thread and batch: 8 (default) or 16
+#define SE3DS_FUSED(DBG, PTS)                                                                    \
+  hipLaunchKernelGGL((splat_bin_fused_kernel<T, EQUIRECT, DBG, PTS>), g_pt, dim3(kChunkThreads), \
+                     8 * ntiles, stream, coords, offset, feats, m, ld, cg.per, channels, height, \
+                     width, wmagic, input_void, ntiles, tiles_x, slice_records(), ws, bw)
+    if (pts == 16) { if (dbg) SE3DS_FUSED(true, 16); else SE3DS_FUSED(false, 16); }
+    else { if (dbg) SE3DS_FUSED(true, 8); else SE3DS_FUSED(false, 8); }
+#undef SE3DS_FUSED
   } else {
     hipLaunchKernelGGL((splat_bin_count_kernel<T, EQUIRECT>), g_pt, dim3(kChunkThreads), 4 * ntiles,
                        stream, coords, offset, feats, m, ld, cg.per, channels, height, width, wmagic,

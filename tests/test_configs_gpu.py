@@ -244,8 +244,8 @@ def test_cfg1_generator_gradients_well_conditioned():
   gin_lite.clear_config()
   G = image_models.ResNetGenerator(image_size=64, gen_dims=128, resnet_version='101', device=DEV,
                                    seed=-3, dtype=torch.float32)
-  _randomise_inference_state(G)
   batch = synth_batch(1, 64, seed=55)
+  _randomise_inference_state(G, batch)
   names = G.store.trainable_names
   def oracle(dt):
     p = {k: v.detach().cpu().to(dt if v.is_floating_point() else v.dtype).clone()
@@ -318,22 +318,37 @@ def test_cfg1_generator_gradients_well_conditioned():
 
 
 # ======================================================================================= cfg2
-def _randomise_inference_state(G, seed=4):
-  """Random BN moving statistics / affine values / biases: inference on moving statistics is
-  trivial (mean 0, variance 1) at initialisation."""
+def _randomise_inference_state(G, batch=None, seed=4):
+  """Non-trivial inference state: random affine values / biases, and batch-norm moving statistics
+  CALIBRATED to the network's own activations on `batch` (a dict of CPU tensors; default: a
+  synthetic batch at the generator's working size).  At initialisation the moving statistics are
+  (0, 1): nothing is normalised, every residual block grows the activations, and after 100+
+  layers tanh / clip saturate -- outputs become trivial and gradients meaningless.  Calibration =
+  one training-mode forward on the device; the batch statistics are recovered from the momentum
+  update moving' = 0.99 moving + 0.01 batch (exactness is irrelevant: the oracle gets the same
+  numbers)."""
   gen = torch.Generator().manual_seed(seed)
   upd = {}
-  for n_ in G.store.state_names:
-    if n_.endswith('moving_mean'):
-      upd[n_] = (torch.randn(G.store[n_].shape, generator=gen) * 0.1).numpy()
-    if n_.endswith('moving_variance'):
-      upd[n_] = (torch.rand(G.store[n_].shape, generator=gen) + 0.5).numpy()
   for n_ in G.store.trainable_names:
     if n_.endswith('gamma'):
-      upd[n_] = (torch.rand(G.store[n_].shape, generator=gen) + 0.5).numpy()
+      upd[n_] = (torch.rand(G.store[n_].shape, generator=gen) * 0.2 + 0.9).numpy()
     if n_.endswith('beta') or n_.endswith('bias'):
       upd[n_] = (torch.randn(G.store[n_].shape, generator=gen) * 0.1).numpy()
   G.store.load_dict(upd)
+  if batch is None:
+    batch = synth_batch(1, 64, seed=seed)
+  stats = [n_ for n_ in G.store.state_names if n_.endswith(('moving_mean', 'moving_variance'))]
+  before = {n_: G.store[n_].clone() for n_ in stats}
+  u0 = {n_: G.store[n_].clone() for n_ in G.store.state_names if n_.endswith('/u')}
+  G.forward(G.make_ctx(True), {k: v.to(DEV) for k, v in batch.items()})
+  for n_ in stats:
+    est = (G.store[n_] - 0.99 * before[n_]) / 0.01
+    if n_.endswith('moving_variance'):
+      est = torch.clamp(est, min=1e-3)
+    G.store[n_].copy_(est)
+  for n_, v in u0.items():   # the calibration pass must not count as a power-iteration step
+    G.store[n_].copy_(v)
+  G.store.version += 1
 
 
 def _check_frame(out, ref, tag):
