@@ -1343,10 +1343,14 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
   const uint64_t wmagic = ((uint64_t)1 << 40) / (uint64_t)width + 1;
   const dim3 g_pt((unsigned)cg.chunks, (unsigned)n);
   const int nparts = cg.chunks * n;
-  // SE3DS_SPLAT_FUSED=0: the three-pass version (count, column scan, scatter) for A/B runs;
-  // SE3DS_SPLAT_DEBUG=1: the single-pass kernel also writes the (idx, z) parity tap
+  // Default: the three-pass version (count, column scan, scatter).  SE3DS_SPLAT_FUSED=8 | 16
+  // selects the single-pass binning kernel with that many points per thread and batch -- measured
+  // (profiles/r02_warp_*): equal on a random depth map (151 us per render either way: the kernel
+  // moves 16 B per point less but is bound by its phase barriers and the reservation atomics'
+  // latency), slower on a smooth one (hot tile cursors, overflow list), so it is not the default.
+  // SE3DS_SPLAT_DEBUG=1: the single-pass kernel also writes the (idx, z) parity tap.
   const char* e_fused = getenv("SE3DS_SPLAT_FUSED");
-  const bool fused = !(e_fused && atoi(e_fused) == 0) &&
+  const bool fused = e_fused && atoi(e_fused) > 0 &&
                      (uint64_t)nb * fused_cap(n, m, (size_t)nb) < ((uint64_t)1 << 32);
   if (fused) {
     bw = carve_fused_ws((char*)workspace + align16(base), n, m, height, width, channels);
@@ -1354,7 +1358,7 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
       return SE3DS_E_LAUNCH;
     const char* e_dbg = getenv("SE3DS_SPLAT_DEBUG");
     const bool dbg = e_dbg && atoi(e_dbg) != 0;
-    const int pts = e_fused ? atoi(e_fused) : 8;   // points per thread and batch: 8 (default) or 16
+    const int pts = atoi(e_fused);   // points per thread and batch: 8 or 16
 #define SE3DS_FUSED(DBG, PTS)                                                                    \
   hipLaunchKernelGGL((splat_bin_fused_kernel<T, EQUIRECT, DBG, PTS>), g_pt, dim3(kChunkThreads), \
                      8 * ntiles, stream, coords, offset, feats, m, ld, cg.per, channels, height, \

@@ -75,7 +75,7 @@ def test_unproject_errors():
 
 @pytest.mark.parametrize('n,h,views', [(1, 16, 1), (2, 32, 2), (1, 128, 2), (1, 256, 1)])
 def test_project_equirect_bit_exact(n, h, views, monkeypatch):
-  monkeypatch.setenv('SE3DS_SPLAT_DEBUG', '1')   # the single-pass binning kernel writes the (idx, z) tap
+  monkeypatch.setenv('SE3DS_SPLAT_DEBUG', '1')   # (the opt-in single-pass binning kernel writes the (idx, z) tap on request)
   rng = np.random.default_rng(11 + h)
   w = 2 * h
   coords, feats = [], []
@@ -300,15 +300,15 @@ def test_bilinear_and_resampling_paths():
 
 @pytest.mark.parametrize('env_extra', [
     dict(SE3DS_SPLAT_SLICE='48'),                          # every tile banded
-    dict(SE3DS_SPLAT_CAP='64'),                            # bins overflow into the overflow list
-    dict(SE3DS_SPLAT_CAP='64', SE3DS_SPLAT_SLICE='48'),    # both
-    dict(SE3DS_SPLAT_FUSED='0'),                           # three-pass version (count / scan / scatter)
-], ids=['banded', 'overflow', 'banded+overflow', 'three-pass'])
+    dict(SE3DS_SPLAT_FUSED='8'),                           # single-pass binning kernel, 8 points / thread
+    dict(SE3DS_SPLAT_FUSED='16', SE3DS_SPLAT_CAP='64'),    # ... 16 points, bins overflow into the list
+    dict(SE3DS_SPLAT_FUSED='8', SE3DS_SPLAT_CAP='64', SE3DS_SPLAT_SLICE='48'),   # overflow + bands
+], ids=['banded', 'single-pass', 'single-pass-overflow', 'single-pass-overflow-banded'])
 def test_splat_banded_tiles_bit_exact(env_extra):
   """The splat parity tests re-run in a child process under switches that are read once per
   process: tiny slices (every tile of the small parity images is cut into bands of rows,
-  splat_tile_resolve_kernel), tiny bin capacities (records spill into the overflow list of the
-  single-pass binning kernel), and the three-pass binning version."""
+  splat_tile_resolve_kernel), and the opt-in single-pass binning kernel (SE3DS_SPLAT_FUSED) with
+  tiny bin capacities (records spill into its overflow list)."""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
