@@ -5,6 +5,7 @@
 // deterministically in two stages (per-block partials -> final), so that the cross-replica
 // all-reduce of [2][C] sums (SyncBN, image_models.py:80-123 etc.) sits between two launches.
 #include "common.h"
+#include <cstdlib>
 
 namespace se3ds {
 namespace {
@@ -381,8 +382,16 @@ affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
 }
 
 // row blocks for the elementwise kernels: ~8 blocks per CU in total
+inline int ew_blocks_per_cu() {
+  static const int v = [] {
+    const char* e = getenv("SE3DS_NORM_EW_BLOCKS");
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? x : 8;
+  }();
+  return v;
+}
 inline dim3 ew_grid(const Layout2D& l, int64_t R, int G) {
-  int64_t want = (256 * 8) / ((int64_t)l.ctiles * G);
+  int64_t want = (256 * (int64_t)ew_blocks_per_cu()) / ((int64_t)l.ctiles * G);
   if (want < 1) want = 1;
   int64_t max_rb = ceil_div(R, l.ry);
   if (want > max_rb) want = max_rb;

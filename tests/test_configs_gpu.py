@@ -97,6 +97,25 @@ def _capture_step(gan, batch):
   return cap
 
 
+def _damp_residual_branches(G, seed=9, scale=0.1):
+  """A deep batch-normalised ResNet at RANDOM initialisation is numerically chaotic: every
+  normalised block re-amplifies perturbations (mean-field theory of batch norm: ~1.2-1.3x per
+  layer), so after the generator's 200+ layers fp32 rounding noise reaches O(1) -- two correct fp32
+  implementations then disagree on activations and gradients alike (measured here: the fp32 oracle
+  sits 20-30 % from its own fp64 run).  Trained networks are not in that regime.  The full-network
+  parity tests therefore scale the LAST batch-norm gain of every residual block (Bottleneck.bn3,
+  TransBasicBlock.bn_b) to ~0.1, which makes each block a small perturbation of the identity
+  ("zero-init residual"-style weights) and the whole map well-conditioned; every other parameter
+  keeps its Keras initial value.  The gin configuration is untouched."""
+  gen = torch.Generator().manual_seed(seed)
+  upd = {}
+  for n_ in G.store.trainable_names:
+    if n_.endswith(('/bn3/gamma', '/bn_b/gamma')):
+      upd[n_] = (scale * (torch.rand(G.store[n_].shape, generator=gen) + 0.5)).numpy()
+  assert upd
+  G.store.load_dict(upd)
+
+
 def _grad_view(store, arena, name):
   o, n, shape = store._off_tr[name]
   return arena[o:o + n].view(shape)
@@ -115,6 +134,7 @@ def test_cfg1_lowres_train_g_d_fp32_and_bf16():
   gan = _gin_gan('lowres', torch.float32)
   assert gan.image_size == 128 and gan.d_step_per_g_step == 2 and gan.mask_blurred is True
   assert gan.generator.store.theta.numel() > 1.1e9
+  _damp_residual_branches(gan.generator)   # well-conditioned weights (see the helper); config untouched
   gp, dp = _cpu_params(gan.generator), _cpu_params(gan.discriminator)
   cfg = _oracle_cfg(gan)
   t0 = time.time()
@@ -335,6 +355,7 @@ def _randomise_inference_state(G, batch=None, seed=4):
     if n_.endswith('beta') or n_.endswith('bias'):
       upd[n_] = (torch.randn(G.store[n_].shape, generator=gen) * 0.1).numpy()
   G.store.load_dict(upd)
+  _damp_residual_branches(G, seed + 1)
   if batch is None:
     batch = synth_batch(1, 64, seed=seed)
   stats = [n_ for n_ in G.store.state_names if n_.endswith(('moving_mean', 'moving_variance'))]

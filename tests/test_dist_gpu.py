@@ -55,3 +55,40 @@ def test_rccl_single_rank_api_paths():
                      timeout=240)
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
   assert 'RCCL_OK' in r.stdout
+
+
+def _run_bench(args, env_extra, timeout=600):
+  env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', **env_extra)
+  env.pop('WORLD_SIZE', None)
+  env.pop('RANK', None)
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=env, cwd=ROOT,
+                     capture_output=True, text=True, timeout=timeout)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  import json
+  line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+  return json.loads(line)
+
+
+def test_bench_gpus_2_launches_two_ranks_on_one_gpu():
+  """`bench.py --gpus 2` (no torchrun around it) starts two ranks itself and reports n_gpus = 2.
+  On a 1-GPU box the ranks share cuda:0 and rendezvous over gloo (SE3DS_BENCH_BACKEND); the warp
+  workload is replicas-only, so this exercises exactly the launcher / barrier / max-over-ranks
+  plumbing of the multi-GPU bench."""
+  out = _run_bench(['--gpus', '2', '--workload', 'warp', '--warp-height', '64', '--steps', '3',
+                    '--warmup', '1', '--no-cpu-baseline'], dict(SE3DS_BENCH_BACKEND='gloo'))
+  assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0
+  assert out['scaling'] == 'weak' and out['config']['workload'].startswith('warp')
+
+
+def test_gan_step_on_two_gpus_over_rccl():
+  """Two real GPUs, RCCL: the data-parallel GAN step (SyncBN statistics all-reduces on the main
+  stream, gradient buckets on the side stream) runs and reports a whole-job value for 2 ranks.
+  Skipped on a 1-GPU box (the 8-GPU scaling run is the driver's)."""
+  import torch
+  if torch.cuda.device_count() < 2:
+    pytest.skip('needs two GPUs')
+  for own in ('0', '1'):
+    out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '1', '--image-size',
+                      '128', '--no-cpu-baseline', '--no-warp'], dict(SE3DS_GRAD_SYNC_OWN_COMM=own))
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 2
+    assert all(v == v for v in out['losses'].values())
