@@ -31,7 +31,7 @@ inline Layout2D make_layout(int C, int V) {
 // mode 0: sums of (x, x^2)                        [forward statistics / column sums]
 // mode 1: sums of (dpre, dpre * xhat), dpre = dy * act'(y)   [backward statistics]
 // Optional row_scale (rows of the [G*R] view) multiplies the first operand (x or dy).
-template <typename T, int VEC, int MODE>
+template <typename T, int VEC, int MODE, bool U2 = false>
 __global__ void __launch_bounds__(256)
 norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -57,7 +57,36 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
   const int64_t r_lo = (int64_t)blockIdx.x * rows_per_block;
   int64_t r_hi = r_lo + rows_per_block;
   if (r_hi > R) r_hi = R;
-  if (cok) {
+  if (cok && MODE == 1 && VEC == 8 && U2 && amask != nullptr && act && row_scale == nullptr) {
+    // two rows per iteration: all six loads are issued before the first use (the kernel is bound
+    // by load latency x occupancy, not by bytes: 3.5 TB/s with one row in flight)
+    for (int64_t r = r_lo + ty; r < r_hi; r += 2 * ry) {
+      const bool two = r + ry < r_hi;
+      const int64_t off0 = ((int64_t)g * R + r) * C + c0;
+      const int64_t off1 = two ? off0 + (int64_t)ry * C : off0;
+      float a0[VEC], a1[VEC], x0[VEC], x1[VEC];
+      VT<T>::load(a + off0, reinterpret_cast<float(&)[VT<T>::V]>(a0));
+      VT<T>::load(x + off0, reinterpret_cast<float(&)[VT<T>::V]>(x0));
+      const unsigned m0 = amask[off0 >> 3];
+      VT<T>::load(a + off1, reinterpret_cast<float(&)[VT<T>::V]>(a1));
+      VT<T>::load(x + off1, reinterpret_cast<float(&)[VT<T>::V]>(x1));
+      const unsigned m1 = amask[off1 >> 3];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float d = a0[e] * act_grad_from_bit((m0 >> e) & 1u, act, alpha);
+        s0[e] += d;
+        s1[e] += d * ((x0[e] - mu[e]) * rs[e]);
+      }
+      if (two) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = a1[e] * act_grad_from_bit((m1 >> e) & 1u, act, alpha);
+          s0[e] += d;
+          s1[e] += d * ((x1[e] - mu[e]) * rs[e]);
+        }
+      }
+    }
+  } else if (cok) {
     for (int64_t r = r_lo + ty; r < r_hi; r += ry) {
       const int64_t off = ((int64_t)g * R + r) * C + c0;
       float av[VEC];
@@ -284,15 +313,21 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
   const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
   const int c0 = (blockIdx.y * cx + tx) * VEC;
   if (c0 >= C) return;
-  float mu[VEC], rs[VEC], gr[VEC], s0[VEC], s1[VEC];
+  // per-channel constants: dx = gr * d - k1 * x + c0k  with  k1 = gr * rstd * S1 / cnt,
+  // c0k = mean * k1 - gr * S0 / cnt  (== gr * (d - S0/cnt - xhat * S1/cnt)).  The prologue runs
+  // once per thread and, on the small tensors (2 rows per thread), used to cost more than the
+  // rows: no divisions here (1 / count comes from the host), two FMAs per element below.
+  float gr[VEC], k1[VEC], c0k[VEC];
+  const float inv_count = 1.0f / count;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
     const int64_t gc = (int64_t)g * C + c0 + e;
-    mu[e] = mean[gc];
-    rs[e] = rstd[gc];
-    gr[e] = (gamma ? gamma[c0 + e] : 1.0f) * rs[e];
-    s0[e] = sums[((int64_t)g * 2) * C + c0 + e] / count;
-    s1[e] = sums[((int64_t)g * 2 + 1) * C + c0 + e] / count;
+    const float mu = mean[gc], rs = rstd[gc];
+    gr[e] = (gamma ? gamma[c0 + e] : 1.0f) * rs;
+    const float s0 = sums[((int64_t)g * 2) * C + c0 + e] * inv_count;
+    const float s1 = sums[((int64_t)g * 2 + 1) * C + c0 + e] * inv_count;
+    k1[e] = gr[e] * rs * s1;
+    c0k[e] = mu * k1[e] - gr[e] * s0;
   }
   for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
     const int64_t off = ((int64_t)g * R + r) * C + c0;
@@ -318,8 +353,7 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
                                    : act_grad_from_out(yv[e], act, alpha));
       float d = dv[e] * ag;
       dr[e] = d;
-      float xh = (xv[e] - mu[e]) * rs[e];
-      o[e] = gr[e] * (d - s0[e] - xh * s1[e]);
+      o[e] = fmaf(gr[e], d, fmaf(-k1[e], xv[e], c0k[e]));
       // x is the output of an activation whose producer left its derivative to us
       if (in_act) o[e] *= act_grad_from_out(xv[e], in_act, in_alpha);
     }
@@ -419,7 +453,14 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
   int rb = pick_rblocks(R, l.ry, l.ctiles, G);
   if (ws_bytes < sizeof(float) * (size_t)G * rb * 2 * C) return SE3DS_E_WORKSPACE;
   dim3 grid((unsigned)rb, (unsigned)l.ctiles, (unsigned)G);
-  if (l.vec > 1)
+  static const bool unroll2 = [] {
+    const char* e = getenv("SE3DS_NORM_UNROLL");
+    return e && atoi(e) == 2;
+  }();
+  if (l.vec > 1 && MODE == 1 && sizeof(T) == 2 && unroll2)
+    hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE, true>), grid, dim3(256), 0, s, a, y, x,
+                       mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
+  else if (l.vec > 1)
     hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE>), grid, dim3(256), 0, s, a, y, x,
                        mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
   else
