@@ -262,6 +262,38 @@ norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
     sc[e] = scale[(int64_t)g * C + c0 + e];
     sh[e] = shift[(int64_t)g * C + c0 + e];
   }
+  if (VEC == 8 && sizeof(T) == 2 && post == nullptr) {
+    // two rows per iteration (see norm_bwd_apply_kernel)
+    const int64_t stride = (int64_t)gridDim.x * ry;
+    for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += 2 * stride) {
+      const bool two = r + stride < R;
+      const int64_t off0 = ((int64_t)g * R + r) * C + c0;
+      const int64_t off1 = two ? off0 + stride * C : off0;
+      float x0[VEC], x1[VEC], r0[VEC], r1[VEC], o[VEC];
+      VT<T>::load(x + off0, reinterpret_cast<float(&)[VT<T>::V]>(x0));
+      if (res) VT<T>::load(res + off0, reinterpret_cast<float(&)[VT<T>::V]>(r0));
+      VT<T>::load(x + off1, reinterpret_cast<float(&)[VT<T>::V]>(x1));
+      if (res) VT<T>::load(res + off1, reinterpret_cast<float(&)[VT<T>::V]>(r1));
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half == 1 && !two) break;
+        const int64_t off = half ? off1 : off0;
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float v = (half ? x1[e] : x0[e]) * sc[e] + sh[e];
+          if (res) v += half ? r1[e] : r0[e];
+          v = act_apply(v, act, alpha);
+          o[e] = v;
+          const uint16_t hb = f32_to_bf16(v);
+          bits |= ((hb & 0x7fffu) != 0 && (hb & 0x8000u) == 0) ? (1u << e) : 0u;
+        }
+        VT<T>::store(y + off, reinterpret_cast<float(&)[VT<T>::V]>(o));
+        if (amask) amask[off >> 3] = (uint8_t)bits;
+      }
+    }
+    return;
+  }
   for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
     const int64_t off = ((int64_t)g * R + r) * C + c0;
     float xv[VEC], rv[VEC], pv[VEC], o[VEC];
@@ -328,6 +360,45 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
     const float s1 = sums[((int64_t)g * 2 + 1) * C + c0 + e] * inv_count;
     k1[e] = gr[e] * rs * s1;
     c0k[e] = mu * k1[e] - gr[e] * s0;
+  }
+  if (VEC == 8 && sizeof(T) == 2 && amask != nullptr && act) {
+    // two rows per iteration, all loads issued before the first use (load latency x occupancy
+    // bounds these kernels, not bytes: the one-row version of the statistics kernel ran at 3.5
+    // TB/s, the two-row version at 5.5)
+    const int64_t stride = (int64_t)gridDim.x * ry;
+    for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += 2 * stride) {
+      const bool two = r + stride < R;
+      const int64_t off0 = ((int64_t)g * R + r) * C + c0;
+      const int64_t off1 = two ? off0 + stride * C : off0;
+      float d0[VEC], d1[VEC], x0[VEC], x1[VEC], o[VEC], dr[VEC];
+      VT<T>::load(dy + off0, reinterpret_cast<float(&)[VT<T>::V]>(d0));
+      VT<T>::load(x + off0, reinterpret_cast<float(&)[VT<T>::V]>(x0));
+      const unsigned m0 = amask[off0 >> 3];
+      VT<T>::load(dy + off1, reinterpret_cast<float(&)[VT<T>::V]>(d1));
+      VT<T>::load(x + off1, reinterpret_cast<float(&)[VT<T>::V]>(x1));
+      const unsigned m1 = amask[off1 >> 3];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float d = d0[e] * act_grad_from_bit((m0 >> e) & 1u, act, alpha);
+        dr[e] = d;
+        o[e] = fmaf(gr[e], d, fmaf(-k1[e], x0[e], c0k[e]));
+        if (in_act) o[e] *= act_grad_from_out(x0[e], in_act, in_alpha);
+      }
+      VT<T>::store(dx + off0, reinterpret_cast<float(&)[VT<T>::V]>(o));
+      if (dres) VT<T>::store(dres + off0, reinterpret_cast<float(&)[VT<T>::V]>(dr));
+      if (two) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = d1[e] * act_grad_from_bit((m1 >> e) & 1u, act, alpha);
+          dr[e] = d;
+          o[e] = fmaf(gr[e], d, fmaf(-k1[e], x1[e], c0k[e]));
+          if (in_act) o[e] *= act_grad_from_out(x1[e], in_act, in_alpha);
+        }
+        VT<T>::store(dx + off1, reinterpret_cast<float(&)[VT<T>::V]>(o));
+        if (dres) VT<T>::store(dres + off1, reinterpret_cast<float(&)[VT<T>::V]>(dr));
+      }
+    }
+    return;
   }
   for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
     const int64_t off = ((int64_t)g * R + r) * C + c0;
@@ -455,7 +526,7 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
   dim3 grid((unsigned)rb, (unsigned)l.ctiles, (unsigned)G);
   static const bool unroll2 = [] {
     const char* e = getenv("SE3DS_NORM_UNROLL");
-    return e && atoi(e) == 2;
+    return !(e && atoi(e) == 1);   // default: two rows per iteration
   }();
   if (l.vec > 1 && MODE == 1 && sizeof(T) == 2 && unroll2)
     hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE, true>), grid, dim3(256), 0, s, a, y, x,

@@ -76,6 +76,17 @@ PROD_CONVS = [
     ('D g5 4x4 s1 512->512', 'spectral', 512, 512, 4, 1, 'VALID', 2, True, False, 17, 33, (16,), 16),
     ('D final 4x4 512->1', 'plain', 512, 1, 4, 1, 'SAME', 0, True, False, 18, 34, (16,), 16),
     ('D1 g0 4x4 s2 4->128 @256', 'plain', 4, 128, 4, 2, 'VALID', 2, True, False, 256, 512, (16,), 8),
+    # cfg1 (128x256 panoramas, batch 2): the same channel counts on TINY maps -- fewer pixels than
+    # one pixel tile / one reduction step (ragged tiles, single-step weight gradients)
+    ('cfg1 deconv1 3x3 1024 @8x16', 'spectral', 1024, 1024, 3, 1, 'VALID', 1, False, False, 8, 16, (1, 2), 2),
+    ('cfg1 deconv1 3x3 1024 @4x8', 'spectral', 1024, 1024, 3, 1, 'VALID', 1, False, False, 4, 8, (1,), 1),
+    ('cfg1 deconv2 3x3 512 @4x8', 'spectral', 512, 512, 3, 1, 'VALID', 1, False, False, 4, 8, (1, 2), 2),
+    ('cfg1 stack3 1x1 512->2048 @8x16', 'partial_spectral', 512, 2048, 1, 1, 'SAME', 0, True, True, 8, 16, (2,), 2),
+    ('cfg1 stack3 1x1 2048->512 @8x16', 'partial_spectral', 2048, 512, 1, 1, 'SAME', 0, True, True, 8, 16, (2,), 2),
+    ('cfg1 stack4 3x3 s2 1024 @8x16', 'partial_spectral', 1024, 1024, 3, 2, 'VALID', 1, True, True, 8, 16, (2,), 2),
+    ('cfg1 stack4 1x1 1024->4096 @4x8', 'partial_spectral', 1024, 4096, 1, 1, 'SAME', 0, True, True, 4, 8, (2,), 2),
+    ('cfg1 encoder final 3x3 4096->512 @4x8', 'partial', 4096, 512, 3, 1, 'VALID', 1, True, True, 4, 8, (2,), 2),
+    ('cfg1 agent3 1x1 2048->512 @8x16', 'partial_spectral', 2048, 512, 1, 1, 'SAME', 0, False, False, 8, 16, (2,), 2),
 ]
 
 _ORACLE_CACHE = {}
@@ -149,7 +160,10 @@ def _oracle(case, n):
   return res
 
 
-def _hip(case, n, dtype):
+def _hip(case, n, dtype, prior_grad=None):
+  """prior_grad: an existing gradient of x (a ResNet block input that already received its
+  residual-branch gradient): the data-gradient kernel then ADDS in its epilogue
+  (se3ds_conv2d_dgrad_acc) instead of writing a fresh tensor."""
   name, kind, cin, cout, k, stride, padding, pad, bias, use_mask, h, w, _, _ = case
   x, kern, b, u, mask, gy = _inputs(case, n)
   store = nn.ParamStore()
@@ -174,6 +188,8 @@ def _hip(case, n, dtype):
     yv = res
   y = yv.data.float().cpu().numpy()
   yv.grad = gy.to(DEV).to(dtype)
+  if prior_grad is not None:
+    xv.grad = prior_grad.to(DEV).to(dtype).clone()
   ctx.backward()
   sg.backward_fixup()
   torch.cuda.synchronize()
@@ -215,7 +231,7 @@ def _case_ids():
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 @pytest.mark.parametrize('case,n', _case_ids())
 def test_prod_conv_fwd_dgrad_wgrad(case, n, dtype):
-  if dtype == torch.float32 and n > case[12][0]:
+  if dtype == torch.float32 and n > case[12][0] and not case[0].startswith('cfg1'):
     pytest.skip('fp32 path: smallest batch only (fp32 MFMA peak is 16x lower; same kernels)')
   _check(case, n, dtype)
 
@@ -277,3 +293,26 @@ def test_prod_conv_transpose(case, n, dtype):
   assert e['y'] < t_act and e['dx'] < t_act and e['dk'] < t_par, (name, n, dtype, e)
   if bias:
     assert e['db'] < t_par, (name, e)
+
+
+ACC_CASES = ['cfg1 deconv1 3x3 1024 @8x16', 'cfg1 stack3 1x1 512->2048 @8x16', 'cfg1 deconv2 3x3 512 @4x8',
+             'deconv1 3x3 1024', 'stack3 3x3 512 partial', 'stack3 1x1 512->2048',
+             'stack3 1x1 2048->512', 'stack2 3x3 s2 256 partial', 'final_conv 3x3 128 @256',
+             'D g2 4x4 s2 256->512']
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('name', ACC_CASES)
+def test_prod_conv_dgrad_accumulates_into_existing_gradient(name, dtype):
+  """se3ds_conv2d_dgrad_acc at production shapes: the input already holds a gradient (the residual
+  branch of a ResNet block), the data-gradient epilogue adds to it in place."""
+  case = next(c for c in PROD_CONVS if c[0] == name)
+  n = case[12][0]
+  ref = _oracle(case, n)
+  g0 = _bf(torch.randn(ref['dx'].shape, generator=torch.Generator().manual_seed(5)))
+  got = _hip(case, n, dtype, prior_grad=g0)
+  want = ref['dx'] + g0.numpy()
+  e = rel_err(got['dx'], want)
+  print(f'{name} n{n} {str(dtype)[6:]}: dx(acc)={e:.2e}')
+  # bf16: the sum is rounded once more when it is stored
+  assert e < (TOL_F32 if dtype == torch.float32 else 2 * TOL_BF16_STORED), (name, e)
