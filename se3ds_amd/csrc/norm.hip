@@ -262,8 +262,8 @@ norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
     sc[e] = scale[(int64_t)g * C + c0 + e];
     sh[e] = shift[(int64_t)g * C + c0 + e];
   }
-  if (VEC == 8 && sizeof(T) == 2 && post == nullptr) {
-    // two rows per iteration (see norm_bwd_apply_kernel)
+  if (false && VEC == 8 && sizeof(T) == 2 && post == nullptr) {
+    // two rows per iteration: measured SLOWER here (496 -> 556 us on the 1 GB tensor), kept off
     const int64_t stride = (int64_t)gridDim.x * ry;
     for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += 2 * stride) {
       const bool two = r + stride < R;
