@@ -361,45 +361,6 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
     k1[e] = gr[e] * rs * s1;
     c0k[e] = mu * k1[e] - gr[e] * s0;
   }
-  if (VEC == 8 && sizeof(T) == 2 && amask != nullptr && act) {
-    // two rows per iteration, all loads issued before the first use (load latency x occupancy
-    // bounds these kernels, not bytes: the one-row version of the statistics kernel ran at 3.5
-    // TB/s, the two-row version at 5.5)
-    const int64_t stride = (int64_t)gridDim.x * ry;
-    for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += 2 * stride) {
-      const bool two = r + stride < R;
-      const int64_t off0 = ((int64_t)g * R + r) * C + c0;
-      const int64_t off1 = two ? off0 + stride * C : off0;
-      float d0[VEC], d1[VEC], x0[VEC], x1[VEC], o[VEC], dr[VEC];
-      VT<T>::load(dy + off0, reinterpret_cast<float(&)[VT<T>::V]>(d0));
-      VT<T>::load(x + off0, reinterpret_cast<float(&)[VT<T>::V]>(x0));
-      const unsigned m0 = amask[off0 >> 3];
-      VT<T>::load(dy + off1, reinterpret_cast<float(&)[VT<T>::V]>(d1));
-      VT<T>::load(x + off1, reinterpret_cast<float(&)[VT<T>::V]>(x1));
-      const unsigned m1 = amask[off1 >> 3];
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float d = d0[e] * act_grad_from_bit((m0 >> e) & 1u, act, alpha);
-        dr[e] = d;
-        o[e] = fmaf(gr[e], d, fmaf(-k1[e], x0[e], c0k[e]));
-        if (in_act) o[e] *= act_grad_from_out(x0[e], in_act, in_alpha);
-      }
-      VT<T>::store(dx + off0, reinterpret_cast<float(&)[VT<T>::V]>(o));
-      if (dres) VT<T>::store(dres + off0, reinterpret_cast<float(&)[VT<T>::V]>(dr));
-      if (two) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const float d = d1[e] * act_grad_from_bit((m1 >> e) & 1u, act, alpha);
-          dr[e] = d;
-          o[e] = fmaf(gr[e], d, fmaf(-k1[e], x1[e], c0k[e]));
-          if (in_act) o[e] *= act_grad_from_out(x1[e], in_act, in_alpha);
-        }
-        VT<T>::store(dx + off1, reinterpret_cast<float(&)[VT<T>::V]>(o));
-        if (dres) VT<T>::store(dres + off1, reinterpret_cast<float(&)[VT<T>::V]>(dr));
-      }
-    }
-    return;
-  }
   for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
     const int64_t off = ((int64_t)g * R + r) * C + c0;
     float dv[VEC], yv[VEC], xv[VEC], o[VEC], dr[VEC];
@@ -434,6 +395,87 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
     } else {
       VT<T>::st1(dx + off, o[0]);
       if (dres) VT<T>::st1(dres + off, dr[0]);
+    }
+  }
+}
+
+// bf16 fast path of norm_bwd_apply: activation kinds are TEMPLATE parameters.  With them as
+// runtime values the generic kernel above compiles to ~300 scalar branches per row and waits for
+// every load separately -- 41 us for a 17 MB tensor where the forward apply takes 10 us (ISA:
+// tools/isa_scan.py; measured with tools/norm_bwd_apply_probe.py).  Here the row loop is
+// branch-free and two rows are in flight.  ACT != 0 requires the activation bit mask.
+template <int ACT, int IN_ACT>
+__global__ void __launch_bounds__(256)
+norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
+                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                           const float* __restrict__ gamma, const float* __restrict__ sums,
+                           float count, int64_t R, int C, int cx, int ry, float alpha,
+                           uint16_t* __restrict__ dx, uint16_t* __restrict__ dres,
+                           const uint8_t* __restrict__ amask, float in_alpha) {
+  typedef uint16_t T;
+  constexpr int VEC = 8;
+  const int g = blockIdx.z;
+  const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
+  const int c0 = (blockIdx.y * cx + tx) * VEC;
+  if (c0 >= C) return;
+  float gr[VEC], k1[VEC], c0k[VEC];
+  {
+    const int64_t gc = (int64_t)g * C + c0;
+    float mu[VEC], rs[VEC], gm[VEC], s0[VEC], s1[VEC];
+    VT<float>::load(mean + gc, reinterpret_cast<float(&)[4]>(mu[0]));
+    VT<float>::load(mean + gc + 4, reinterpret_cast<float(&)[4]>(mu[4]));
+    VT<float>::load(rstd + gc, reinterpret_cast<float(&)[4]>(rs[0]));
+    VT<float>::load(rstd + gc + 4, reinterpret_cast<float(&)[4]>(rs[4]));
+    VT<float>::load(gamma + c0, reinterpret_cast<float(&)[4]>(gm[0]));
+    VT<float>::load(gamma + c0 + 4, reinterpret_cast<float(&)[4]>(gm[4]));
+    VT<float>::load(sums + (int64_t)g * 2 * C + c0, reinterpret_cast<float(&)[4]>(s0[0]));
+    VT<float>::load(sums + (int64_t)g * 2 * C + c0 + 4, reinterpret_cast<float(&)[4]>(s0[4]));
+    VT<float>::load(sums + ((int64_t)g * 2 + 1) * C + c0, reinterpret_cast<float(&)[4]>(s1[0]));
+    VT<float>::load(sums + ((int64_t)g * 2 + 1) * C + c0 + 4, reinterpret_cast<float(&)[4]>(s1[4]));
+    const float inv_count = 1.0f / count;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      gr[e] = gm[e] * rs[e];
+      k1[e] = gr[e] * rs[e] * (s1[e] * inv_count);
+      c0k[e] = mu[e] * k1[e] - gr[e] * (s0[e] * inv_count);
+    }
+  }
+  const int64_t stride = (int64_t)gridDim.x * ry;
+  for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += 2 * stride) {
+    const bool two = r + stride < R;
+    const int64_t off0 = ((int64_t)g * R + r) * C + c0;
+    const int64_t off1 = two ? off0 + stride * C : off0;
+    float d0[VEC], d1[VEC], x0[VEC], x1[VEC], o[VEC];
+    unsigned m0 = 0xffu, m1 = 0xffu;
+    VT<T>::load(dy + off0, d0);
+    VT<T>::load(x + off0, x0);
+    if (ACT != 0) m0 = amask[off0 >> 3];
+    VT<T>::load(dy + off1, d1);
+    VT<T>::load(x + off1, x1);
+    if (ACT != 0) m1 = amask[off1 >> 3];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      if (ACT == 1) d0[e] = ((m0 >> e) & 1u) ? d0[e] : 0.0f;
+      if (ACT == 2) d0[e] = ((m0 >> e) & 1u) ? d0[e] : d0[e] * alpha;
+      float v = fmaf(gr[e], d0[e], fmaf(-k1[e], x0[e], c0k[e]));
+      if (IN_ACT == 1) v = x0[e] > 0.0f ? v : 0.0f;
+      if (IN_ACT == 2) v = x0[e] > 0.0f ? v : v * in_alpha;
+      o[e] = v;
+    }
+    VT<T>::store(dx + off0, o);
+    if (dres) VT<T>::store(dres + off0, d0);
+    if (two) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (ACT == 1) d1[e] = ((m1 >> e) & 1u) ? d1[e] : 0.0f;
+        if (ACT == 2) d1[e] = ((m1 >> e) & 1u) ? d1[e] : d1[e] * alpha;
+        float v = fmaf(gr[e], d1[e], fmaf(-k1[e], x1[e], c0k[e]));
+        if (IN_ACT == 1) v = x1[e] > 0.0f ? v : 0.0f;
+        if (IN_ACT == 2) v = x1[e] > 0.0f ? v : v * in_alpha;
+        o[e] = v;
+      }
+      VT<T>::store(dx + off1, o);
+      if (dres) VT<T>::store(dres + off1, d1);
     }
   }
 }
@@ -660,7 +702,22 @@ int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype
     if (l.vec > 1) LAUNCH_BWD(float, 4); else LAUNCH_BWD(float, 1);
   } else if (dtype == SE3DS_BF16) {
     Layout2D l = make_layout(c, 8);
-    if (l.vec > 1) LAUNCH_BWD(uint16_t, 8); else LAUNCH_BWD(uint16_t, 1);
+    static const bool no_fast = getenv("SE3DS_NORM_BWD_GENERIC") != nullptr;
+    const bool fast = l.vec > 1 && gamma != nullptr && (act == 0 || act_mask != nullptr) &&
+                      act >= 0 && act <= 2 && (in_act == 0 || in_act == 2) && !no_fast;
+    if (fast) {
+#define LAUNCH_FAST(A, I)                                                                        \
+  hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<A, I>), ew_grid(l, r, g), dim3(256), 0, s,      \
+                     (const uint16_t*)dy, (const uint16_t*)x, mean, rstd, gamma, sums, count, r, \
+                     c, l.cx, l.ry, alpha, (uint16_t*)dx, (uint16_t*)dres,                        \
+                     (const uint8_t*)act_mask, in_alpha)
+      if (in_act == 0) {
+        if (act == 0) LAUNCH_FAST(0, 0); else if (act == 1) LAUNCH_FAST(1, 0); else LAUNCH_FAST(2, 0);
+      } else {
+        if (act == 0) LAUNCH_FAST(0, 2); else if (act == 1) LAUNCH_FAST(1, 2); else LAUNCH_FAST(2, 2);
+      }
+#undef LAUNCH_FAST
+    } else if (l.vec > 1) LAUNCH_BWD(uint16_t, 8); else LAUNCH_BWD(uint16_t, 1);
   } else {
     return SE3DS_E_BADDTYPE;
   }
