@@ -31,7 +31,7 @@ inline Layout2D make_layout(int C, int V) {
 // mode 0: sums of (x, x^2)                        [forward statistics / column sums]
 // mode 1: sums of (dpre, dpre * xhat), dpre = dy * act'(y)   [backward statistics]
 // Optional row_scale (rows of the [G*R] view) multiplies the first operand (x or dy).
-template <typename T, int VEC, int MODE, bool U2 = false>
+template <typename T, int VEC, int MODE, bool U2 = false, int ACT = 0>
 __global__ void __launch_bounds__(256)
 norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -57,7 +57,7 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
   const int64_t r_lo = (int64_t)blockIdx.x * rows_per_block;
   int64_t r_hi = r_lo + rows_per_block;
   if (r_hi > R) r_hi = R;
-  if (cok && MODE == 1 && VEC == 8 && U2 && amask != nullptr && act && row_scale == nullptr) {
+  if (cok && MODE == 1 && VEC == 8 && U2) {   // (launched only with a mask, ACT in {1, 2}, no row scale)
     // two rows per iteration: all six loads are issued before the first use (the kernel is bound
     // by load latency x occupancy, not by bytes: 3.5 TB/s with one row in flight)
     for (int64_t r = r_lo + ty; r < r_hi; r += 2 * ry) {
@@ -67,20 +67,21 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
       float a0[VEC], a1[VEC], x0[VEC], x1[VEC];
       VT<T>::load(a + off0, reinterpret_cast<float(&)[VT<T>::V]>(a0));
       VT<T>::load(x + off0, reinterpret_cast<float(&)[VT<T>::V]>(x0));
-      const unsigned m0 = amask[off0 >> 3];
+      const unsigned m0 = ACT != 0 ? amask[off0 >> 3] : 0xffu;
       VT<T>::load(a + off1, reinterpret_cast<float(&)[VT<T>::V]>(a1));
       VT<T>::load(x + off1, reinterpret_cast<float(&)[VT<T>::V]>(x1));
-      const unsigned m1 = amask[off1 >> 3];
+      const unsigned m1 = ACT != 0 ? amask[off1 >> 3] : 0xffu;
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float d = a0[e] * act_grad_from_bit((m0 >> e) & 1u, act, alpha);
+        // (ACT is the compile-time activation kind: 1 relu, 2 leaky relu)
+        const float d = (ACT == 0 || ((m0 >> e) & 1u)) ? a0[e] : (ACT == 1 ? 0.0f : a0[e] * alpha);
         s0[e] += d;
         s1[e] += d * ((x0[e] - mu[e]) * rs[e]);
       }
       if (two) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          const float d = a1[e] * act_grad_from_bit((m1 >> e) & 1u, act, alpha);
+          const float d = (ACT == 0 || ((m1 >> e) & 1u)) ? a1[e] : (ACT == 1 ? 0.0f : a1[e] * alpha);
           s0[e] += d;
           s1[e] += d * ((x1[e] - mu[e]) * rs[e]);
         }
@@ -262,38 +263,6 @@ norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
     sc[e] = scale[(int64_t)g * C + c0 + e];
     sh[e] = shift[(int64_t)g * C + c0 + e];
   }
-  if (false && VEC == 8 && sizeof(T) == 2 && post == nullptr) {
-    // two rows per iteration: measured SLOWER here (496 -> 556 us on the 1 GB tensor), kept off
-    const int64_t stride = (int64_t)gridDim.x * ry;
-    for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += 2 * stride) {
-      const bool two = r + stride < R;
-      const int64_t off0 = ((int64_t)g * R + r) * C + c0;
-      const int64_t off1 = two ? off0 + stride * C : off0;
-      float x0[VEC], x1[VEC], r0[VEC], r1[VEC], o[VEC];
-      VT<T>::load(x + off0, reinterpret_cast<float(&)[VT<T>::V]>(x0));
-      if (res) VT<T>::load(res + off0, reinterpret_cast<float(&)[VT<T>::V]>(r0));
-      VT<T>::load(x + off1, reinterpret_cast<float(&)[VT<T>::V]>(x1));
-      if (res) VT<T>::load(res + off1, reinterpret_cast<float(&)[VT<T>::V]>(r1));
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if (half == 1 && !two) break;
-        const int64_t off = half ? off1 : off0;
-        unsigned bits = 0;
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float v = (half ? x1[e] : x0[e]) * sc[e] + sh[e];
-          if (res) v += half ? r1[e] : r0[e];
-          v = act_apply(v, act, alpha);
-          o[e] = v;
-          const uint16_t hb = f32_to_bf16(v);
-          bits |= ((hb & 0x7fffu) != 0 && (hb & 0x8000u) == 0) ? (1u << e) : 0u;
-        }
-        VT<T>::store(y + off, reinterpret_cast<float(&)[VT<T>::V]>(o));
-        if (amask) amask[off >> 3] = (uint8_t)bits;
-      }
-    }
-    return;
-  }
   for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
     const int64_t off = ((int64_t)g * R + r) * C + c0;
     float xv[VEC], rv[VEC], pv[VEC], o[VEC];
@@ -329,6 +298,47 @@ norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
         amask[off >> 3] = (uint8_t)bits;
       }
     }
+  }
+}
+
+// bf16 fast path of norm_apply: activation kind and the residual operand are template
+// parameters (branch-free row loop, cf. norm_bwd_apply_fast_kernel); one row per iteration (two
+// rows in flight measured slower for this kernel).
+template <int ACT, bool HAS_RES>
+__global__ void __launch_bounds__(256)
+norm_apply_fast_kernel(const uint16_t* __restrict__ x, const float* __restrict__ scale,
+                       const float* __restrict__ shift, const uint16_t* __restrict__ res, int64_t R,
+                       int C, int cx, int ry, float alpha, uint16_t* __restrict__ y,
+                       uint8_t* __restrict__ amask) {
+  typedef uint16_t T;
+  constexpr int VEC = 8;
+  const int g = blockIdx.z;
+  const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
+  const int c0 = (blockIdx.y * cx + tx) * VEC;
+  if (c0 >= C) return;
+  float sc[VEC], sh[VEC];
+  VT<float>::load(scale + (int64_t)g * C + c0, reinterpret_cast<float(&)[4]>(sc[0]));
+  VT<float>::load(scale + (int64_t)g * C + c0 + 4, reinterpret_cast<float(&)[4]>(sc[4]));
+  VT<float>::load(shift + (int64_t)g * C + c0, reinterpret_cast<float(&)[4]>(sh[0]));
+  VT<float>::load(shift + (int64_t)g * C + c0 + 4, reinterpret_cast<float(&)[4]>(sh[4]));
+  for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += (int64_t)gridDim.x * ry) {
+    const int64_t off = ((int64_t)g * R + r) * C + c0;
+    float xv[VEC], rv[VEC], o[VEC];
+    VT<T>::load(x + off, xv);
+    if (HAS_RES) VT<T>::load(res + off, rv);
+    unsigned bits = 0;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float v = xv[e] * sc[e] + sh[e];
+      if (HAS_RES) v += rv[e];
+      if (ACT == 1) v = v > 0.f ? v : 0.f;
+      if (ACT == 2) v = v > 0.f ? v : v * alpha;
+      o[e] = v;
+      const uint16_t hb = f32_to_bf16(v);
+      bits |= ((hb & 0x7fffu) != 0 && (hb & 0x8000u) == 0) ? (1u << e) : 0u;
+    }
+    VT<T>::store(y + off, o);
+    if (amask) amask[off >> 3] = (uint8_t)bits;
   }
 }
 
@@ -570,10 +580,18 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
     const char* e = getenv("SE3DS_NORM_UNROLL");
     return !(e && atoi(e) == 1);   // default: two rows per iteration
   }();
-  if (l.vec > 1 && MODE == 1 && sizeof(T) == 2 && unroll2)
-    hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE, true>), grid, dim3(256), 0, s, a, y, x,
-                       mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
-  else if (l.vec > 1)
+  if (l.vec > 1 && MODE == 1 && sizeof(T) == 2 && unroll2 && row_scale == nullptr &&
+      (act == 0 || ((act == 1 || act == 2) && amask != nullptr))) {
+    if (act == 0)
+      hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE, true, 0>), grid, dim3(256), 0, s, a, y,
+                         x, mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
+    else if (act == 1)
+      hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE, true, 1>), grid, dim3(256), 0, s, a, y,
+                         x, mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
+    else
+      hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE, true, 2>), grid, dim3(256), 0, s, a, y,
+                         x, mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
+  } else if (l.vec > 1)
     hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE>), grid, dim3(256), 0, s, a, y, x,
                        mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
   else
@@ -659,7 +677,19 @@ int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const fl
     if (l.vec > 1) LAUNCH_APPLY(float, 4); else LAUNCH_APPLY(float, 1);
   } else if (dtype == SE3DS_BF16) {
     Layout2D l = make_layout(c, 8);
-    if (l.vec > 1) LAUNCH_APPLY(uint16_t, 8); else LAUNCH_APPLY(uint16_t, 1);
+    static const bool no_fast = getenv("SE3DS_NORM_BWD_GENERIC") != nullptr;
+    if (l.vec > 1 && post == nullptr && act >= 0 && act <= 2 && !no_fast) {
+#define LAUNCH_FAST(A, RES)                                                                      \
+  hipLaunchKernelGGL((norm_apply_fast_kernel<A, RES>), ew_grid(l, r, g), dim3(256), 0, s,        \
+                     (const uint16_t*)x, scale, shift, (const uint16_t*)res, r, c, l.cx, l.ry,   \
+                     alpha, (uint16_t*)y, (uint8_t*)act_mask)
+      if (res) {
+        if (act == 0) LAUNCH_FAST(0, true); else if (act == 1) LAUNCH_FAST(1, true); else LAUNCH_FAST(2, true);
+      } else {
+        if (act == 0) LAUNCH_FAST(0, false); else if (act == 1) LAUNCH_FAST(1, false); else LAUNCH_FAST(2, false);
+      }
+#undef LAUNCH_FAST
+    } else if (l.vec > 1) LAUNCH_APPLY(uint16_t, 8); else LAUNCH_APPLY(uint16_t, 1);
   } else {
     return SE3DS_E_BADDTYPE;
   }
