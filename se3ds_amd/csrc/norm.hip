@@ -28,6 +28,19 @@ inline Layout2D make_layout(int C, int V) {
   return l;
 }
 
+// raw 16-byte load / unpack of 8 bf16 (the two-row kernels load everything first, THEN convert:
+// with VT<T>::load the compiler schedules the conversion -- the first use -- right behind each
+// load and waits for every load separately)
+__device__ __forceinline__ uint4 ld16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void unpack8(const uint4& v, float (&o)[8]) {
+  const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    o[2 * e] = __uint_as_float(q[e] << 16);
+    o[2 * e + 1] = __uint_as_float(q[e] & 0xffff0000u);
+  }
+}
+
 // mode 0: sums of (x, x^2)                        [forward statistics / column sums]
 // mode 1: sums of (dpre, dpre * xhat), dpre = dy * act'(y)   [backward statistics]
 // Optional row_scale (rows of the [G*R] view) multiplies the first operand (x or dy).
@@ -64,13 +77,13 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
       const bool two = r + ry < r_hi;
       const int64_t off0 = ((int64_t)g * R + r) * C + c0;
       const int64_t off1 = two ? off0 + (int64_t)ry * C : off0;
-      float a0[VEC], a1[VEC], x0[VEC], x1[VEC];
-      VT<T>::load(a + off0, reinterpret_cast<float(&)[VT<T>::V]>(a0));
-      VT<T>::load(x + off0, reinterpret_cast<float(&)[VT<T>::V]>(x0));
+      float a0[8], a1[8], x0[8], x1[8];
+      const uint4 qa0 = ld16((const uint16_t*)a + off0), qx0 = ld16((const uint16_t*)x + off0);
+      const uint4 qa1 = ld16((const uint16_t*)a + off1), qx1 = ld16((const uint16_t*)x + off1);
       const unsigned m0 = ACT != 0 ? amask[off0 >> 3] : 0xffu;
-      VT<T>::load(a + off1, reinterpret_cast<float(&)[VT<T>::V]>(a1));
-      VT<T>::load(x + off1, reinterpret_cast<float(&)[VT<T>::V]>(x1));
       const unsigned m1 = ACT != 0 ? amask[off1 >> 3] : 0xffu;
+      __builtin_amdgcn_sched_barrier(0);   // all six loads are issued before the first use
+      unpack8(qa0, a0); unpack8(qx0, x0); unpack8(qa1, a1); unpack8(qx1, x1);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         // (ACT is the compile-time activation kind: 1 relu, 2 leaky relu)
@@ -457,12 +470,12 @@ norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __re
     const int64_t off1 = two ? off0 + stride * C : off0;
     float d0[VEC], d1[VEC], x0[VEC], x1[VEC], o[VEC];
     unsigned m0 = 0xffu, m1 = 0xffu;
-    VT<T>::load(dy + off0, d0);
-    VT<T>::load(x + off0, x0);
+    const uint4 qd0 = ld16(dy + off0), qx0 = ld16(x + off0);
+    const uint4 qd1 = ld16(dy + off1), qx1 = ld16(x + off1);
     if (ACT != 0) m0 = amask[off0 >> 3];
-    VT<T>::load(dy + off1, d1);
-    VT<T>::load(x + off1, x1);
     if (ACT != 0) m1 = amask[off1 >> 3];
+    __builtin_amdgcn_sched_barrier(0);   // all six loads are issued before the first use
+    unpack8(qd0, d0); unpack8(qx0, x0); unpack8(qd1, d1); unpack8(qx1, x1);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       if (ACT == 1) d0[e] = ((m0 >> e) & 1u) ? d0[e] : 0.0f;
