@@ -70,33 +70,38 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
   const int64_t r_lo = (int64_t)blockIdx.x * rows_per_block;
   int64_t r_hi = r_lo + rows_per_block;
   if (r_hi > R) r_hi = R;
-  if (cok && MODE == 1 && VEC == 8 && U2) {   // (launched only with a mask, ACT in {1, 2}, no row scale)
-    // two rows per iteration: all six loads are issued before the first use (the kernel is bound
-    // by load latency x occupancy, not by bytes: 3.5 TB/s with one row in flight)
-    for (int64_t r = r_lo + ty; r < r_hi; r += 2 * ry) {
-      const bool two = r + ry < r_hi;
-      const int64_t off0 = ((int64_t)g * R + r) * C + c0;
-      const int64_t off1 = two ? off0 + (int64_t)ry * C : off0;
-      float a0[8], a1[8], x0[8], x1[8];
-      const uint4 qa0 = ld16((const uint16_t*)a + off0), qx0 = ld16((const uint16_t*)x + off0);
-      const uint4 qa1 = ld16((const uint16_t*)a + off1), qx1 = ld16((const uint16_t*)x + off1);
-      const unsigned m0 = ACT != 0 ? amask[off0 >> 3] : 0xffu;
-      const unsigned m1 = ACT != 0 ? amask[off1 >> 3] : 0xffu;
-      __builtin_amdgcn_sched_barrier(0);   // all six loads are issued before the first use
-      unpack8(qa0, a0); unpack8(qx0, x0); unpack8(qa1, a1); unpack8(qx1, x1);
+  if (cok && MODE == 1 && VEC == 8 && U2) {   // (launched only when ACT matches `act`, no row scale)
+    // NR rows per iteration: the 2 * NR 16-byte loads (+ NR mask bytes) are issued as raw loads
+    // before anything is converted (load latency x occupancy bounds this kernel, not bytes: one
+    // row in flight ran at 3.5 TB/s on a 1 GB tensor, two at 5.5)
+    constexpr int NR = 4;
+    const uint16_t* A = (const uint16_t*)a;
+    const uint16_t* X = (const uint16_t*)x;
+    for (int64_t r = r_lo + ty; r < r_hi; r += (int64_t)NR * ry) {
+      uint4 qa[NR], qx[NR];
+      unsigned mk[NR];
+      bool ok[NR];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        // (ACT is the compile-time activation kind: 1 relu, 2 leaky relu)
-        const float d = (ACT == 0 || ((m0 >> e) & 1u)) ? a0[e] : (ACT == 1 ? 0.0f : a0[e] * alpha);
-        s0[e] += d;
-        s1[e] += d * ((x0[e] - mu[e]) * rs[e]);
+      for (int u = 0; u < NR; ++u) {
+        ok[u] = r + (int64_t)u * ry < r_hi;
+        const int64_t off = ((int64_t)g * R + (ok[u] ? r + (int64_t)u * ry : r)) * C + c0;
+        qa[u] = ld16(A + off);
+        qx[u] = ld16(X + off);
+        mk[u] = ACT != 0 ? amask[off >> 3] : 0xffu;
       }
-      if (two) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        if (!ok[u]) continue;
+        float av[8], xv[8];
+        unpack8(qa[u], av);
+        unpack8(qx[u], xv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          const float d = (ACT == 0 || ((m1 >> e) & 1u)) ? a1[e] : (ACT == 1 ? 0.0f : a1[e] * alpha);
+          // (ACT is the compile-time activation kind: 0 none, 1 relu, 2 leaky relu)
+          const float d = (ACT == 0 || ((mk[u] >> e) & 1u)) ? av[e] : (ACT == 1 ? 0.0f : av[e] * alpha);
           s0[e] += d;
-          s1[e] += d * ((x1[e] - mu[e]) * rs[e]);
+          s1[e] += d * ((xv[e] - mu[e]) * rs[e]);
         }
       }
     }
