@@ -1,0 +1,39 @@
+"""Summarise rocprofv3 PMC passes (rocpd .db files) per kernel: counter averages per launch.
+usage: pmc_summary.py out.json '<glob>' ['<regex on kernel names>']   (several globs allowed)
+FETCH_SIZE / WRITE_SIZE are reported in MB per launch (the counters are in KB); FETCH_SIZE is also
+given with the guide's gfx950 correction for wide coalesced reads (x2, MI355X_MICROARCH.md, HBM)."""
+import glob
+import json
+import re
+import sqlite3
+import sys
+
+out_path = sys.argv[1]
+globs = [a for a in sys.argv[2:] if '*' in a or a.endswith('.db')]
+pats = [a for a in sys.argv[2:] if a not in globs]
+pat = re.compile(pats[0]) if pats else None
+res = {}
+for g in globs:
+  for path in glob.glob(g):
+    db = sqlite3.connect(path)
+    q = 'select name, counter_name, avg(counter_value), count(*) from pmc_events group by name, counter_name'
+    for name, counter, v, n in db.execute(q):
+      if pat and not pat.search(name):
+        continue
+      m = re.search(r'(\w+_kernel(<[^(]*>)?)', name)
+      short = (m.group(1) if m else name[:60]).replace('se3ds::(anonymous namespace)::', '')
+      res.setdefault(short, {})[counter] = dict(avg=v, launches=n)
+for k, d in res.items():
+  if 'FETCH_SIZE' in d:
+    d['fetch_mb'] = d['FETCH_SIZE']['avg'] / 1024
+    d['fetch_mb_x2_wide_read_correction'] = 2 * d['fetch_mb']
+  if 'WRITE_SIZE' in d:
+    d['write_mb'] = d['WRITE_SIZE']['avg'] / 1024
+  if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'SQ_BUSY_CYCLES' in d and d['SQ_BUSY_CYCLES']['avg'] > 0:
+    d['mfma_busy_over_sq_busy'] = d['SQ_VALU_MFMA_BUSY_CYCLES']['avg'] / d['SQ_BUSY_CYCLES']['avg']
+  if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'GRBM_GUI_ACTIVE' in d and d['GRBM_GUI_ACTIVE']['avg'] > 0:
+    # MFMA_BUSY sums over the 4 SIMDs of 256 CUs; GUI_ACTIVE is wall cycles of the dispatch
+    d['mfma_util_of_1024_simds'] = d['SQ_VALU_MFMA_BUSY_CYCLES']['avg'] / (1024.0 * d['GRBM_GUI_ACTIVE']['avg'])
+json.dump(res, open(out_path, 'w'), indent=1, sort_keys=True)
+for k, d in sorted(res.items()):
+  print(k[:70].ljust(70), {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in d.items() if not isinstance(vv, dict)})
