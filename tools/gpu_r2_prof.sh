@@ -24,3 +24,6 @@ python tools/pmc_summary.py gpurun_out/r02_warp_pmc.json "gpurun_out/pmc_r2_f_wa
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_warp_r2b -o warp -- python bench.py --workload warp --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
 python tools/rocpd_summary.py gpurun_out/prof_warp_r2b/warp_results.db gpurun_out/r02_warp_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload warp --steps 200 --warmup 20 --no-cpu-baseline"
 head -8 gpurun_out/r02_warp_kernel_stats.csv | cut -c1-150
+# the raw databases are large (the merge back is limited to 64 MiB): keep the summaries only
+rm -rf gpurun_out/prof_gan_r2 gpurun_out/prof_warp_r2b gpurun_out/pmc_r2_*
+du -sh gpurun_out

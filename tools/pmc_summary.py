@@ -36,4 +36,5 @@ for k, d in res.items():
     d['mfma_util_of_1024_simds'] = d['SQ_VALU_MFMA_BUSY_CYCLES']['avg'] / (1024.0 * d['GRBM_GUI_ACTIVE']['avg'])
 json.dump(res, open(out_path, 'w'), indent=1, sort_keys=True)
 for k, d in sorted(res.items()):
-  print(k[:70].ljust(70), {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in d.items() if not isinstance(vv, dict)})
+  print(k[:70].ljust(70), {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in d.items() if not isinstance(vv, dict)},
+        {kk: '%.4g' % vv['avg'] for kk, vv in d.items() if isinstance(vv, dict) and kk.startswith(('SQ_', 'GRBM'))})
