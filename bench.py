@@ -70,6 +70,28 @@ def _launch_ranks(n):
   return subprocess.run(cmd, env=env).returncode
 
 
+def _pmc_traffic(json_name, kernels):
+  """HBM bytes per launch from the TRACKED rocprofv3 PMC summaries under profiles/ (separate
+  FETCH_SIZE / WRITE_SIZE passes, tools/gpu_r2_prof.sh; raw counter values, the guide's x2 gfx950
+  correction for wide coalesced reads is listed beside them).  None when the file is missing."""
+  path = os.path.join(ROOT, 'profiles', json_name)
+  if not os.path.exists(path):
+    return None, None
+  d = json.load(open(path))
+  fetch = write = 0.0
+  used = []
+  for k, v in d.items():
+    if any(t in k for t in kernels) and 'fetch_mb' in v and 'write_mb' in v:
+      fetch += v['fetch_mb']
+      write += v['write_mb']
+      used.append(k)
+  if not used:
+    return None, None
+  detail = {'source': 'profiles/' + json_name, 'kernels': sorted(used), 'fetch_mb_raw': fetch,
+            'fetch_mb_x2_wide_read_correction': 2 * fetch, 'write_mb': write}
+  return (fetch + write) * 1e6, detail
+
+
 def _barrier(world):
   if world > 1:
     dist.barrier()
@@ -168,6 +190,9 @@ def bench_warp(args, rank, world, dev):
   algo_bytes = 28 * M + 20 * P  # 28 B/point in, 16 B/px out + 4 B/px mask
   achieved = algo_bytes / (proj_ms * 1e-3) / 1e9
 
+  traffic, traffic_detail = (None, None)
+  if (h, views, args.warp_depth) == (1024, 2, 'random'):
+    traffic, traffic_detail = _pmc_traffic('r02_warp_pmc.json', ('splat_bin', 'splat_tile', 'splat_sink'))
   out = {
       'metric': 'panoramas/sec (2-view unproject + 1 target render, 1024x2048 equirect)',
       'value': world * args.steps / dt, 'unit': 'panoramas/sec', 'n_gpus': world,
@@ -178,7 +203,8 @@ def bench_warp(args, rank, world, dev):
                              ('' if args.warp_depth == 'random' else f', {args.warp_depth} depth')},
       'roofline': {'bound': 'hbm', 'kernel': 'project+splat (chunk count, column scan, scatter, per-tile resolve)',
                    'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                   'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                   'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                   'traffic_detail': traffic_detail,
                    'ms_per_launch': proj_ms, 'algorithmic_bytes': algo_bytes},
   }
   if rank == 0 and world == 1 and not args.no_cpu_baseline:

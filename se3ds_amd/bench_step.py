@@ -94,6 +94,22 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
   peak = BF16_PEAK_TFLOPS if args.dtype == 'bf16' else F32_PEAK_TFLOPS
   achieved = summ['flops'] / (summ['ms'] * 1e-3) / 1e12 if summ['ms'] > 0 else 0.0
   m = gan._save_metrics_to_dict()
+  # HBM traffic of the dominant kernel (3x3 1024->1024 @32x64 forward, 35 % of the conv time with
+  # its data-gradient twin) from the tracked PMC summary; the family is MFMA-bound, the figure
+  # shows that no kernel re-reads its operands from HBM (algorithmic: 52 MB in, 33.5 MB out)
+  traffic = traffic_detail = None
+  if h == 512 and n == 8 and args.dtype == 'bf16':
+    import json
+    path = os.path.join(ROOT, 'profiles', 'r02_conv_pmc_1024_1024_3_1_32_64_1_8.json')
+    if os.path.exists(path):
+      k = json.load(open(path)).get('igemm_halo_kernel<0, 256, 2>')
+      if k and 'fetch_mb' in k:
+        traffic = (k['fetch_mb'] + k['write_mb']) * 1e6
+        traffic_detail = {'source': 'profiles/r02_conv_pmc_1024_1024_3_1_32_64_1_8.json',
+                          'kernel': 'igemm_halo_kernel<0, 256, 2> (3x3 1024->1024 @32x64, batch 8)',
+                          'fetch_mb_raw': k['fetch_mb'],
+                          'fetch_mb_x2_wide_read_correction': 2 * k['fetch_mb'],
+                          'write_mb': k['write_mb'], 'algorithmic_mb': 52.4 + 33.6}
   out = {
       'metric': 'panoramas/sec (G+D train step) at 512x1024 RGB-D' if h == 512 else
                 f'panoramas/sec (G+D train step) at {h}x{2 * h} RGB-D',
@@ -107,7 +123,8 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
       'roofline': {'bound': 'mfma', 'kernel': 'implicit-GEMM convolutions: igemm_halo / igemm_big / '
                    'igemm_glds + wgrad_taps / wgrad_glds (every conv fwd, dgrad and wgrad call of '
                    'one step)', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                   'frac': achieved / peak, 'traffic': None, 'launches': summ['launches'],
+                   'frac': achieved / peak, 'traffic': traffic, 'traffic_detail': traffic_detail,
+                   'launches': summ['launches'],
                    'avg_launch_ms': summ['ms'] / max(summ['launches'], 1),
                    'conv_ms_per_step': summ['ms'], 'conv_tflop_per_step': summ['flops'] / 1e12,
                    'by_kind': summ['by_kind']},
