@@ -4,8 +4,8 @@ cd $GRAFT_REPO_ROOT
 ulimit -c 0
 mkdir -p gpurun_out
 SECONDS=0
-timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest rc=$? elapsed $SECONDS s"; tail -5 gpurun_out/pytest_gpu.log
+timeout 3000 python -m pytest tests -m gpu -x -q --durations=15 > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest rc=$? elapsed $SECONDS s"; tail -25 gpurun_out/pytest_gpu.log
 SECONDS=0
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 echo "smoke rc=$? elapsed $SECONDS s"; tail -3 gpurun_out/smoke.log
