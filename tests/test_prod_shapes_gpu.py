@@ -316,3 +316,71 @@ def test_prod_conv_dgrad_accumulates_into_existing_gradient(name, dtype):
   print(f'{name} n{n} {str(dtype)[6:]}: dx(acc)={e:.2e}')
   # bf16: the sum is rounded once more when it is stored
   assert e < (TOL_F32 if dtype == torch.float32 else 2 * TOL_BF16_STORED), (name, e)
+
+
+# ------------------------------------------------------------------------------ norm layers
+# kind, n, h, w, c, act, with_res  (cfg3 / cfg1 tensor shapes of the generator's batch norms and the
+# discriminator's instance norms; training mode = batch statistics)
+PROD_NORMS = [
+    ('batch', 2, 8, 16, 1024, 1, True),      # cfg1 deconv1 (256 samples per channel)
+    ('batch', 2, 8, 16, 2048, 1, True),      # cfg1 stack3 bn3
+    ('batch', 2, 4, 8, 4096, 1, True),       # cfg1 stack4 bn3 (64 samples per channel)
+    ('batch', 8, 32, 64, 1024, 1, True),     # cfg3 deconv1
+    ('batch', 2, 128, 256, 128, 1, True),    # cfg1 final_conv / cfg3 deconv4 class
+    ('batch', 2, 512, 1024, 128, 0, False),  # cfg3 head batch norm (no activation)
+    ('batch', 2, 64, 128, 512, 2, False),    # upc-style LeakyReLU
+    ('instance', 4, 129, 257, 256, 2, False),  # discriminator group 1
+    ('instance', 4, 17, 33, 512, 2, False),    # discriminator group 4
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', PROD_NORMS, ids=[f'{c[0]}_{c[1]}x{c[2]}x{c[3]}x{c[4]}' for c in PROD_NORMS])
+def test_prod_norm_fwd_bwd(case, dtype):
+  kind, n, h, w, c, act, with_res = case
+  store = nn.ParamStore()
+  layer = nn.NormLayer(store, 'n', c, kind)
+  store.finalize(DEV, None)
+  gen = torch.Generator().manual_seed(3 + c + h)
+  store.load_dict({'n/gamma': (torch.rand(c, generator=gen) + 0.5).numpy(),
+                   'n/beta': (torch.randn(c, generator=gen) * 0.2).numpy()})
+  # channel means far from zero relative to the spread (as behind a ReLU + residual stream)
+  x = _bf(torch.randn((n, h, w, c), generator=gen) * 0.7 + torch.randn(c, generator=gen) * 2.0)
+  r = _bf(torch.randn((n, h, w, c), generator=gen))
+  gy = _bf(torch.randn((n, h, w, c), generator=gen))
+  alpha = 0.2
+  p = {k: v.cpu().clone() for k, v in store.views.items()}
+  p['n/gamma'].requires_grad_(True)
+  p['n/beta'].requires_grad_(True)
+  xo, ro = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+  net = O.Net(p, training=True)
+  yo = net.sync_bn(xo, 'n') if kind == 'batch' else net.instance_norm(xo, 'n')
+  if with_res:
+    yo = yo + ro
+  if act == 1:
+    yo = torch.relu(yo)
+  elif act == 2:
+    yo = O.leaky_relu(yo, alpha)
+  yo.backward(gy)
+  ctx = nn.Ctx(DEV, dtype, training=True, record=True)
+  xv = nn.Var(x.to(DEV).to(dtype))
+  rv = nn.Var(r.to(DEV).to(dtype)) if with_res else None
+  yv = nn.norm_act(ctx, xv, layer, act=act, alpha=alpha, res=rv)
+  t_act = TOL_F32 if dtype == torch.float32 else 2 * TOL_BF16_STORED
+  t_par = 2e-4 if dtype == torch.float32 else 1e-2
+  e = dict(y=rel_err(yv.data.float().cpu().numpy(), yo.detach().numpy()))
+  if kind == 'batch':
+    for nm in ('moving_mean', 'moving_variance'):
+      assert rel_err(store['n/' + nm].cpu().numpy(), net.updates['n/' + nm].numpy()) < 1e-5, nm
+  yv.grad = gy.to(DEV).to(dtype)
+  ctx.backward()
+  e['dx'] = rel_err(xv.grad.float().cpu().numpy(), xo.grad.numpy())
+  e['dgamma'] = rel_err(store.grad_views['n/gamma'].cpu().numpy(), p['n/gamma'].grad.numpy())
+  e['dbeta'] = rel_err(store.grad_views['n/beta'].cpu().numpy(), p['n/beta'].grad.numpy())
+  if with_res:
+    e['dres'] = rel_err(rv.grad.float().cpu().numpy(), ro.grad.numpy())
+  print(f'{case} {str(dtype)[6:]}: ' + ' '.join(f'{k}={v:.2e}' for k, v in e.items()))
+  assert e['y'] < t_act and e['dx'] < 2 * t_act, e
+  assert e['dgamma'] < t_par and e['dbeta'] < t_par, e
+  if with_res:
+    assert e['dres'] < t_act, e
