@@ -124,6 +124,28 @@ __device__ __forceinline__ void mfma_tile<float>(f32x16_t (&acc)[2][2], const ui
         }
 }
 
+// fp32 (parity) path: two-level accumulation.  A 32x32x2 MFMA chain adds the K products strictly in
+// sequence, so its rounding error grows like sqrt(K) (measured 1.6e-6 relative at K = 9216, 6.5x the
+// PyTorch-CPU oracle whose vector lanes hold 16 interleaved partial sums).  Flushing the chain into
+// a second accumulator every kFlushSteps K steps brings the two to the same level; deep
+// batch-normalised nets amplify that difference ~1e4 x (tools/noise_probe.py).  bf16
+// instantiations compile to nothing.
+constexpr int kFlushSteps = 4;
+template <typename T>
+__device__ __forceinline__ void flush_acc(f32x16_t (&tot)[2][2], f32x16_t (&acc)[2][2]) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          tot[i][j][r] += acc[i][j][r];
+          acc[i][j][r] = 0.f;
+        }
+  }
+}
+
 // Decoded coordinates of one gather row (an output pixel of this kernel).
 struct RowInfo {
   int n, a, b;   // FWD: (n, oy, ox)   DGRAD: (n, iy, ix)
@@ -532,13 +554,13 @@ igemm_kernel(const IgemmParams p) {
     }
   };
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[2][2], tot[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
   if (nk > 0) {
     load_step(0);
@@ -563,8 +585,13 @@ igemm_kernel(const IgemmParams p) {
         xf[i][ks] = *reinterpret_cast<const uint4*>(xt + xrow * ROWB + swz(xrow, c) * 16);
       }
     mfma_tile<T>(acc, wf, xf);
+    if ((kt % kFlushSteps) == kFlushSteps - 1) flush_acc<T>(tot, acc);
     if (kt + 1 < nk) store_step(stage ^ 1);
     __syncthreads();
+  }
+  if constexpr (sizeof(T) == 4) {
+    flush_acc<T>(tot, acc);
+    flush_acc<T>(acc, tot);   // result back in acc
   }
 
   store_tile<T, MODE>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py, px,
@@ -722,13 +749,13 @@ igemm_glds_kernel(const IgemmParams p) {
     }
   };
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[2][2], tot[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
   if (nk > 0) {
     setup_tap(0);
@@ -760,6 +787,11 @@ igemm_glds_kernel(const IgemmParams p) {
   for (int kt = 0; kt < nk; kt += 2) {
     k_step(stage0, stage1, kt + 1 < nk);
     if (kt + 1 < nk) k_step(stage1, stage0, kt + 2 < nk);
+    if ((kt & 2) != 0) flush_acc<T>(tot, acc);   // every 4 K steps (128 fp32 products per output)
+  }
+  if constexpr (sizeof(T) == 4) {
+    flush_acc<T>(tot, acc);
+    flush_acc<T>(acc, tot);
   }
   // (the loop's closing __syncthreads leaves both stages idle: stage0 is the epilogue scratch)
   float* stats_row = (MODE == MODE_FWD && p.stats)

@@ -5,6 +5,7 @@
 // deterministically in two stages (per-block partials -> final), so that the cross-replica
 // all-reduce of [2][C] sums (SyncBN, image_models.py:80-123 etc.) sits between two launches.
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace se3ds {
@@ -52,15 +53,23 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
                     float alpha, int rblocks, float* __restrict__ partial,
                     const uint8_t* __restrict__ amask) {
   // grid: (rblocks, ctiles, G)
-  __shared__ float red[2][256 * (VEC > 1 ? VEC : 1)];
+  // fp32 (parity) path: binary64 accumulators.  Batch-norm statistics enter as
+  // var = E[x^2] - E[x]^2 (the reference's formula): with channel means of a few standard
+  // deviations every 1e-6 of relative error in the sums becomes 1e-5 in the output, and on a
+  // 16 M-element tensor behind a ReLU that flips the derivative of hundreds of elements against
+  // any other fp32 implementation.  PyTorch's cascade summation is ~10x more accurate than fp32
+  // partial sums of 8..128 rows + a 64-deep second stage; binary64 closes that gap for free (the
+  // kernel is bound by its loads).  bf16 keeps fp32 accumulators.
+  typedef typename std::conditional<sizeof(T) == 4, double, float>::type ACC;
+  __shared__ ACC red[2][256 * (VEC > 1 ? VEC : 1)];
   const int g = blockIdx.z;
   const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
   const int cv = blockIdx.y * cx + tx;  // channel-vector index
   const int c0 = cv * VEC;
   const bool cok = c0 < C;
-  float s0[VEC], s1[VEC];
+  ACC s0[VEC], s1[VEC];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+  for (int e = 0; e < VEC; ++e) { s0[e] = 0; s1[e] = 0; }
   float mu[VEC], rs[VEC];
   if (MODE == 1 && cok) {
 #pragma unroll
@@ -115,7 +124,7 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
       if (MODE == 0) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          float v = av[e] * rsc;
+          const ACC v = (ACC)(av[e] * rsc);
           s0[e] += v;
           s1[e] += v * v;
         }
@@ -163,8 +172,8 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
     float* P = partial + (((int64_t)g * rblocks + blockIdx.x) * 2) * C;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      P[c0 + e] = s0[e];
-      P[C + c0 + e] = s1[e];
+      P[c0 + e] = (float)s0[e];
+      P[C + c0 + e] = (float)s1[e];
     }
   }
 }
@@ -181,12 +190,13 @@ norm_final_reduce_kernel(const float* __restrict__ partial, int rblocks, int C, 
                          float* __restrict__ sums, float* __restrict__ dst0,
                          float* __restrict__ dst1) {
   static_assert(COLS * LANES == 256, "block shape");
-  __shared__ float sh[LANES][COLS + 1];
+  // (binary64 accumulation: a few hundred adds per launch, see norm_partial_kernel)
+  __shared__ double sh[LANES][COLS + 1];
   const int g = blockIdx.y;
   const int cl = threadIdx.x % COLS;
   const int col = blockIdx.x * COLS + cl;   // index into [2][C]
   const int lane_b = threadIdx.x / COLS;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
   if (col < 2 * C) {
     const float* P = partial + (int64_t)g * rblocks * 2 * C + col;
     int b = lane_b;
@@ -201,9 +211,10 @@ norm_final_reduce_kernel(const float* __restrict__ partial, int rblocks, int C, 
   sh[lane_b][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (lane_b == 0 && col < 2 * C) {
-    float t = 0.f;
+    double td = 0;
 #pragma unroll
-    for (int i = 0; i < LANES; ++i) t += sh[i][cl];
+    for (int i = 0; i < LANES; ++i) td += sh[i][cl];
+    const float t = (float)td;
     sums[(int64_t)g * 2 * C + col] = t;
     if (g == 0) {
       if (dst0 && col < C) dst0[col] = t;

@@ -352,23 +352,42 @@ def test_prod_norm_fwd_bwd(case, dtype):
   p = {k: v.cpu().clone() for k, v in store.views.items()}
   p['n/gamma'].requires_grad_(True)
   p['n/beta'].requires_grad_(True)
-  xo, ro = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
-  net = O.Net(p, training=True)
-  yo = net.sync_bn(xo, 'n') if kind == 'batch' else net.instance_norm(xo, 'n')
-  if with_res:
-    yo = yo + ro
-  if act == 1:
-    yo = torch.relu(yo)
-  elif act == 2:
-    yo = O.leaky_relu(yo, alpha)
-  yo.backward(gy)
   ctx = nn.Ctx(DEV, dtype, training=True, record=True)
   xv = nn.Var(x.to(DEV).to(dtype))
   rv = nn.Var(r.to(DEV).to(dtype)) if with_res else None
   yv = nn.norm_act(ctx, xv, layer, act=act, alpha=alpha, res=rv)
+  y_h = yv.data.float().cpu()
+  xo, ro = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+  net = O.Net(p, training=True)
+  pre = net.sync_bn(xo, 'n') if kind == 'batch' else net.instance_norm(xo, 'n')
+  if with_res:
+    pre = pre + ro
+  # The derivative of ReLU / LeakyReLU is a DECISION on the sign of the pre-activation.  Two correct
+  # fp32 evaluations of var = E[x^2] - E[x]^2 differ by ~1e-6 relative, so on a 16 M-element tensor a
+  # few dozen pre-activations straddle zero and the two backward passes differ there by a whole
+  # |dy| (0.25 in max-norm at 8x32x64x1024 -- measured, both implementations correct).  The test
+  # therefore (1) bounds where decisions may differ -- only inside the forward error band around
+  # zero, which is a theorem for correct arithmetic -- and (2) runs the oracle's backward under the
+  # HIP path's decisions, after which everything is linear algebra and must agree tightly.
+  if act == 0:
+    yo_own = pre
+    yo = pre
+    flips = 0
+  else:
+    slope = 0.0 if act == 1 else alpha
+    pos_h = y_h > 0
+    pos_o = pre.detach() > 0
+    yo_own = torch.where(pos_o, pre.detach(), pre.detach() * slope)
+    yo = torch.where(pos_h, pre, pre * slope)
+    flip = pos_h != pos_o
+    flips = int(flip.sum())
+    band = float((y_h - yo_own).abs().max()) * 1.01 + 1e-30
+    assert not bool((flip & (pre.detach().abs() > band)).any()), 'sign decision outside the error band'
+    assert flips <= 2e-4 * flip.numel(), flips
+  yo.backward(gy)
   t_act = TOL_F32 if dtype == torch.float32 else 2 * TOL_BF16_STORED
   t_par = 2e-4 if dtype == torch.float32 else 1e-2
-  e = dict(y=rel_err(yv.data.float().cpu().numpy(), yo.detach().numpy()))
+  e = dict(y=rel_err(y_h.numpy(), yo_own.detach().numpy()))
   if kind == 'batch':
     for nm in ('moving_mean', 'moving_variance'):
       assert rel_err(store['n/' + nm].cpu().numpy(), net.updates['n/' + nm].numpy()) < 1e-5, nm
@@ -379,7 +398,7 @@ def test_prod_norm_fwd_bwd(case, dtype):
   e['dbeta'] = rel_err(store.grad_views['n/beta'].cpu().numpy(), p['n/beta'].grad.numpy())
   if with_res:
     e['dres'] = rel_err(rv.grad.float().cpu().numpy(), ro.grad.numpy())
-  print(f'{case} {str(dtype)[6:]}: ' + ' '.join(f'{k}={v:.2e}' for k, v in e.items()))
+  print(f'{case} {str(dtype)[6:]}: flips={flips} ' + ' '.join(f'{k}={v:.2e}' for k, v in e.items()))
   assert e['y'] < t_act and e['dx'] < 2 * t_act, e
   assert e['dgamma'] < t_par and e['dbeta'] < t_par, e
   if with_res:
