@@ -2038,6 +2038,227 @@ wgrad_taps_kernel(const WgradTapsParams p) {
   }
 }
 
+// ------------------------------------------------- tap-fused 3x3 wgrad, step-pipelined schedule
+// Same tiling, LDS layout and fragment reads as wgrad_taps_kernel, different schedule (round 2;
+// measured on 3x3 1024->1024 @32x64 batch 8 with compile-time switches: MFMAs alone 126-143 us,
+// the ping-pong kernel 346 us of which the per-step DMA issue code, the barrier bubble at every
+// step boundary and the unhidden LDS-DMA account for ~150 us):
+//  * three LDS stages; ONE barrier per step, placed after the third of the four 16-pixel slots:
+//    it publishes the tiles of step st+1 (fetched a whole step earlier) and frees the stage of
+//    step st-1 for the tiles of step st+2, whose LDS-DMA is issued right behind it.  The last
+//    slot then already reads the first fragments of step st+1, so no wave meets the barrier
+//    with an empty MFMA queue;
+//  * inside a step: wait(k) -> issue the reads of slot k+1 -> nine MFMAs of slot k.  At every
+//    wait only the fragments it needs are outstanding (lgkmcnt(0) is exact);
+//  * the DMA source addresses are a per-step scalar base + per-lane constants (no divisions,
+//    no per-piece branches); stage pointers are compile-time constants in the unrolled loop so
+//    that the compiler knows DMA targets and fragment reads never alias (it otherwise puts
+//    vmcnt(0) in front of the reads).
+// Restrictions (the launcher falls back to wgrad_taps_kernel): no gather mask, no wrap, full
+// 128-channel dy blocks.
+__global__ void __launch_bounds__(512)
+wgrad_taps3_kernel(const WgradTapsParams p) {
+  typedef uint16_t T;
+  constexpr int YROW = 256, XROW = 128, PC = 34;
+  constexpr int YT = 64 * YROW;              // 16 KiB
+  constexpr int XR = 4 * PC;                 // 136 halo rows
+  constexpr int XPIECES = (XR + 7) / 8;      // 17
+  constexpr int XT = XPIECES * 8 * XROW + 1024;
+  __shared__ __attribute__((aligned(16))) unsigned char stage0[YT + XT];
+  __shared__ __attribute__((aligned(16))) unsigned char stage1[YT + XT];
+  __shared__ __attribute__((aligned(16))) unsigned char stage2[YT + XT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int iw = wave >> 2, cw = wave & 3;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 128;
+  const int split = blockIdx.z;
+  const int st_begin = split * p.steps_per_split;
+  int st_end = st_begin + p.steps_per_split;
+  if (st_end > p.total_steps) st_end = p.total_steps;
+  const int nsteps = st_end > st_begin ? st_end - st_begin : 0;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page_w);
+
+  // ---- LDS-DMA pieces of this wave: lane constants
+  // dy: pieces 2*wave, 2*wave+1 (4 rows x 256 B); x: pieces wave, wave+8 (and 16 on wave 0; 8 rows
+  // x 128 B).  Offsets in elements relative to the step's first pixel.
+  int ya[2], yb[2];
+  int64_t yoff[2];
+  const T* yzero[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 4 + (lane >> 4);
+    ya[j] = r >> 5; yb[j] = r & 31;
+    const int ch = (lane & 15) ^ ((r & 3) << 2);
+    yoff[j] = ((int64_t)ya[j] * p.Wo + yb[j]) * p.Cout + co0 + ch * 8;
+    yzero[j] = zero + ch * 8;
+  }
+  int xa[3], xb[3];
+  int64_t xoff[3];
+  const T* xzero[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int r = (wave + 8 * j) * 8 + (lane >> 3);
+    xa[j] = r / PC; xb[j] = r - xa[j] * PC;
+    if (r >= XR) xa[j] = 1 << 20;   // rows past the halo: always out of bounds
+    const int ch = (lane & 7) ^ ((r & 2) << 1);
+    xoff[j] = ((int64_t)(r >= XR ? 0 : xa[j]) * p.W + xb[j]) * p.Cin + ci0 + ch * 8;
+    xzero[j] = zero + ch * 8;
+  }
+
+  struct StepPos { int img, y0, x0; };
+  StepPos fp;
+  {
+    int t = st_begin;
+    const int sx_i = t % p.steps_x; t /= p.steps_x;
+    const int sy_i = t % p.steps_y;
+    fp.img = t / p.steps_y;
+    fp.y0 = sy_i * 2; fp.x0 = sx_i * 32;
+  }
+  auto advance = [&](StepPos& sp) {
+    sp.x0 += 32;
+    if (sp.x0 >= p.steps_x * 32) {
+      sp.x0 = 0;
+      sp.y0 += 2;
+      if (sp.y0 >= p.steps_y * 2) { sp.y0 = 0; ++sp.img; }
+    }
+  };
+  // all five (four) pieces of one step; `real` is wave-uniform (past the last step nothing is
+  // issued: the waits below are vmcnt(0))
+  auto issue = [&](const StepPos& sp, unsigned char* stg, bool real) {
+    if (!real) return;
+    const T* ybase = p.dy + ((int64_t)(sp.img * p.Ho + sp.y0) * p.Wo + sp.x0) * p.Cout;
+    const T* xbase = p.x + ((int64_t)(sp.img * p.H + sp.y0 - p.pad_t) * p.W + (sp.x0 - p.pad_l)) * p.Cin;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool ok = sp.y0 + ya[j] < p.Ho && sp.x0 + yb[j] < p.Wo;
+      const T* src = ok ? ybase + yoff[j] : yzero[j];
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(stg + (wave * 2 + j) * 4 * YROW), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j == 2 && wave != 0) break;
+      const bool ok = (unsigned)(sp.y0 - p.pad_t + xa[j]) < (unsigned)p.H &&
+                      (unsigned)(sp.x0 - p.pad_l + xb[j]) < (unsigned)p.W;
+      const T* src = ok ? xbase + xoff[j] : xzero[j];
+      __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(stg + YT + (wave + 8 * j) * 8 * XROW), 16,
+                                       0, 0);
+    }
+  };
+
+  f32x16_t acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  issue(fp, stage0, nsteps > 0);
+  advance(fp);
+  issue(fp, stage1, nsteps > 1);
+  advance(fp);
+
+  const int half = lane >> 5, l32 = lane & 31;
+  const int g16 = (lane >> 4) & 1, i16 = lane & 15;
+  const int jrow = i16 >> 2, qcol = i16 & 3;
+  const int ycol = cw * 32 + g16 * 16 + qcol * 4;
+  const int yo = (((ycol >> 3) ^ ((jrow & 3) << 2)) << 4) + ((ycol & 4) << 1);
+  const int xcol = iw * 32 + g16 * 16 + qcol * 4;
+  const int xlo = (xcol & 4) << 1;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_seg;
+  int xlane[2];   // swizzle parity of the halo row (see wgrad_taps_kernel)
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    const int swz = pp ^ ((jrow >> 1) & 1);
+    xlane[pp] = (YT + (half * 8 + jrow) * XROW + ((xcol >> 3) << 4) + xlo) ^ (swz << 6);
+  }
+  const int ylane = (half * 8 + jrow) * YROW + yo;
+
+  auto read_frag = [&](const unsigned char* cur, int kq, uint4& yf, uint2 (&xr)[3][3]) {
+    const int a = kq >> 1;
+    const unsigned char* yp = cur + ylane + (a * 32 + (kq & 1) * 16) * YROW;
+    uint2 v0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)yp));
+    uint2 v1 = __builtin_bit_cast(
+        uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(yp + 4 * YROW)));
+    yf = make_uint4(v0.x, v0.y, v1.x, v1.y);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const unsigned char* xp = cur + xlane[(a + ky) & 1] + ((a + ky) * PC + (kq & 1) * 16) * XROW;
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+        xr[ky][w] = __builtin_bit_cast(
+            uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(xp + w * 4 * XROW)));
+    }
+  };
+  auto mfma9 = [&](const uint4& yf, const uint2 (&xr)[3][3]) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const uint2 v0 = xr[ky][0], v1 = xr[ky][1], v2 = xr[ky][2];
+      const uint4 f0 = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      const uint4 f1 = make_uint4(__builtin_amdgcn_alignbit(v0.y, v0.x, 16),
+                                  __builtin_amdgcn_alignbit(v1.x, v0.y, 16),
+                                  __builtin_amdgcn_alignbit(v1.y, v1.x, 16),
+                                  __builtin_amdgcn_alignbit(v2.x, v1.y, 16));
+      const uint4 f2 = make_uint4(v0.y, v1.x, v1.y, v2.x);
+      acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          __builtin_bit_cast(bf16x8_t, yf), __builtin_bit_cast(bf16x8_t, f0), acc[ky * 3 + 0], 0, 0, 0);
+      acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          __builtin_bit_cast(bf16x8_t, yf), __builtin_bit_cast(bf16x8_t, f1), acc[ky * 3 + 1], 0, 0, 0);
+      acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          __builtin_bit_cast(bf16x8_t, yf), __builtin_bit_cast(bf16x8_t, f2), acc[ky * 3 + 2], 0, 0, 0);
+    }
+  };
+#define TAPS_WAIT_LDS() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                             __builtin_amdgcn_sched_barrier(0); } while (0)
+  uint4 yA, yB;
+  uint2 xA[3][3], xB[3][3];
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): steps 0 and 1 landed
+  __builtin_amdgcn_s_barrier();
+  if (nsteps > 0) read_frag(stage0, 0, yA, xA);
+  // cur: step st, nxt: step st+1, far: held step st-1, receives step st+2
+  auto step = [&](unsigned char* cur, unsigned char* nxt, unsigned char* far, int st) {
+    TAPS_WAIT_LDS();
+    read_frag(cur, 1, yB, xB);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma9(yA, xA);
+    TAPS_WAIT_LDS();
+    read_frag(cur, 2, yA, xA);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma9(yB, xB);
+    TAPS_WAIT_LDS();
+    read_frag(cur, 3, yB, xB);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma9(yA, xA);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of step st+1 landed
+    __builtin_amdgcn_s_barrier();         // ... everyone's did; every wave is done with `far`
+    __builtin_amdgcn_sched_barrier(0);
+    issue(fp, far, st + 2 < nsteps);
+    advance(fp);
+    TAPS_WAIT_LDS();
+    if (st + 1 < nsteps) read_frag(nxt, 0, yA, xA);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma9(yB, xB);
+  };
+#undef TAPS_WAIT_LDS
+  for (int st = 0; st < nsteps; st += 3) {
+    step(stage0, stage1, stage2, st);
+    if (st + 1 < nsteps) step(stage1, stage2, stage0, st + 1);
+    if (st + 2 < nsteps) step(stage2, stage0, stage1, st + 2);
+  }
+
+  // acc[t][r]: ci = ci0 + iw*32 + l32, co = co0 + cw*32 + (r&3) + 8*(r>>2) + 4*half
+  const int64_t K = (int64_t)9 * p.Cin;
+  float* __restrict__ dw = p.dw + (int64_t)split * K * p.Cout;
+  const int ci = ci0 + iw * 32 + l32;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float* row = dw + ((int64_t)t * p.Cin + ci) * p.Cout + co0 + cw * 32 + half * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *reinterpret_cast<float4*>(row + g * 8) =
+          make_float4(acc[t][g * 4], acc[t][g * 4 + 1], acc[t][g * 4 + 2], acc[t][g * 4 + 3]);
+  }
+}
+
 // dy[px][cout] (cout <= 8) -> dst[px][8], zero padded (input of the thin tap-fused wgrad)
 __global__ void __launch_bounds__(256)
 pad_channels8_kernel(const uint16_t* __restrict__ src, int cout, int64_t px,
@@ -3341,7 +3562,11 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
       q.steps_per_split = ceil_div(tsteps, tsplits);
       q.dy_cstride = cout; q.co_valid = cout;
       dim3 tgrid((unsigned)(cin / 64), (unsigned)(cout / 128), (unsigned)tsplits);
-      hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(512), 0, s, q);
+      static const bool taps3 = [] { const char* e = getenv("SE3DS_WGRAD_TAPS3"); return !e || atoi(e) != 0; }();
+      if (taps3 && in_mask == nullptr && !wrap_w)
+        hipLaunchKernelGGL(wgrad_taps3_kernel, tgrid, dim3(512), 0, s, q);
+      else
+        hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(512), 0, s, q);
       const int64_t tnel = (int64_t)9 * cin * cout;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(tnel, 256)), dim3(256), 0, s,
                          (const float*)workspace, tsplits, tnel, accumulate, out_scale, dw);
