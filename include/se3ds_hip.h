@@ -273,6 +273,15 @@ int se3ds_mask_window(const float* mask, int n, int h, int w, int ho, int wo, in
                       int stride, int pad_t, int pad_l, int wrap_w, float* ratio, float* um,
                       float* ru, float* bu, void* stream);
 
+/* se3ds_norm_reduce_rows + se3ds_norm_finalize in one launch for the single-replica batch norm
+ * whose column statistics came out of the producing convolution's epilogue (rows <= 2048 partial
+ * rows of [2][c]); bit-identical to the pair.  Replaces the statistics half of
+ * tf.keras.layers.experimental.SyncBatchNormalization (image_models.py:170-176). */
+int se3ds_norm_reduce_rows_finalize(const float* partial, int64_t rows, int c, float count,
+                                    const float* gamma, const float* beta, float eps, float momentum,
+                                    float* moving_mean, float* moving_var, float* scale, float* shift,
+                                    float* mean, float* rstd, void* stream);
+
 /* ======================================================================================
  * Normalisation: tensors viewed as [g][r][c]; g = 1 for SyncBatchNormalization (279 sites in
  * the generator, e.g. models/layers.py:235-251), g = batch for tfa InstanceNormalization

@@ -271,6 +271,65 @@ norm_finalize_kernel(const float* __restrict__ sums, float count, int G, int C,
   }
 }
 
+// norm_final_reduce_kernel + norm_finalize_kernel in one launch (single replica, one group: the
+// batch norms whose statistics came out of the producing convolution's epilogue -- 309 per step, two
+// launch-latency-bound kernels each).  Same arithmetic in the same order as the pair: binary64 column
+// sums rounded once to fp32, then the fp32 finalize.  Block = COLS channels x LANES partial lanes.
+template <int COLS, int LANES>
+__global__ void __launch_bounds__(256)
+norm_reduce_finalize_kernel(const float* __restrict__ partial, int rblocks, int C, float count,
+                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                            float momentum, float* __restrict__ moving_mean,
+                            float* __restrict__ moving_var, float* __restrict__ scale,
+                            float* __restrict__ shift, float* __restrict__ mean_out,
+                            float* __restrict__ rstd_out) {
+  static_assert(COLS * LANES == 256, "block shape");
+  __shared__ double sh[2][LANES][COLS + 1];
+  const int cl = threadIdx.x % COLS;
+  const int c = blockIdx.x * COLS + cl;
+  const int lane_b = threadIdx.x / COLS;
+  double a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+  if (c < C) {
+    const float* P = partial + c;
+    int b = lane_b;
+    for (; b + 3 * LANES < rblocks; b += 4 * LANES) {
+      a0 += P[(int64_t)b * 2 * C];
+      a1 += P[(int64_t)(b + LANES) * 2 * C];
+      a2 += P[(int64_t)(b + 2 * LANES) * 2 * C];
+      a3 += P[(int64_t)(b + 3 * LANES) * 2 * C];
+      b0 += P[(int64_t)b * 2 * C + C];
+      b1 += P[(int64_t)(b + LANES) * 2 * C + C];
+      b2 += P[(int64_t)(b + 2 * LANES) * 2 * C + C];
+      b3 += P[(int64_t)(b + 3 * LANES) * 2 * C + C];
+    }
+    for (; b < rblocks; b += LANES) {
+      a0 += P[(int64_t)b * 2 * C];
+      b0 += P[(int64_t)b * 2 * C + C];
+    }
+  }
+  sh[0][lane_b][cl] = (a0 + a1) + (a2 + a3);
+  sh[1][lane_b][cl] = (b0 + b1) + (b2 + b3);
+  __syncthreads();
+  if (lane_b == 0 && c < C) {
+    double t1 = 0, t2 = 0;
+#pragma unroll
+    for (int i = 0; i < LANES; ++i) { t1 += sh[0][i][cl]; t2 += sh[1][i][cl]; }
+    const float mean = (float)t1 / count;
+    const float var = (float)t2 / count - mean * mean;
+    if (moving_mean) {
+      moving_mean[c] = moving_mean[c] - (moving_mean[c] - mean) * (1.0f - momentum);
+      moving_var[c] = moving_var[c] - (moving_var[c] - var) * (1.0f - momentum);
+    }
+    float rstd = rsqrtf(var + eps);
+    rstd = rstd * (1.5f - 0.5f * (var + eps) * rstd * rstd);
+    const float inv = rstd * (gamma ? gamma[c] : 1.0f);
+    scale[c] = inv;
+    shift[c] = (beta ? beta[c] : 0.0f) - mean * inv;
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+  }
+}
+
 // Elementwise kernels use the same 2-D thread layout as the statistics kernel: a thread owns
 // VEC consecutive channels (scale/shift/mean/rstd live in registers) and strides over rows, so
 // the inner loop has no integer divisions.  grid = (row blocks, channel tiles, G).
@@ -679,6 +738,23 @@ int se3ds_norm_reduce_rows(const float* partial, int64_t rows, int c, float* sum
                         nullptr, nullptr);
   launch_final_reduce(s, mid, (int)groups, c, 1, sums, nullptr, nullptr);
   return check_launch("norm_reduce_rows");
+}
+
+int se3ds_norm_reduce_rows_finalize(const float* partial, int64_t rows, int c, float count,
+                                    const float* gamma, const float* beta, float eps, float momentum,
+                                    float* moving_mean, float* moving_var, float* scale, float* shift,
+                                    float* mean, float* rstd, void* stream) {
+  if (rows <= 0 || rows > 2048 || c <= 0) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+  if (rows > 32)
+    hipLaunchKernelGGL((norm_reduce_finalize_kernel<8, 32>), dim3((unsigned)ceil_div(c, 8)), dim3(256), 0, s,
+                       partial, (int)rows, c, count, gamma, beta, eps, momentum, moving_mean, moving_var,
+                       scale, shift, mean, rstd);
+  else
+    hipLaunchKernelGGL((norm_reduce_finalize_kernel<32, 8>), dim3((unsigned)ceil_div(c, 32)), dim3(256), 0, s,
+                       partial, (int)rows, c, count, gamma, beta, eps, momentum, moving_mean, moving_var,
+                       scale, shift, mean, rstd);
+  return check_launch("norm_reduce_rows_finalize");
 }
 
 int se3ds_norm_finalize(const float* sums, float count, int g, int c, const float* gamma,

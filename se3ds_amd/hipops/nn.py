@@ -9,6 +9,8 @@ import math
 from typing import List, Optional
 
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -735,6 +737,9 @@ class NormLayer:
       store.add(name + '/moving_variance', (c,), ones_init, trainable=False)
 
 
+_MERGED_BN_STATS = os.environ.get('SE3DS_NORM_MERGED', '1') != '0'
+
+
 def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: Var = None,
              post: Var = None, in_act=None) -> Var:
   """y = act(norm(x) [+ res]) [+ post].  Batch norm uses cross-replica batch statistics when
@@ -765,7 +770,19 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
                                rstd.data_ptr(), _lib.stream()), 'se3ds_norm_finalize')
   else:
     fused = getattr(x, 'col_stats', None)
-    if fused is not None and not inst and fused.shape[2] == c:
+    finalized = False
+    if (fused is not None and not inst and fused.shape[2] == c and ctx.world == 1 and
+        fused.shape[0] <= 2048 and _MERGED_BN_STATS):
+      # statistics came out of the producing convolution's epilogue; single replica: column
+      # reduction and finalize in one launch
+      _chk(L.se3ds_norm_reduce_rows_finalize(
+          fused.data_ptr(), fused.shape[0], c, count, gamma.data_ptr(), beta.data_ptr(), eps,
+          BN_MOMENTUM, st[layer.name + '/moving_mean'].data_ptr(),
+          st[layer.name + '/moving_variance'].data_ptr(), scale.data_ptr(), shift.data_ptr(),
+          mean.data_ptr(), rstd.data_ptr(), _lib.stream()), 'se3ds_norm_reduce_rows_finalize')
+      x.col_stats = None
+      finalized = True
+    elif fused is not None and not inst and fused.shape[2] == c:
       # statistics came out of the producing convolution's epilogue
       sums = torch.empty((1, 2, c), dtype=torch.float32, device=ctx.device)
       ws = ctx.ws('norm', L.se3ds_norm_workspace_bytes(max(1, (fused.shape[0] + 511) // 512), c))
@@ -775,15 +792,16 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
       x.col_stats = None
     else:
       sums = _colsum(ctx, xd.data_ptr(), ctx.code, r, c, groups=g)
-    if not inst and ctx.world > 1:
-      ctx.allreduce_sum(sums)
-      count = float(r * ctx.world)
-    mm = st[layer.name + '/moving_mean'] if not inst else None
-    mv = st[layer.name + '/moving_variance'] if not inst else None
-    _chk(L.se3ds_norm_finalize(sums.data_ptr(), count, g, c, gamma.data_ptr(), beta.data_ptr(),
-                               eps, BN_MOMENTUM, _lib.ptr(mm), _lib.ptr(mv), 0, scale.data_ptr(),
-                               shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _lib.stream()),
-         'se3ds_norm_finalize')
+    if not finalized:
+      if not inst and ctx.world > 1:
+        ctx.allreduce_sum(sums)
+        count = float(r * ctx.world)
+      mm = st[layer.name + '/moving_mean'] if not inst else None
+      mv = st[layer.name + '/moving_variance'] if not inst else None
+      _chk(L.se3ds_norm_finalize(sums.data_ptr(), count, g, c, gamma.data_ptr(), beta.data_ptr(),
+                                 eps, BN_MOMENTUM, _lib.ptr(mm), _lib.ptr(mv), 0, scale.data_ptr(),
+                                 shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _lib.stream()),
+           'se3ds_norm_finalize')
   y = ctx.empty(xd.shape)
   # one "output > 0" bit per element for the backward pass (instead of re-reading y twice)
   amask = None
