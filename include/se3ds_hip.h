@@ -437,6 +437,23 @@ int se3ds_spectral_part_rows(void);
 int se3ds_spectral_vpart_len(void);
 int se3ds_spectral_power_iter(const int64_t* table, int nlayers, int training, void* stream);
 int se3ds_spectral_bwd_fixup(const int64_t* table, int nlayers, void* stream);
+/* The fix-up folded into the clip pass (one read-modify-write of the gradient arena instead of
+ * two, no separate norm pass over the spectral kernels):
+ *   se3ds_spectral_bwd_dots       pass 1 only: <grad,W>, <grad,grad>, <grad, v_hat^T u_hat> into vpart
+ *   se3ds_multi_sqnorm_sn         as se3ds_multi_sqnorm; tensors t with tensor_sn[t] != 0 (address of
+ *                                 their table row) get |fixed grad|^2 in closed form from vpart
+ *   se3ds_multi_clip_by_norm_sn   as se3ds_multi_clip_by_norm; those tensors are fixed up and
+ *                                 clipped in the same pass
+ * tensor_sn: int64[number of tensors], absolute tensor ids as in the chunk rows; tensor_base: id of
+ * the first tensor of tensor_chunk_start / sqnorm (per-segment calls).  Reference semantics:
+ * models/layers.py:299-347 (gradient through sigma), trainers/se3ds_trainer.py:27-32 (clip). */
+int se3ds_spectral_bwd_dots(const int64_t* table, int nlayers, void* stream);
+int se3ds_multi_sqnorm_sn(const float* grads, const int64_t* chunks, int64_t nchunks,
+                          const int64_t* tensor_chunk_start, int ntensors, float* partial,
+                          float* sqnorm, const int64_t* tensor_sn, int tensor_base, void* stream);
+int se3ds_multi_clip_by_norm_sn(float* grads, const int64_t* chunks, int64_t nchunks,
+                                const float* sqnorm, int ntensors, float clip_norm,
+                                float* mean_norm_out, const int64_t* tensor_sn, void* stream);
 
 /* ======================================================================================
  * Input pipeline, device-side half

@@ -16,9 +16,13 @@ constexpr int kB = 256;
 // chunk table: int64 triples (tensor id, start element, length)
 __global__ void __launch_bounds__(kB)
 chunk_sqsum_kernel(const float* __restrict__ g, const int64_t* __restrict__ chunks,
-                   float* __restrict__ partial) {
+                   float* __restrict__ partial, const int64_t* __restrict__ tensor_sn) {
   __shared__ float sh[kB / 64];
   const int64_t start = chunks[blockIdx.x * 3 + 1], len = chunks[blockIdx.x * 3 + 2];
+  if (tensor_sn && tensor_sn[chunks[blockIdx.x * 3]] != 0) {   // (block-uniform)
+    if (threadIdx.x == 0) partial[blockIdx.x] = 0.f;
+    return;
+  }
   float s = 0.f;
   for (int64_t i = threadIdx.x; i < len; i += kB) {
     float v = g[start + i];
@@ -37,8 +41,9 @@ chunk_sqsum_kernel(const float* __restrict__ g, const int64_t* __restrict__ chun
 // tensor_chunk_start: (T+1) prefix of chunk indices per tensor
 __global__ void __launch_bounds__(kB)
 tensor_sqsum_kernel(const float* __restrict__ partial, const int64_t* __restrict__ tensor_chunk_start,
-                    int T, float* __restrict__ sqnorm) {
+                    int T, float* __restrict__ sqnorm, const int64_t* __restrict__ tensor_sn) {
   for (int t = blockIdx.x * kB + threadIdx.x; t < T; t += gridDim.x * kB) {
+    if (tensor_sn && tensor_sn[t] != 0) continue;   // written by sn_sqnorm_kernel
     float s = 0.f;
     for (int64_t c = tensor_chunk_start[t]; c < tensor_chunk_start[t + 1]; ++c) s += partial[c];
     sqnorm[t] = s;
@@ -48,13 +53,40 @@ tensor_sqsum_kernel(const float* __restrict__ partial, const int64_t* __restrict
 // tf.clip_by_norm: (g * clip) / max(l2norm, clip), l2norm = sqrt(sum g^2) (0 if the sum is 0)
 __global__ void __launch_bounds__(kB)
 clip_kernel(float* __restrict__ g, const int64_t* __restrict__ chunks,
-            const float* __restrict__ sqnorm, float clip) {
+            const float* __restrict__ sqnorm, float clip, const int64_t* __restrict__ tensor_sn) {
   const int64_t t = chunks[blockIdx.x * 3], start = chunks[blockIdx.x * 3 + 1],
                 len = chunks[blockIdx.x * 3 + 2];
   const float sq = sqnorm[t];
   const float norm = sq > 0.f ? sqrtf(sq) : sq;
   const float den = fmaxf(norm, clip);
-  for (int64_t i = threadIdx.x; i < len; i += kB) g[start + i] = (g[start + i] * clip) / den;
+  const int64_t* L = tensor_sn ? (const int64_t*)tensor_sn[t] : nullptr;
+  if (L == nullptr) {
+    for (int64_t i = threadIdx.x; i < len; i += kB) g[start + i] = (g[start + i] * clip) / den;
+    return;
+  }
+  // spectral layer whose gradient still is dL/d(W/sigma): the fix-up of sn_fix_kernel
+  // (G := inv*G - inv^2 <G,W> vhat uhat^T) is applied here, in the clip pass (one read-modify-write
+  // of the arena instead of two).  Table fields as in the SN section below.
+  const float* v = (const float*)L[2];
+  const float* uhat = (const float*)L[3];
+  const float* sig = (const float*)L[4];
+  const float* vpart = (const float*)L[6];
+  const int C = (int)L[8];
+  float dot = 0.f;
+  for (int i = 0; i < 64; ++i) dot += vpart[i];   // SN_RB partials of <G, W>
+  const float inv = sig[1];
+  const float coef = inv * inv * dot;
+  const int64_t e0 = (g + start) - (const float*)L[9] + threadIdx.x;   // element of the tensor
+  int64_t k = e0 / C;
+  int c = (int)(e0 - k * C);
+  const int dq = kB / C, dr = kB - dq * C;
+  for (int64_t i = threadIdx.x; i < len; i += kB) {
+    const float f = inv * g[start + i] - coef * v[k] * uhat[c];
+    g[start + i] = (f * clip) / den;
+    k += dq;
+    c += dr;
+    if (c >= C) { c -= C; ++k; }
+  }
 }
 
 // metric: mean over tensors of ||clipped g|| = norm * clip / max(norm, clip)
@@ -265,6 +297,85 @@ sn_fix_kernel(const int64_t* __restrict__ tab) {
   }
 }
 
+// Fused variant of the fix-up (round 2): pass 1 of the backward fix-up with everything the clip
+// pass needs.  Per layer and block: partials of <G,W>, <G,G> and <G, vhat uhat^T>; block 0 also
+// |vhat|^2 and |uhat|^2.  vpart layout: [0,RB) dot, [RB,2RB) gg, [2RB,3RB) gvu, [3RB] |v|^2, [3RB+1] |u|^2.
+// One wave per row of W (rows of C floats are contiguous), no integer division per element.
+__global__ void __launch_bounds__(kB)
+sn_dots_kernel(const int64_t* __restrict__ tab) {
+  const int64_t* L = tab + (int64_t)blockIdx.y * SN_F;
+  const float* W = (const float*)L[0];
+  const float* v = (const float*)L[2];
+  const float* uhat = (const float*)L[3];
+  float* vpart = (float*)L[6];
+  const float* G = (const float*)L[9];
+  const int64_t K = L[7];
+  const int C = (int)L[8];
+  __shared__ float sh[3][kB / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float dot = 0.f, gg = 0.f, gvu = 0.f;
+  for (int64_t k = (int64_t)blockIdx.x * 4 + wave; k < K; k += (int64_t)SN_RB * 4) {
+    const float vk = v[k];
+    float row = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float gv = G[k * C + c];
+      dot += gv * W[k * C + c];
+      gg += gv * gv;
+      row += gv * uhat[c];
+    }
+    gvu += row * vk;
+  }
+  dot = wave_sum(dot);
+  gg = wave_sum(gg);
+  gvu = wave_sum(gvu);
+  if (lane == 0) { sh[0][wave] = dot; sh[1][wave] = gg; sh[2][wave] = gvu; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float* q = sh[threadIdx.x];
+    vpart[threadIdx.x * SN_RB + blockIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
+  }
+  if (blockIdx.x == 0) {
+    __syncthreads();
+    float nv = 0.f, nu = 0.f;
+    for (int64_t k = threadIdx.x; k < K; k += kB) nv += v[k] * v[k];
+    for (int c = threadIdx.x; c < C; c += kB) nu += uhat[c] * uhat[c];
+    nv = wave_sum(nv);
+    nu = wave_sum(nu);
+    if (lane == 0) { sh[0][wave] = nv; sh[1][wave] = nu; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+      const float* q = sh[threadIdx.x];
+      vpart[3 * SN_RB + threadIdx.x] = (q[0] + q[1]) + (q[2] + q[3]);
+    }
+  }
+}
+
+// |inv*G - coef*v u^T|^2 = inv^2 <G,G> - 2 inv coef <G, v u^T> + coef^2 |v|^2 |u|^2, coef = inv^2 <G,W>
+// (combined in binary64: the three terms cancel when G is nearly parallel to v u^T).  One thread
+// per tensor of [tensor_base, tensor_base + T); sqnorm is indexed relative to tensor_base.
+__global__ void __launch_bounds__(kB)
+sn_sqnorm_kernel(const int64_t* __restrict__ tensor_sn, int tensor_base, int T,
+                 float* __restrict__ sqnorm) {
+  for (int t = blockIdx.x * kB + threadIdx.x; t < T; t += gridDim.x * kB) {
+    const int64_t* L = (const int64_t*)tensor_sn[tensor_base + t];
+    if (L == nullptr) continue;
+    const float* sig = (const float*)L[4];
+    const float* vpart = (const float*)L[6];
+    float dot = 0.f;
+    double gg = 0.0, gvu = 0.0;
+    for (int i = 0; i < SN_RB; ++i) {
+      dot += vpart[i];   // (fp32, in the order sn_fix_kernel / clip_kernel use)
+      gg += (double)vpart[SN_RB + i];
+      gvu += (double)vpart[2 * SN_RB + i];
+    }
+    const float inv = sig[1];
+    const float coef = inv * inv * dot;
+    const double nvu = (double)vpart[3 * SN_RB] * (double)vpart[3 * SN_RB + 1];
+    double sq = (double)inv * inv * gg - 2.0 * (double)inv * coef * gvu + (double)coef * coef * nvu;
+    sqnorm[t] = sq > 0.0 ? (float)sq : 0.f;
+  }
+}
+
 }  // namespace
 }  // namespace se3ds
 
@@ -281,25 +392,43 @@ static float adam_alpha(float lr, float beta1, float beta2, int64_t step) {
 
 extern "C" {
 
-int se3ds_multi_sqnorm(const float* grads, const int64_t* chunks, int64_t nchunks,
-                       const int64_t* tensor_chunk_start, int ntensors, float* partial,
-                       float* sqnorm, void* stream) {
+int se3ds_multi_sqnorm_sn(const float* grads, const int64_t* chunks, int64_t nchunks,
+                          const int64_t* tensor_chunk_start, int ntensors, float* partial,
+                          float* sqnorm, const int64_t* tensor_sn, int tensor_base, void* stream) {
   if (nchunks <= 0 || ntensors <= 0) return SE3DS_OK;
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(chunk_sqsum_kernel, dim3((unsigned)nchunks), dim3(kB), 0, s, grads, chunks,
-                     partial);
+                     partial, tensor_sn);
   hipLaunchKernelGGL(tensor_sqsum_kernel, dim3(grid_for(ntensors, kB)), dim3(kB), 0, s, partial,
-                     tensor_chunk_start, ntensors, sqnorm);
+                     tensor_chunk_start, ntensors, sqnorm,
+                     tensor_sn ? tensor_sn + tensor_base : nullptr);
+  if (tensor_sn)
+    hipLaunchKernelGGL(sn_sqnorm_kernel, dim3(grid_for(ntensors, kB)), dim3(kB), 0, s, tensor_sn,
+                       tensor_base, ntensors, sqnorm);
   return check_launch("multi_sqnorm");
+}
+
+int se3ds_multi_sqnorm(const float* grads, const int64_t* chunks, int64_t nchunks,
+                       const int64_t* tensor_chunk_start, int ntensors, float* partial,
+                       float* sqnorm, void* stream) {
+  return se3ds_multi_sqnorm_sn(grads, chunks, nchunks, tensor_chunk_start, ntensors, partial, sqnorm,
+                               nullptr, 0, stream);
 }
 
 int se3ds_multi_clip_by_norm(float* grads, const int64_t* chunks, int64_t nchunks,
                              const float* sqnorm, int ntensors, float clip_norm,
                              float* mean_norm_out, void* stream) {
+  return se3ds_multi_clip_by_norm_sn(grads, chunks, nchunks, sqnorm, ntensors, clip_norm,
+                                     mean_norm_out, nullptr, stream);
+}
+
+int se3ds_multi_clip_by_norm_sn(float* grads, const int64_t* chunks, int64_t nchunks,
+                                const float* sqnorm, int ntensors, float clip_norm,
+                                float* mean_norm_out, const int64_t* tensor_sn, void* stream) {
   if (nchunks <= 0) return SE3DS_OK;
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(clip_kernel, dim3((unsigned)nchunks), dim3(kB), 0, s, grads, chunks, sqnorm,
-                     clip_norm);
+                     clip_norm, tensor_sn);
   if (mean_norm_out)
     hipLaunchKernelGGL(mean_clipped_norm_kernel, dim3(1), dim3(kB), 0, s, sqnorm, ntensors,
                        clip_norm, mean_norm_out);
@@ -361,8 +490,15 @@ int se3ds_spectral_bwd_fixup(const int64_t* table, int nlayers, void* stream) {
   return check_launch("spectral_bwd_fixup");
 }
 
+int se3ds_spectral_bwd_dots(const int64_t* table, int nlayers, void* stream) {
+  if (nlayers <= 0) return SE3DS_OK;
+  hipLaunchKernelGGL(sn_dots_kernel, dim3(SN_RB, (unsigned)nlayers), dim3(kB), 0, as_stream(stream),
+                     table);
+  return check_launch("spectral_bwd_dots");
+}
+
 int se3ds_spectral_table_fields(void) { return SN_F; }
 int se3ds_spectral_part_rows(void) { return SN_KB; }
-int se3ds_spectral_vpart_len(void) { return SN_RB; }
+int se3ds_spectral_vpart_len(void) { return 3 * SN_RB + 2; }
 
 }  // extern "C"

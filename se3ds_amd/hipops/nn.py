@@ -488,10 +488,26 @@ class SpectralGroup:
                                           1 if training else 0, _lib.stream()),
            'se3ds_spectral_power_iter')
 
-  def backward_fixup(self, prefix=None):
+  def tensor_sn(self, store):
+    """int64 [number of trainable tensors]: address of the effective spectral layer's table row
+    for its kernel tensor, 0 elsewhere (se3ds_multi_sqnorm_sn / se3ds_multi_clip_by_norm_sn)."""
+    tab = self.eff_table
+    if tab is None:
+      return None
+    if getattr(self, '_tensor_sn', None) is None:
+      nf = tab.shape[1]
+      index = {n_: t for t, n_ in enumerate(store.trainable_names)}
+      rows = [0] * len(store.trainable_names)
+      for j, i in enumerate(self._eff):
+        rows[index[self.layers[i].name + '/kernel']] = tab.data_ptr() + 8 * nf * j
+      self._tensor_sn = torch.tensor(rows, dtype=torch.int64, device=tab.device)
+    return self._tensor_sn
+
+  def backward_fixup(self, prefix=None, dots_only=False):
     """Only layers that convolve with W/sigma (SpectralConv); PartialSpectralConv computes
     sigma but convolves with the raw kernel (layers.py:189-195).  `prefix` restricts the
-    fix-up to one top-level module (per-segment gradient synchronisation)."""
+    fix-up to one top-level module (per-segment gradient synchronisation).  dots_only: just the
+    reductions; the fix-up itself then happens inside the clip pass (AdamState.clip_*(fused_sn))."""
     tab = self.eff_table
     if tab is None:
       return
@@ -505,6 +521,10 @@ class SpectralGroup:
       tab = cache[prefix]
       if tab is None:
         return
+    if dots_only:
+      _chk(_L().se3ds_spectral_bwd_dots(tab.data_ptr(), tab.shape[0], _lib.stream()),
+           'se3ds_spectral_bwd_dots')
+      return
     _chk(_L().se3ds_spectral_bwd_fixup(tab.data_ptr(), tab.shape[0], _lib.stream()),
          'se3ds_spectral_bwd_fixup')
 

@@ -55,25 +55,35 @@ class AdamState:
     self.sqnorm = torch.empty(len(model.store.trainable_names), dtype=torch.float32, device=dev)
     self.mean_norm = torch.zeros(1, dtype=torch.float32, device=dev)
 
-  def clip_gradients(self, clip_norm=5.0):
+  def _sn_ptr(self, fused_sn):
+    """fused_sn: the model's spectral layers only ran SpectralGroup.backward_fixup(dots_only=True);
+    their fix-up is folded into this clip pass."""
+    if not fused_sn:
+      return None
+    sn = self.model.spectral.tensor_sn(self.model.store)
+    return sn.data_ptr() if sn is not None else None
+
+  def clip_gradients(self, clip_norm=5.0, fused_sn=False):
     """Per-tensor tf.clip_by_norm, in place on the gradient arena (se3ds_trainer.py:27-32)."""
     st = self.model.store
     L = _lib.lib()
     nt = len(st.trainable_names)
-    _lib.check(L.se3ds_multi_sqnorm(st.grad.data_ptr(), self.chunks.data_ptr(),
-                                    self.chunks.shape[0], self.tensor_chunk_start.data_ptr(), nt,
-                                    self.partial.data_ptr(), self.sqnorm.data_ptr(),
-                                    _lib.stream()), 'se3ds_multi_sqnorm')
-    _lib.check(L.se3ds_multi_clip_by_norm(st.grad.data_ptr(), self.chunks.data_ptr(),
-                                          self.chunks.shape[0], self.sqnorm.data_ptr(), nt,
-                                          float(clip_norm), self.mean_norm.data_ptr(),
-                                          _lib.stream()), 'se3ds_multi_clip_by_norm')
+    sn = self._sn_ptr(fused_sn)
+    _lib.check(L.se3ds_multi_sqnorm_sn(st.grad.data_ptr(), self.chunks.data_ptr(),
+                                       self.chunks.shape[0], self.tensor_chunk_start.data_ptr(), nt,
+                                       self.partial.data_ptr(), self.sqnorm.data_ptr(), sn, 0,
+                                       _lib.stream()), 'se3ds_multi_sqnorm_sn')
+    _lib.check(L.se3ds_multi_clip_by_norm_sn(st.grad.data_ptr(), self.chunks.data_ptr(),
+                                             self.chunks.shape[0], self.sqnorm.data_ptr(), nt,
+                                             float(clip_norm), self.mean_norm.data_ptr(), sn,
+                                             _lib.stream()), 'se3ds_multi_clip_by_norm_sn')
     return self.mean_norm
 
-  def clip_segment(self, t0, t1, clip_norm=5.0):
+  def clip_segment(self, t0, t1, clip_norm=5.0, fused_sn=False):
     """clip_gradients restricted to tensors [t0, t1) (per-segment gradient synchronisation)."""
     st = self.model.store
     L = _lib.lib()
+    sn = self._sn_ptr(fused_sn)
     c0, c1 = self._tcs_host[t0], self._tcs_host[t1]
     if c1 <= c0:
       return
@@ -81,15 +91,15 @@ class AdamState:
     if (t0, t1) not in cache:   # chunk prefix of the segment, relative to its first chunk
       cache[(t0, t1)] = (self.tensor_chunk_start[t0:t1 + 1] - c0).contiguous()
     tcs = cache[(t0, t1)]
-    _lib.check(L.se3ds_multi_sqnorm(st.grad.data_ptr(), self.chunks.data_ptr() + 24 * c0, c1 - c0,
-                                    tcs.data_ptr(), t1 - t0, self.partial.data_ptr(),
-                                    self.sqnorm.data_ptr() + 4 * t0, _lib.stream()),
-               'se3ds_multi_sqnorm')
+    _lib.check(L.se3ds_multi_sqnorm_sn(st.grad.data_ptr(), self.chunks.data_ptr() + 24 * c0, c1 - c0,
+                                       tcs.data_ptr(), t1 - t0, self.partial.data_ptr(),
+                                       self.sqnorm.data_ptr() + 4 * t0, sn, t0, _lib.stream()),
+               'se3ds_multi_sqnorm_sn')
     # chunk rows carry absolute tensor ids: sqnorm is passed from its base
-    _lib.check(L.se3ds_multi_clip_by_norm(st.grad.data_ptr(), self.chunks.data_ptr() + 24 * c0,
-                                          c1 - c0, self.sqnorm.data_ptr(), t1 - t0,
-                                          float(clip_norm), None, _lib.stream()),
-               'se3ds_multi_clip_by_norm')
+    _lib.check(L.se3ds_multi_clip_by_norm_sn(st.grad.data_ptr(), self.chunks.data_ptr() + 24 * c0,
+                                             c1 - c0, self.sqnorm.data_ptr(), t1 - t0,
+                                             float(clip_norm), None, sn, _lib.stream()),
+               'se3ds_multi_clip_by_norm_sn')
 
   def mean_clipped_norm(self, clip_norm=5.0):
     _lib.check(_lib.lib().se3ds_mean_clipped_norm(

@@ -26,6 +26,8 @@ from se3ds_amd.trainers import dist_utils
 from se3ds_amd.trainers import gan_manager
 from se3ds_amd.trainers.gan_manager import Mean
 
+# the generator's spectral gradient fix-up rides on the clip pass (SE3DS_FUSED_SN_CLIP=0: separate passes)
+FUSED_SN_CLIP = os.environ.get('SE3DS_FUSED_SN_CLIP', '1') != '0'
 GRAD_CLIP_NORM = 5.0   # _clip_grad default, reference :27
 
 
@@ -255,8 +257,8 @@ class GAN(gan_manager.GANManager):
     ema_theta, ema_omd = self.ema_fused_args()   # EMA of the trainable variables rides on Adam
     if sync is None:
       ctx_g.backward()
-      G.spectral.backward_fixup()
-      g_norm = self.g_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
+      G.spectral.backward_fixup(dots_only=FUSED_SN_CLIP)
+      g_norm = self.g_optimizer.clip_gradients(GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP).clone()
       d_norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
       self.g_optimizer.apply_gradients(group, R, ema_theta, ema_omd)
       self.d_optimizer.apply_gradients(group, R)
@@ -267,8 +269,8 @@ class GAN(gan_manager.GANManager):
         if name not in self._g_segments:
           return
         t0, t1, e0, e1 = self._g_segments[name]
-        G.spectral.backward_fixup(prefix=G.SEGMENTS[name])
-        self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM)
+        G.spectral.backward_fixup(prefix=G.SEGMENTS[name], dots_only=FUSED_SN_CLIP)
+        self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP)
         sync.reduce_range(G.store.grad, e0, e1)
       ctx_g.on_segment = segment_done
       ctx_g.backward()

@@ -882,3 +882,55 @@ def test_adam_and_ema_recurrences_vs_oracle(num_batched_steps, steps):
       assert close(gan.ema_generator.store[k].cpu(), v), (step, k)
     if gs >= num_batched_steps:   # decay phase: the average lags the weights
       assert not torch.equal(gan.ema_generator.store.theta, G.store.theta)
+
+
+def test_fused_spectral_fixup_clip_matches_separate_passes():
+  """The generator's spectral fix-up folded into the clip pass (se3ds_spectral_bwd_dots +
+  se3ds_multi_sqnorm_sn + se3ds_multi_clip_by_norm_sn) against the separate passes
+  (se3ds_spectral_bwd_fixup, then sqnorm + clip) on the same gradient arena: whole arena and
+  per-segment, clip both active (large gradients) and inactive (small)."""
+  gan = _make_gan(64, 8, '50', 3)
+  G, opt = gan.generator, gan.g_optimizer
+  st = G.store
+  st.grad_views   # allocates the arena
+  ctx = G.make_ctx(True, record=False)
+  G.spectral.power_iteration(training=True)   # sigma, v_hat, u_hat of every layer
+  gen = torch.Generator(device=DEV).manual_seed(5)
+  for scale in (10.0, 1e-3):
+    g0 = torch.randn(st.grad.shape, generator=gen, device=DEV) * scale
+    # One spectral gradient dominated by its v u^T component: the fixed gradient is then a small
+    # difference of large terms -- in the separate passes element by element, in the fused pass in
+    # the closed-form norm.  Both carry the fp32 rounding of coef = <G,W>/(sigma+eps)^2 amplified
+    # by |G/sigma|^2 / |fixed|^2 (~1e3 here), so this tensor's norm is compared at 1e-3.
+    name = next(n_ for n_ in st.trainable_names if n_.endswith('/kernel') and 'deconv' in n_)
+    lay = next(l for l in G.spectral.layers if l.name + '/kernel' == name)
+    t_adv = st.trainable_names.index(name)
+    o, n_, shape = st._off_tr[name]
+    outer = (lay.sn['v'][:, None] * lay.sn['uhat'][None, :]).reshape(-1)
+    g0[o:o + n_] = outer * (30.0 * scale * float(n_) ** 0.5) + g0[o:o + n_]
+    st.grad.copy_(g0)
+    G.spectral.backward_fixup()
+    norm_a = opt.clip_gradients(5.0).clone()
+    ref, sq_ref = st.grad.clone(), opt.sqnorm.clone()
+    st.grad.copy_(g0)
+    G.spectral.backward_fixup(dots_only=True)
+    norm_b = opt.clip_gradients(5.0, fused_sn=True).clone()
+    got, sq = st.grad.clone(), opt.sqnorm.clone()
+    tol = 1e-5 * float(ref.abs().max())   # (the dominated tensor: rounding of coef, see above)
+    assert float((got - ref).abs().max()) <= tol, (scale, float((got - ref).abs().max()), tol)
+    rel = ((sq - sq_ref).abs() / sq_ref.clamp_min(1e-30)).cpu()
+    assert float(rel[t_adv]) < 1e-3, (scale, float(rel[t_adv]))
+    rel[t_adv] = 0
+    assert float(rel.max()) < 5e-5, (scale, float(rel.max()), int(rel.argmax()))
+    assert abs(float(norm_a) - float(norm_b)) <= 1e-5 * abs(float(norm_a))
+    # per-segment form
+    st.grad.copy_(g0)
+    segments = st.segments(G.SEGMENTS)
+    assert sum(t1 - t0 for t0, t1, _, _ in segments.values()) == len(st.trainable_names)
+    for seg, (t0, t1, e0, e1) in segments.items():
+      G.spectral.backward_fixup(prefix=G.SEGMENTS[seg], dots_only=True)
+      opt.clip_segment(t0, t1, 5.0, fused_sn=True)
+    assert float((st.grad - ref).abs().max()) <= tol, ('segments', scale)
+    rel = ((opt.sqnorm - sq_ref).abs() / sq_ref.clamp_min(1e-30)).cpu()
+    rel[t_adv] = 0
+    assert float(rel.max()) < 5e-5, ('segments', scale, float(rel.max()))
