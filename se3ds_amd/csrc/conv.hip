@@ -1633,11 +1633,40 @@ wgrad_glds_kernel(const WgradParams p) {
     pox[j] = rem - poy[j] * p.Wo;
   }
 
-  // Per-slot running state (all 32-bit): pixel coordinates and the linear index of the
-  // un-shifted pixel; the tap shift and the bounds test are a few adds / compares per step.
+  // Per-slot running state (all 32-bit): pixel coordinates of the slot's row, advanced by BL
+  // pixels per step without loops (BL = adv_y rows + adv_x columns), and -- one step AHEAD --
+  // the gathered pixel's index, its bounds flag and its mask value: the mask load is issued
+  // right behind a step's LDS-DMA and is consumed a step later, when those DMAs have landed
+  // anyway (a load + wait inside the issue path made every step pay a memory latency:
+  // measured 97 us against 74 us without mask on the 1x1 2048->512 @32x64 layer).
+  // 1x1 / stride 1 / no padding (`lin`): gathered pixel == output pixel, no coordinates at all.
   const int dyoff = ky - p.pad_t, dxoff = kx - p.pad_l;
   const int st_ = p.stride;
   const int l_end_rel = (int)(l_end - l_begin);
+  const bool lin = p.kh == 1 && p.kw == 1 && p.stride == 1 && p.pad_t == 0 && p.pad_l == 0;
+  const int adv_y = BL / p.Wo, adv_x = BL - adv_y * p.Wo;
+  int pixn[NI];
+  bool okn[NI];
+  float mnext[NI];
+  auto look_ahead = [&](int st) {   // pixel / bounds / mask of step `st` at the current coordinates
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int lrel = st * BL + srow[j];
+      bool ok = xc_ok[j] && lrel < l_end_rel;
+      int pix;
+      if (lin) {
+        pix = (int)l_begin + lrel;
+      } else {
+        int sy = poy[j] * st_ + dyoff, sx = pox[j] * st_ + dxoff;
+        if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
+        ok = ok && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+        pix = (pn[j] * p.H + sy) * p.W + sx;
+      }
+      pixn[j] = pix;
+      okn[j] = ok;
+      mnext[j] = (p.src_mask && ok) ? p.src_mask[pix] : 1.0f;
+    }
+  };
   auto issue = [&](int st, unsigned char* xt) {
     unsigned char* yt = xt + TILE;
 #pragma unroll
@@ -1645,25 +1674,23 @@ wgrad_glds_kernel(const WgradParams p) {
       const int lrel = st * BL + srow[j];
       const T* xs = zero + lch[j] * EPC;
       const T* ys = xs;
-      if (lrel < l_end_rel) {
-        int sy = poy[j] * st_ + dyoff, sx = pox[j] * st_ + dxoff;
-        if (p.wrap_w) sx = sx < 0 ? sx + p.W : (sx >= p.W ? sx - p.W : sx);
-        if (xc_ok[j] && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W) {
-          const int pix = (pn[j] * p.H + sy) * p.W + sx;
-          if (!(p.src_mask && p.src_mask[pix] == 0.0f))
-            xs = x + (int64_t)pix * p.Cin + ci0 + lch[j] * EPC;
-        }
-        if (yc_ok[j]) ys = dy + (l_begin + lrel) * p.Cout + co0 + lch[j] * EPC;
-      }
+      if (okn[j] && mnext[j] != 0.0f) xs = x + (int64_t)pixn[j] * p.Cin + ci0 + lch[j] * EPC;
+      if (yc_ok[j] && lrel < l_end_rel) ys = dy + (l_begin + lrel) * p.Cout + co0 + lch[j] * EPC;
       const int slab = (j * 4 + wave) * RPI * ROWBYTES;   // wave-uniform
       __builtin_amdgcn_global_load_lds((gas_ptr)xs, (las_ptr)(xt + slab), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gas_ptr)ys, (las_ptr)(yt + slab), 16, 0, 0);
-      pox[j] += BL;
-      while (pox[j] >= p.Wo) {
-        pox[j] -= p.Wo;
-        if (++poy[j] == p.Ho) { poy[j] = 0; ++pn[j]; }
+      if (!lin) {
+        pox[j] += adv_x;
+        poy[j] += adv_y;
+        if (pox[j] >= p.Wo) { pox[j] -= p.Wo; ++poy[j]; }
+        if (poy[j] >= p.Ho) {
+          const int t = poy[j] / p.Ho;
+          pn[j] += t;
+          poy[j] -= t * p.Ho;
+        }
       }
     }
+    look_ahead(st + 1);
   };
 
   f32x16_t acc[2][2];
@@ -1674,6 +1701,7 @@ wgrad_glds_kernel(const WgradParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  look_ahead(0);
   if (nsteps > 0) issue(0, stage0);
   __syncthreads();
   const int half = lane >> 5, l32 = lane & 31;

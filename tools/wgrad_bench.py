@@ -17,9 +17,13 @@ dw = torch.zeros((k, k, cin, cout), device=DEV)
 wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, h, w, cin, cout, k, k)
 ws = torch.empty(wsz, dtype=torch.uint8, device=DEV)
 stream = torch.cuda.current_stream().cuda_stream
+mask = None
+if os.environ.get('MASK'):
+  mask = (torch.rand((n, h, w), device=DEV) > 0.3).float()
 def run():
   rc = L.se3ds_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 3, n, h, w, cin, h, w, cout, k, k, 1,
-                            pad, pad, 0, None, 0, None, None, 0, ws.data_ptr(), wsz, stream)
+                            pad, pad, 0, mask.data_ptr() if mask is not None else None, 1 if mask is not None else 0,
+                            None, None, 0, ws.data_ptr(), wsz, stream)
   assert rc == 0, rc
 for _ in range(10):
   run()
@@ -33,4 +37,4 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / iters
 fl = 2.0 * k * k * cin * cout * n * h * w
-print(f'wgrad {cin}->{cout} k{k} @{h}x{w} n{n}: {us:.1f} us  {fl / us * 1e-6:.0f} TFLOP/s  dbg={os.environ.get("SE3DS_TAPS_DBG", "0")}')
+print(f'wgrad {cin}->{cout} k{k} @{h}x{w} n{n}: {us:.1f} us  {fl / us * 1e-6:.0f} TFLOP/s  mask={int(mask is not None)}')
