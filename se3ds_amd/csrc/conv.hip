@@ -2152,6 +2152,18 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
   };
   // all five (four) pieces of one step; `real` is wave-uniform (past the last step nothing is
   // issued: the waits below are vmcnt(0))
+  // binary gather mask (partial convs): the three mask values of a step are loaded one issue
+  // AHEAD, right behind the previous step's LDS-DMA, and are in registers when they are needed
+  float mxn[3] = {1.0f, 1.0f, 1.0f};
+  auto mask_ahead = [&](const StepPos& sp, bool real) {
+    if (p.src_mask == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int sy = sp.y0 - p.pad_t + xa[j], sx = sp.x0 - p.pad_l + xb[j];
+      const bool ok = real && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
+      mxn[j] = ok ? p.src_mask[(sp.img * p.H + sy) * p.W + sx] : 1.0f;
+    }
+  };
   auto issue = [&](const StepPos& sp, unsigned char* stg, bool real) {
     if (!real) return;
     const T* ybase = p.dy + ((int64_t)(sp.img * p.Ho + sp.y0) * p.Wo + sp.x0) * p.Cout;
@@ -2166,7 +2178,7 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
     for (int j = 0; j < 3; ++j) {
       if (j == 2 && wave != 0) break;
       const bool ok = (unsigned)(sp.y0 - p.pad_t + xa[j]) < (unsigned)p.H &&
-                      (unsigned)(sp.x0 - p.pad_l + xb[j]) < (unsigned)p.W;
+                      (unsigned)(sp.x0 - p.pad_l + xb[j]) < (unsigned)p.W && mxn[j] != 0.0f;
       const T* src = ok ? xbase + xoff[j] : xzero[j];
       __builtin_amdgcn_global_load_lds((gas_ptr)src, (las_ptr)(stg + YT + (wave + 8 * j) * 8 * XROW), 16,
                                        0, 0);
@@ -2179,10 +2191,13 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+  mask_ahead(fp, nsteps > 0);
   issue(fp, stage0, nsteps > 0);
   advance(fp);
+  mask_ahead(fp, nsteps > 1);
   issue(fp, stage1, nsteps > 1);
   advance(fp);
+  mask_ahead(fp, nsteps > 2);
 
   const int half = lane >> 5, l32 = lane & 31;
   const int g16 = (lane >> 4) & 1, i16 = lane & 15;
@@ -2261,6 +2276,7 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
     __builtin_amdgcn_sched_barrier(0);
     issue(fp, far, st + 2 < nsteps);
     advance(fp);
+    mask_ahead(fp, st + 3 < nsteps);
     TAPS_WAIT_LDS();
     if (st + 1 < nsteps) read_frag(nxt, 0, yA, xA);
     __builtin_amdgcn_sched_barrier(0);
@@ -3591,7 +3607,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
       q.dy_cstride = cout; q.co_valid = cout;
       dim3 tgrid((unsigned)(cin / 64), (unsigned)(cout / 128), (unsigned)tsplits);
       static const bool taps3 = [] { const char* e = getenv("SE3DS_WGRAD_TAPS3"); return !e || atoi(e) != 0; }();
-      if (taps3 && in_mask == nullptr && !wrap_w)
+      if (taps3 && !wrap_w)
         hipLaunchKernelGGL(wgrad_taps3_kernel, tgrid, dim3(512), 0, s, q);
       else
         hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(512), 0, s, q);
