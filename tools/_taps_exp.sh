@@ -1,7 +1,7 @@
-cd $GRAFT_REPO_ROOT
-for M in "" 1; do
-MASK=$M python tools/wgrad_bench.py 512 512 3 32 64 8 2>/dev/null | tail -1
-MASK=$M python tools/wgrad_bench.py 1024 1024 3 32 64 8 2>/dev/null | tail -1
-MASK=$M python tools/wgrad_bench.py 256 256 3 64 128 8 2>/dev/null | tail -1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for D in 0 1 2 4 8 16 31; do
+rm -rf gpurun_out/pw; SE3DS_COUNT_DBG=$D rocprofv3 --kernel-trace --stats -d gpurun_out/pw -o w -- python bench.py --workload warp --steps 100 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
+python tools/rocpd_summary.py gpurun_out/pw/w_results.db gpurun_out/pw.csv x > /dev/null 2>&1
+echo "DBG=$D $(grep -E 'count_kernel|scatter_kernel|resolve_kernel' gpurun_out/pw.csv | sed -E 's/.*(splat_[a-z_]+kernel).*\)",([0-9]+),([0-9.]+),([0-9.]+),.*/\1 \4/' | tr '\n' ' ')"
 done
-timeout 900 python -m pytest tests/test_prod_shapes_gpu.py -q -x -k "conv and bf16 and (partial or 3x3)" 2>&1 | tail -3
+rm -rf gpurun_out/pw gpurun_out/pw.csv
