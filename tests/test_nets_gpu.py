@@ -363,20 +363,13 @@ ACC_FACTOR = 5.0
 
 
 def close_to_f64(hip, o32, r64, what):
-  """HIP fp32 result is as accurate as the fp32 oracle (both measured against fp64), or --
-  for tensors where the toy configuration amplifies fp32 noise beyond that -- points the same
-  way (cosine >= 0.999) with a bounded max error."""
+  """HIP fp32 result is within 1e-3 of the fp32 oracle, or as accurate as the fp32 oracle when
+  both are measured against fp64 (factor ACC_FACTOR, + 1e-3).  No cosine fallback: a tensor that
+  misses both bars fails."""
+  e_direct = rel_err(hip, o32)
   e_hip, e_o32 = rel_err(hip, r64), rel_err(o32, r64)
-  if e_hip <= ACC_FACTOR * e_o32 + 1e-3:
-    return e_hip, e_o32
-  a, b = np.asarray(hip, np.float64).ravel(), np.asarray(r64, np.float64).ravel()
-  cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
-  assert cos >= 0.99 and e_hip <= 0.2, (what, e_hip, e_o32, cos)
-  FALLBACKS.append(what)
+  assert e_direct <= 1e-3 or e_hip <= ACC_FACTOR * e_o32 + 1e-3, (what, e_direct, e_hip, e_o32)
   return e_hip, e_o32
-
-
-FALLBACKS = []
 
 
 @pytest.mark.parametrize('size,version,context,training', [
@@ -561,6 +554,12 @@ def test_train_g_d_gradients_and_update_fp32():
     e_hip, e_o32 = (num_h / den) ** 0.5, (num_o / den) ** 0.5
     print(f'{tag}: ||grad - f64|| / ||f64||: hip {e_hip:.3e}, fp32 oracle {e_o32:.3e}')
     assert e_hip <= ACC_FACTOR * e_o32 + 1e-3, (tag, e_hip, e_o32)
+  # the discriminator has no batch statistics (instance norm): every one of its tensors is held
+  # to the per-tensor bar (1e-3 of the fp32 oracle, or the fp64 yardstick), no fallback
+  for k in ref['d_grads']:
+    r64 = ref64['d_grads'][k].numpy()
+    if float(np.abs(r64).max()) >= 1e-7:
+      close_to_f64(captured['d'][k], ref['d_grads'][k].numpy(), r64, 'd/' + k)
   # Adam (Keras form), applied to the gradients the step actually used
   for tag, opt, lr, p0 in (('g', gan.g_optimizer, 1e-4, gp), ('d', gan.d_optimizer, 4e-4, dp)):
     names = list(captured[tag])
