@@ -2,8 +2,10 @@
 
 Tolerances (north_star: "generator activations and grads within 1e-3 rel fp32"):
   fp32 path  : max |a-b| <= 1e-3 * max|b| per tensor (most tensors are ~1e-5)
-  bf16 path  : 3e-2 * max|b| (bf16 has 8 mantissa bits; operands are rounded to bf16, the
-               accumulation is fp32)
+  bf16 path  : 1e-2 * max|b| (bf16 has 8 mantissa bits; operands are rounded to bf16, the
+               accumulation is fp32; the suite also passes at 6e-3 -- SE3DS_TEST_BF16_TOL overrides).
+               The per-output-type bars (fp32-stored outputs of the bf16 path 1e-4, bf16-stored
+               6e-3) are in test_prod_shapes_gpu.py, on bf16-representable inputs.
 """
 import os
 
@@ -28,7 +30,7 @@ def rel_err(a, b):
 
 
 def tol(dtype):
-  return 1e-3 if dtype == torch.float32 else 3e-2
+  return 1e-3 if dtype == torch.float32 else float(os.environ.get('SE3DS_TEST_BF16_TOL', '1e-2'))
 
 
 def to_dev(x, dtype):
