@@ -257,6 +257,9 @@ class Ctx:
   def allreduce_sum(self, t):
     if self.world > 1:
       dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+      cb = getattr(self, 'after_collective', None)
+      if cb is not None:
+        cb()   # (GradSync.pump: one pending gradient bucket goes out behind this collective)
 
 
 _WS = {}

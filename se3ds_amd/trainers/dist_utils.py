@@ -8,6 +8,7 @@ import torch
 import torch.distributed as dist
 
 GRAD_BUCKET_ELEMS = 64 * 1024 * 1024   # 256 MiB fp32 per all-reduce: large messages for xGMI rings
+DRIP_BUCKET_ELEMS = 16 * 1024 * 1024   # 64 MiB: drip-fed behind SyncBN collectives (GradSync)
 
 
 def world_size(group=None):
@@ -47,25 +48,51 @@ class GradSync:
   parameter gradients are final (and clipped, per replica and per tensor, as the reference does
   before aggregation) its slice of the flat gradient arena is all-reduced on a side HIP stream
   while the main stream keeps running backward kernels.  `finish()` joins the streams before
-  the optimiser reads the arena."""
+  the optimiser reads the arena.
 
-  def __init__(self, device, group=None, bucket_elems: int = GRAD_BUCKET_ELEMS):
+  PyTorch runs the collectives of one process group FIFO on that group's RCCL stream.  On the
+  SHARED communicator (the default) a module's whole slice, handed over at once, would sit in
+  front of the next SyncBN sum the backward pass needs and the overlap would be lost; so the slice
+  is cut into buckets that are DRIP-FED: one right away, one more behind every SyncBN collective
+  of the continuing backward pass (`pump`, wired to `Ctx.after_collective`), the rest at
+  `finish()`.  A SyncBN sum then waits for at most one bucket (64 MiB: ~0.3 ms on an 8-GPU xGMI
+  ring) that had the preceding layer's backward kernels to overlap with.  With its own
+  communicator (`SE3DS_GRAD_SYNC_OWN_COMM=1`) nothing queues behind the buckets and `drip` is
+  off: large buckets go out at once."""
+
+  def __init__(self, device, group=None, bucket_elems: int = None, drip: bool = True):
     self.device = torch.device(device)
     self.group = group
+    self.drip = drip
+    if bucket_elems is None:
+      bucket_elems = DRIP_BUCKET_ELEMS if drip else GRAD_BUCKET_ELEMS
     self.bucket = bucket_elems
     self.side = torch.cuda.Stream(device=self.device)
-    self.launched = []   # (e0, e1) ranges handed to the side stream this step (for tests)
+    self.pending = []    # (arena, o, n, ready event) not yet on the side stream
+    self.launched = []   # (e0, e1) ranges handed over this step (for tests)
+
+  def _issue(self, arena, o, n, ready):
+    with torch.cuda.stream(self.side):
+      self.side.wait_event(ready)
+      if world_size(self.group) > 1:
+        dist.all_reduce(arena[o:o + n], op=dist.ReduceOp.SUM, group=self.group)
 
   def reduce_range(self, arena: torch.Tensor, e0: int, e1: int):
     ready = torch.cuda.Event()
     ready.record()   # on the main stream: the slice is clipped and final
-    with torch.cuda.stream(self.side):
-      self.side.wait_event(ready)
-      if world_size(self.group) > 1:
-        for o in range(e0, e1, self.bucket):
-          dist.all_reduce(arena[o:min(o + self.bucket, e1)], op=dist.ReduceOp.SUM, group=self.group)
+    for o in range(e0, e1, self.bucket):
+      self.pending.append((arena, o, min(self.bucket, e1 - o), ready))
     self.launched.append((e0, e1))
+    self.pump(1 if self.drip else len(self.pending))
+
+  def pump(self, k: int = 1):
+    """Moves up to k pending buckets onto the side stream (called behind every SyncBN
+    collective while gradients are pending)."""
+    while k > 0 and self.pending:
+      self._issue(*self.pending.pop(0))
+      k -= 1
 
   def finish(self):
+    self.pump(len(self.pending))
     torch.cuda.current_stream(self.device).wait_stream(self.side)
     self.launched = []

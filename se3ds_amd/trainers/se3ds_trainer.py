@@ -113,7 +113,8 @@ class GAN(gan_manager.GANManager):
     if getattr(self, '_sync', None) is None:
       G = self.generator
       group = self.strategy.group
-      if R > 1 and os.environ.get('SE3DS_GRAD_SYNC_OWN_COMM') == '1':
+      own = R > 1 and os.environ.get('SE3DS_GRAD_SYNC_OWN_COMM') == '1'
+      if own:
         # opt-in: a second communicator keeps the 4.5 GB of gradient traffic from queueing ahead
         # of the small SyncBN statistics all-reduces the backward pass waits on.  Two RCCL
         # communicators in flight on one device are only safe when every rank issues them in the
@@ -126,7 +127,8 @@ class GAN(gan_manager.GANManager):
         warm = torch.zeros(1, dtype=torch.float32, device=G.store.theta.device)
         torch.distributed.all_reduce(warm, group=group)
         torch.cuda.synchronize(G.store.theta.device)
-      self._sync = dist_utils.GradSync(G.store.theta.device, group)
+      # shared communicator: buckets are drip-fed behind the SyncBN collectives (GradSync)
+      self._sync = dist_utils.GradSync(G.store.theta.device, group, drip=not own)
       self._g_segments = G.store.segments(G.SEGMENTS)
       covered = sum(t1 - t0 for t0, t1, _, _ in self._g_segments.values())
       assert covered == len(G.store.trainable_names), 'generator segments miss some tensors'
@@ -273,8 +275,10 @@ class GAN(gan_manager.GANManager):
         self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP)
         sync.reduce_range(G.store.grad, e0, e1)
       ctx_g.on_segment = segment_done
+      ctx_g.after_collective = sync.pump
       ctx_g.backward()
       ctx_g.on_segment = None
+      ctx_g.after_collective = None
       g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
       sync.finish()
       self.g_optimizer.apply_gradients(group, 1, ema_theta, ema_omd)

@@ -50,11 +50,19 @@ def test_rccl_single_rank_api_paths():
   """The real `nccl` (= RCCL) backend with one rank: every collective shape of the multi-GPU step
   is accepted (the 8-GPU run itself is the driver's)."""
   env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
-  r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_rccl_worker.py'),
-                      str(_free_port())], env=env, cwd=ROOT, capture_output=True, text=True,
-                     timeout=240)
-  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-  assert 'RCCL_OK' in r.stdout
+  outs = []
+  for attempt in range(2):   # one retry: communicator set-up on a fresh box failed once in ~15 runs
+    try:
+      r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', '_rccl_worker.py'),
+                          str(_free_port())], env=env, cwd=ROOT, capture_output=True, text=True,
+                         timeout=240)
+    except subprocess.TimeoutExpired as e:
+      outs.append('timeout: ' + str(e.stdout)[-1500:] + str(e.stderr)[-3000:])
+      continue
+    if r.returncode == 0 and 'RCCL_OK' in r.stdout:
+      return
+    outs.append(r.stdout[-1500:] + r.stderr[-3000:])
+  pytest.fail('RCCL single-rank worker failed twice:\n' + '\n----\n'.join(outs))
 
 
 def _run_bench(args, env_extra, timeout=600):
