@@ -935,3 +935,31 @@ def test_fused_spectral_fixup_clip_matches_separate_passes():
     rel = ((opt.sqnorm - sq_ref).abs() / sq_ref.clamp_min(1e-30)).cpu()
     rel[t_adv] = 0
     assert float(rel.max()) < 5e-5, ('segments', scale, float(rel.max()))
+
+
+def test_grad_sync_drip_feeds_buckets():
+  """GradSync on the shared communicator: a slice is cut into buckets, the first goes to the side
+  stream at once, one more per pump() (wired behind every SyncBN collective), the rest at
+  finish(); without drip everything is issued by reduce_range."""
+  from se3ds_amd.trainers import dist_utils
+  arena = torch.randn(10 * 1024 + 3, device=DEV)
+  ref = arena.clone()
+  sync = dist_utils.GradSync(DEV, None, bucket_elems=1024, drip=True)
+  sync.reduce_range(arena, 5, arena.numel())
+  n_buckets = -(-(arena.numel() - 5) // 1024)
+  assert len(sync.pending) == n_buckets - 1
+  sync.pump()
+  sync.pump(2)
+  assert len(sync.pending) == n_buckets - 4
+  sync.reduce_range(arena, 0, 5)          # a later slice queues behind the pending buckets
+  assert len(sync.pending) == n_buckets - 4   # (one bucket issued, the new one appended)
+  sync.finish()
+  assert not sync.pending and not sync.launched
+  torch.cuda.synchronize()
+  assert torch.equal(arena, ref)          # world size 1: the collective is skipped
+  sync = dist_utils.GradSync(DEV, None, bucket_elems=1024, drip=False)
+  sync.reduce_range(arena, 0, arena.numel())
+  assert not sync.pending
+  sync.finish()
+  assert dist_utils.GradSync(DEV, None).bucket == dist_utils.DRIP_BUCKET_ELEMS
+  assert dist_utils.GradSync(DEV, None, drip=False).bucket == dist_utils.GRAD_BUCKET_ELEMS
