@@ -114,6 +114,37 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
         }
       }
     }
+  } else if (cok && MODE == 0 && VEC == 8 && sizeof(T) == 2) {
+    // forward statistics / (row-scaled) column sums, bf16: four rows per iteration, raw loads first
+    // (bias-gradient sums of the partial convs and instance-norm statistics: ~170 launches per
+    // step that ran one row at a time at ~1 TB/s)
+    constexpr int NR = 4;
+    const uint16_t* A = (const uint16_t*)a;
+    for (int64_t r = r_lo + ty; r < r_hi; r += (int64_t)NR * ry) {
+      uint4 qa[NR];
+      float rsc[NR];
+      bool ok[NR];
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        ok[u] = r + (int64_t)u * ry < r_hi;
+        const int64_t row = (int64_t)g * R + (ok[u] ? r + (int64_t)u * ry : r);
+        qa[u] = ld16(A + row * C + c0);
+        rsc[u] = row_scale ? row_scale[row] : 1.0f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        if (!ok[u]) continue;
+        float av[8];
+        unpack8(qa[u], av);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const ACC v = (ACC)(av[e] * rsc[u]);
+          s0[e] += v;
+          s1[e] += v * v;
+        }
+      }
+    }
   } else if (cok) {
     for (int64_t r = r_lo + ty; r < r_hi; r += ry) {
       const int64_t off = ((int64_t)g * R + r) * C + c0;
