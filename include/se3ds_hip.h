@@ -282,6 +282,16 @@ int se3ds_norm_reduce_rows_finalize(const float* partial, int64_t rows, int c, f
                                     float* moving_mean, float* moving_var, float* scale, float* shift,
                                     float* mean, float* rstd, void* stream);
 
+/* One pass over dy [r][c] (bf16, c % 8 == 0) for the backward of a partial convolution with bias:
+ * scaled_out = dy * out_row_scale[row]  (what se3ds_row_scale would write: the renormalised output
+ * gradient the LDS-DMA data / weight gradient kernels take) and colsum_out[c] = sum_rows dy *
+ * sum_row_scale[row] (the bias gradient, models/layers.py:199-203).  sums: [1][2][c] scratch like
+ * se3ds_norm_stats.  SE3DS_E_UNSUPPORTED for other layouts (callers use the two separate calls). */
+int se3ds_colsum_row_scale(const void* x, int dtype, int64_t r, int c, const float* sum_row_scale,
+                           const float* out_row_scale, void* scaled_out, float* sums,
+                           float* colsum_out, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* ======================================================================================
  * Normalisation: tensors viewed as [g][r][c]; g = 1 for SyncBatchNormalization (279 sites in
  * the generator, e.g. models/layers.py:235-251), g = batch for tfa InstanceNormalization

@@ -51,8 +51,12 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
                     const float* __restrict__ mean, const float* __restrict__ rstd,
                     const float* __restrict__ row_scale, int64_t R, int C, int cx, int ry, int act,
                     float alpha, int rblocks, float* __restrict__ partial,
-                    const uint8_t* __restrict__ amask) {
+                    const uint8_t* __restrict__ amask, T* __restrict__ sc_out = nullptr,
+                    const float* __restrict__ sc_row = nullptr) {
   // grid: (rblocks, ctiles, G)
+  // sc_out / sc_row (MODE 0, bf16, VEC 8 only): the same pass also writes a * sc_row[row] -- the
+  // partial convs' backward needs dy * (per-pixel renormalisation) for its LDS-DMA kernels AND the
+  // column sums of dy * (another per-pixel factor) for the bias gradient: one read of dy, not two.
   // fp32 (parity) path: binary64 accumulators.  Batch-norm statistics enter as
   // var = E[x^2] - E[x]^2 (the reference's formula): with channel means of a few standard
   // deviations every 1e-6 of relative error in the sums becomes 1e-5 in the output, and on a
@@ -122,7 +126,7 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
     const uint16_t* A = (const uint16_t*)a;
     for (int64_t r = r_lo + ty; r < r_hi; r += (int64_t)NR * ry) {
       uint4 qa[NR];
-      float rsc[NR];
+      float rsc[NR], osc[NR];
       bool ok[NR];
 #pragma unroll
       for (int u = 0; u < NR; ++u) {
@@ -130,6 +134,7 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
         const int64_t row = (int64_t)g * R + (ok[u] ? r + (int64_t)u * ry : r);
         qa[u] = ld16(A + row * C + c0);
         rsc[u] = row_scale ? row_scale[row] : 1.0f;
+        osc[u] = sc_row ? sc_row[row] : 1.0f;
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -142,6 +147,13 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
           const ACC v = (ACC)(av[e] * rsc[u]);
           s0[e] += v;
           s1[e] += v * v;
+        }
+        if (sc_out) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = av[e] * osc[u];
+          const int64_t row = (int64_t)g * R + r + (int64_t)u * ry;
+          VT<T>::store(sc_out + row * C + c0, reinterpret_cast<float(&)[VT<T>::V]>(o));
         }
       }
     }
@@ -690,8 +702,10 @@ template <typename T, int MODE>
 int launch_partial(const T* a, const T* y, const T* x, const float* mean, const float* rstd,
                    const float* row_scale, int G, int64_t R, int C, int act, float alpha,
                    float* sums, float* dst0, float* dst1, float* ws, size_t ws_bytes,
-                   hipStream_t s, const uint8_t* amask = nullptr) {
+                   hipStream_t s, const uint8_t* amask = nullptr, T* sc_out = nullptr,
+                   const float* sc_row = nullptr) {
   Layout2D l = make_layout(C, VT<T>::V);
+  if (sc_out != nullptr && !(MODE == 0 && sizeof(T) == 2 && l.vec == 8)) return SE3DS_E_UNSUPPORTED;
   int rb = pick_rblocks(R, l.ry, l.ctiles, G);
   if (ws_bytes < sizeof(float) * (size_t)G * rb * 2 * C) return SE3DS_E_WORKSPACE;
   dim3 grid((unsigned)rb, (unsigned)l.ctiles, (unsigned)G);
@@ -712,7 +726,8 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
                          x, mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
   } else if (l.vec > 1)
     hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE>), grid, dim3(256), 0, s, a, y, x,
-                       mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
+                       mean, rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask, sc_out,
+                       sc_row);
   else
     hipLaunchKernelGGL((norm_partial_kernel<T, 1, MODE>), grid, dim3(256), 0, s, a, y, x, mean,
                        rstd, row_scale, R, C, l.cx, l.ry, act, alpha, rb, ws, amask);
@@ -745,6 +760,18 @@ int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const fl
                                        row_scale, g, r, c, 0, 0.f, sums, colsum_out, nullptr,
                                        (float*)workspace, workspace_bytes, s);
   return SE3DS_E_BADDTYPE;
+}
+
+int se3ds_colsum_row_scale(const void* x, int dtype, int64_t r, int c, const float* sum_row_scale,
+                           const float* out_row_scale, void* scaled_out, float* sums,
+                           float* colsum_out, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  if (r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
+  if (dtype != SE3DS_BF16 || (c % 8) != 0 || scaled_out == nullptr) return SE3DS_E_UNSUPPORTED;
+  return launch_partial<uint16_t, 0>((const uint16_t*)x, nullptr, nullptr, nullptr, nullptr,
+                                     sum_row_scale, 1, r, c, 0, 0.f, sums, colsum_out, nullptr,
+                                     (float*)workspace, workspace_bytes, as_stream(stream), nullptr,
+                                     (uint16_t*)scaled_out, out_row_scale);
 }
 
 int se3ds_norm_reduce_rows(const float* partial, int64_t rows, int c, float* sums, void* workspace,

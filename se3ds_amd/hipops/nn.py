@@ -635,17 +635,30 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
       rows = n * ho * wo
       row_scale = None
       dys = dy
+      st = layer.store
+      bias_done = False
       if partial:
         row_scale = ru if bias is not None else ratio
         if ctx.binary_masks:
           # pre-scale dy once so that wgrad / dgrad can take the LDS-DMA kernels
           dys = ctx.empty(dy.shape)
-          _chk(L.se3ds_row_scale(dy.data_ptr(), ctx.code, rows, layer.cout, row_scale.data_ptr(),
-                                 dys.data_ptr(), _lib.stream()), 'se3ds_row_scale')
+          if (ctx.param_grads and bias is not None and dy.dtype == torch.bfloat16 and
+              layer.cout % 8 == 0):
+            # ... and take the bias gradient's column sums from the same read of dy
+            sums = torch.empty((1, 2, layer.cout), dtype=torch.float32, device=ctx.device)
+            ws = ctx.ws('norm', L.se3ds_norm_workspace_bytes(1, layer.cout))
+            _chk(L.se3ds_colsum_row_scale(dy.data_ptr(), ctx.code, rows, layer.cout, bu.data_ptr(),
+                                          row_scale.data_ptr(), dys.data_ptr(), sums.data_ptr(),
+                                          st.grad_views[layer.name + '/bias'].data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _lib.stream()),
+                 'se3ds_colsum_row_scale')
+            bias_done = True
+          else:
+            _chk(L.se3ds_row_scale(dy.data_ptr(), ctx.code, rows, layer.cout, row_scale.data_ptr(),
+                                   dys.data_ptr(), _lib.stream()), 'se3ds_row_scale')
           row_scale = None
-      st = layer.store
       if ctx.param_grads:
-        if bias is not None:
+        if bias is not None and not bias_done:
           _colsum(ctx, dy.data_ptr(), ctx.code, rows, layer.cout,
                   row_scale=bu if partial else None, out=st.grad_views[layer.name + '/bias'])
         gk = st.grad_views[layer.name + '/kernel']
