@@ -963,3 +963,29 @@ def test_grad_sync_drip_feeds_buckets():
   sync.finish()
   assert dist_utils.GradSync(DEV, None).bucket == dist_utils.DRIP_BUCKET_ELEMS
   assert dist_utils.GradSync(DEV, None, drip=False).bucket == dist_utils.GRAD_BUCKET_ELEMS
+
+
+def test_maxpool_backward_ties_go_to_first_maximum_bf16():
+  """TF MaxPoolGrad routes the gradient to the FIRST maximal element of a window (row-major);
+  the vectorised bf16 kernel on windows that are all ties, partly ties, and ragged (odd H, W)."""
+  gen = torch.Generator().manual_seed(3)
+  for (h, w) in ((6, 8), (7, 9)):
+    x = torch.randint(0, 2, (2, h, w, 16), generator=gen).float()   # values {0, 1}: ties everywhere
+    ctx = nn.Ctx(DEV, torch.bfloat16, training=True, record=True)
+    xv = nn.Var(x.to(DEV).bfloat16())
+    yv = nn.maxpool2x2(ctx, xv)
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    gy = torch.randn((2, ho, wo, 16), generator=gen).bfloat16().float()
+    yv.grad = gy.to(DEV).bfloat16()
+    ctx.backward()
+    want = torch.zeros_like(x)
+    for oy in range(ho):
+      for ox in range(wo):
+        win = [(2 * oy + a, 2 * ox + b) for a in (0, 1) for b in (0, 1) if 2 * oy + a < h and 2 * ox + b < w]
+        m = torch.stack([x[:, qy, qx] for qy, qx in win]).max(0).values
+        taken = torch.zeros_like(m, dtype=torch.bool)
+        for qy, qx in win:
+          hit = (x[:, qy, qx] == m) & ~taken
+          want[:, qy, qx] = torch.where(hit, gy[:, oy, ox], torch.zeros_like(m))
+          taken |= hit
+    np.testing.assert_array_equal(xv.grad.float().cpu().numpy(), want.numpy())
