@@ -3206,6 +3206,52 @@ weight_prep_kernel(const float* __restrict__ w, int64_t K, int Cout, T* __restri
   }
 }
 
+// bf16, Cout % 4 == 0 and K % 8 == 0 (every layer of the bench but the thin heads): 64 x 64 tiles,
+// 16-byte reads of the fp32 master, 8-byte stores of wn and 16-byte stores of the transposed wt
+// (the 32 x 32 kernel above stores single bf16 values: 2 bytes per lane).
+__global__ void __launch_bounds__(256)
+weight_prep_vec_kernel(const float* __restrict__ w, int64_t K, int Cout, uint16_t* __restrict__ wt,
+                       uint16_t* __restrict__ wn) {
+  __shared__ float tile[64][65];
+  const int64_t k0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+  {
+    const int cq = (tid & 15) * 4, r0 = tid >> 4;   // 16 lanes x float4 cover 64 columns
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + 16 * i;
+      const int64_t k = k0 + r;
+      const int c = c0 + cq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && c < Cout) {
+        v = *reinterpret_cast<const float4*>(w + k * Cout + c);
+        if (wn) {
+          uint16_t o[4] = {f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
+          *reinterpret_cast<uint2*>(wn + k * Cout + c) = *reinterpret_cast<const uint2*>(o);
+        }
+      }
+      tile[r][cq] = v.x; tile[r][cq + 1] = v.y; tile[r][cq + 2] = v.z; tile[r][cq + 3] = v.w;
+    }
+  }
+  __syncthreads();
+  {
+    const int kq = (tid & 7) * 8, cr0 = tid >> 3;   // 8 lanes x 8 bf16 cover 64 k of one channel
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cr = cr0 + 32 * j;
+      const int c = c0 + cr;
+      const int64_t k = k0 + kq;
+      if (c < Cout && k < K) {
+        uint16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(tile[kq + e][cr]);
+        *reinterpret_cast<uint4*>(wt + (int64_t)c * K + k) = *reinterpret_cast<const uint4*>(o);
+      }
+    }
+  }
+}
+
 int fill_classes(IgemmParams& p, int mode, int bm = BM) {
   int total = 0;
   if (mode == MODE_FWD) {
@@ -3775,6 +3821,10 @@ int se3ds_weight_prep(const float* w, int64_t k, int cout, int dtype, void* wt, 
   if (dtype == SE3DS_F32)
     hipLaunchKernelGGL(weight_prep_kernel<float>, grid, dim3(256), 0, s, w, k, cout, (float*)wt,
                        (float*)wn);
+  else if (dtype == SE3DS_BF16 && (cout % 4) == 0 && (k % 8) == 0 &&
+           (((uintptr_t)w | (uintptr_t)wt) & 15) == 0 && (((uintptr_t)wn) & 7) == 0)
+    hipLaunchKernelGGL(weight_prep_vec_kernel, dim3((unsigned)ceil_div(k, 64), (unsigned)ceil_div(cout, 64)),
+                       dim3(256), 0, s, w, k, cout, (uint16_t*)wt, (uint16_t*)wn);
   else if (dtype == SE3DS_BF16)
     hipLaunchKernelGGL(weight_prep_kernel<uint16_t>, grid, dim3(256), 0, s, w, k, cout,
                        (uint16_t*)wt, (uint16_t*)wn);
