@@ -989,3 +989,38 @@ def test_maxpool_backward_ties_go_to_first_maximum_bf16():
           want[:, qy, qx] = torch.where(hit, gy[:, oy, ox], torch.zeros_like(m))
           taken |= hit
     np.testing.assert_array_equal(xv.grad.float().cpu().numpy(), want.numpy())
+
+
+def test_colsum_row_scale_matches_the_two_separate_passes():
+  """se3ds_colsum_row_scale (one read of dy) vs se3ds_row_scale + se3ds_norm_stats: the scaled copy
+  and the row-weighted column sums must be bit-identical (same arithmetic, same order)."""
+  from se3ds_amd import _lib
+  L = _lib.lib()
+  gen = torch.Generator().manual_seed(11)
+  for rows, c in ((1000, 64), (4096, 256), (37, 8)):
+    dy = torch.randn((rows, c), generator=gen).bfloat16().to(DEV)
+    ru = torch.rand(rows, generator=gen).to(DEV)
+    bu = (torch.rand(rows, generator=gen) > 0.2).float().to(DEV)
+    wsz = L.se3ds_norm_workspace_bytes(1, c)
+    ws = torch.empty(wsz, dtype=torch.uint8, device=DEV)
+    ref_s = torch.empty_like(dy)
+    _lib.check(L.se3ds_row_scale(dy.data_ptr(), _lib.BF16, rows, c, ru.data_ptr(), ref_s.data_ptr(),
+                                 _lib.stream()), 'se3ds_row_scale')
+    sums = torch.empty((1, 2, c), dtype=torch.float32, device=DEV)
+    ref_b = torch.empty(c, dtype=torch.float32, device=DEV)
+    _lib.check(L.se3ds_norm_stats(dy.data_ptr(), _lib.BF16, 1, rows, c, bu.data_ptr(), sums.data_ptr(),
+                                  ref_b.data_ptr(), ws.data_ptr(), wsz, _lib.stream()), 'se3ds_norm_stats')
+    got_s = torch.empty_like(dy)
+    got_b = torch.empty(c, dtype=torch.float32, device=DEV)
+    _lib.check(L.se3ds_colsum_row_scale(dy.data_ptr(), _lib.BF16, rows, c, bu.data_ptr(), ru.data_ptr(),
+                                        got_s.data_ptr(), sums.data_ptr(), got_b.data_ptr(),
+                                        ws.data_ptr(), wsz, _lib.stream()), 'se3ds_colsum_row_scale')
+    torch.cuda.synchronize()
+    assert torch.equal(got_s.view(torch.int16), ref_s.view(torch.int16)), (rows, c)
+    assert torch.equal(got_b, ref_b), (rows, c)
+    want = (dy.float() * bu[:, None]).double().sum(0)
+    assert float((got_b.double() - want).abs().max()) <= 1e-3 * float(want.abs().max() + 1)
+  # unsupported layouts are refused (callers fall back to the two passes)
+  x = torch.zeros((8, 4), device=DEV)
+  assert L.se3ds_colsum_row_scale(x.data_ptr(), _lib.F32, 8, 4, None, None, x.data_ptr(), None, None,
+                                  None, 0, _lib.stream()) != 0
