@@ -1024,3 +1024,40 @@ def test_colsum_row_scale_matches_the_two_separate_passes():
   x = torch.zeros((8, 4), device=DEV)
   assert L.se3ds_colsum_row_scale(x.data_ptr(), _lib.F32, 8, 4, None, None, x.data_ptr(), None, None,
                                   None, 0, _lib.stream()) != 0
+
+
+def test_norm_reduce_rows_finalize_matches_the_pair():
+  """se3ds_norm_reduce_rows_finalize vs se3ds_norm_reduce_rows + se3ds_norm_finalize: scale, shift,
+  mean, rstd and the moving statistics are bit-identical."""
+  from se3ds_amd import _lib
+  L = _lib.lib()
+  gen = torch.Generator().manual_seed(12)
+  for rows, c in ((256, 1024), (17, 64), (2048, 128)):
+    part = (torch.randn((rows, 2, c), generator=gen) * 3).to(DEV)
+    part[:, 1] = part[:, 1].abs() * 4 + 10          # sums of squares
+    gamma = (torch.rand(c, generator=gen) + 0.5).to(DEV)
+    beta = torch.randn(c, generator=gen).to(DEV)
+    count = float(rows * 64)
+    outs = []
+    for fused in (False, True):
+      mm, mv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+      o = [torch.empty((1, c), device=DEV) for _ in range(4)]
+      if fused:
+        _lib.check(L.se3ds_norm_reduce_rows_finalize(
+            part.data_ptr(), rows, c, count, gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.99,
+            mm.data_ptr(), mv.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+            o[3].data_ptr(), _lib.stream()), 'se3ds_norm_reduce_rows_finalize')
+      else:
+        sums = torch.empty((1, 2, c), device=DEV)
+        wsz = L.se3ds_norm_workspace_bytes(max(1, (rows + 511) // 512), c)
+        ws = torch.empty(wsz, dtype=torch.uint8, device=DEV)
+        _lib.check(L.se3ds_norm_reduce_rows(part.data_ptr(), rows, c, sums.data_ptr(), ws.data_ptr(),
+                                            wsz, _lib.stream()), 'se3ds_norm_reduce_rows')
+        _lib.check(L.se3ds_norm_finalize(sums.data_ptr(), count, 1, c, gamma.data_ptr(),
+                                         beta.data_ptr(), 1e-3, 0.99, mm.data_ptr(), mv.data_ptr(), 0,
+                                         o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(),
+                                         o[3].data_ptr(), _lib.stream()), 'se3ds_norm_finalize')
+      torch.cuda.synchronize()
+      outs.append([t.clone() for t in o] + [mm, mv])
+    for a, b in zip(*outs):
+      assert torch.equal(a, b), (rows, c)
