@@ -43,9 +43,17 @@ def _dist_setup(ngpus):
   backend = os.environ.get('SE3DS_BENCH_BACKEND', 'nccl')
   if backend != 'nccl':
     local = 0
+  if backend == 'nccl' and torch.cuda.device_count() < max(world, ngpus):
+    # (device_count() does not initialise the GPU) fail fast, before any rendezvous can hang
+    raise SystemExit(f'bench.py: --gpus {ngpus} (WORLD_SIZE {world}) needs one GPU per rank, this '
+                     f'node has {torch.cuda.device_count()}')
   torch.cuda.set_device(local)
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    # single-node job: keep the bootstrap / rendezvous sockets on loopback (the hostname of the
+    # GPU boxes does not resolve; c10d logs it on every run)
+    os.environ.setdefault('NCCL_SOCKET_IFNAME', 'lo')
+    os.environ.setdefault('GLOO_SOCKET_IFNAME', 'lo')
     if backend == 'nccl':
       dist.init_process_group('nccl', rank=rank, world_size=world,
                               device_id=torch.device('cuda', local))
@@ -59,6 +67,10 @@ def _launch_ranks(n):
   must also work from a process that has initialised the GPU) and relay its output."""
   import socket
   import subprocess
+  if os.environ.get('SE3DS_BENCH_BACKEND', 'nccl') == 'nccl' and torch.cuda.device_count() < n:
+    sys.stderr.write(f'bench.py: --gpus {n} needs {n} GPUs on this node, found '
+                     f'{torch.cuda.device_count()} (one process per GPU over RCCL)\n')
+    return 2
   with socket.socket() as sk:
     sk.bind(('127.0.0.1', 0))
     port = sk.getsockname()[1]
@@ -70,26 +82,7 @@ def _launch_ranks(n):
   return subprocess.run(cmd, env=env).returncode
 
 
-def _pmc_traffic(json_name, kernels):
-  """HBM bytes per launch from the TRACKED rocprofv3 PMC summaries under profiles/ (separate
-  FETCH_SIZE / WRITE_SIZE passes, tools/gpu_r2_prof.sh; raw counter values, the guide's x2 gfx950
-  correction for wide coalesced reads is listed beside them).  None when the file is missing."""
-  path = os.path.join(ROOT, 'profiles', json_name)
-  if not os.path.exists(path):
-    return None, None
-  d = json.load(open(path))
-  fetch = write = 0.0
-  used = []
-  for k, v in d.items():
-    if any(t in k for t in kernels) and 'fetch_mb' in v and 'write_mb' in v:
-      fetch += v['fetch_mb']
-      write += v['write_mb']
-      used.append(k)
-  if not used:
-    return None, None
-  detail = {'source': 'profiles/' + json_name, 'kernels': sorted(used), 'fetch_mb_raw': fetch,
-            'fetch_mb_x2_wide_read_correction': 2 * fetch, 'write_mb': write}
-  return (fetch + write) * 1e6, detail
+from se3ds_amd.bench_util import pmc_traffic as _pmc_traffic  # noqa: E402
 
 
 def _barrier(world):
@@ -252,6 +245,8 @@ def main():
   ap.add_argument('--image-size', type=int, default=512)
   ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-batch-max', action='store_true',
+                  help='gan_step: skip the extra large-batch measurement (batch_max) on the default line')
   ap.add_argument('--no-warp', action='store_true',
                   help='gan_step: skip the extra cfg5 warp measurement on the default line')
   args = ap.parse_args()
@@ -278,6 +273,8 @@ def main():
     wargs.steps, wargs.warmup, wargs.no_cpu_baseline = 50, 5, True
     w = bench_warp(wargs, rank, world, dev)
     out['warp'] = {k: w[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'config', 'roofline')}
+  out['backend'] = (dist.get_backend() if world > 1 else None)
+  out['world_size'] = (dist.get_world_size() if world > 1 else 1)
   if rank == 0:
     print(json.dumps(out))
   if world > 1:

@@ -374,8 +374,10 @@ int se3ds_fill(void* p, int dtype, int64_t n, float value, void* stream);
 /* SE3DSModel quantisation glue -- models/models.py:198 (int / 255 -> fp32), :289-291
  * (proj_rgb / 255 clipped to [0,1]), :325-331 (int32(g * 255) clipped to [-1,255];
  * int32(clip(g,0,1) * 255)), :353,:359 (casts to uint8): out = Q(clamp?(in) * mul / div) with one
- * rounding per op; float outputs are clamped to [lo,hi], integer outputs truncate toward zero
- * (tf.cast) and are then clamped to [lo,hi].  dtypes: SE3DS_F32 / SE3DS_I32 / SE3DS_U8. */
+ * rounding per op; float outputs are clamped to [lo,hi] as tf.clip_by_value does (NaN
+ * propagates), integer outputs truncate toward zero (tf.cast) and are then clamped to [lo,hi];
+ * lo > hi selects the pure cast (no clamp; int32 -> uint8 wraps modulo 256 like tf.cast).
+ * dtypes: SE3DS_F32 / SE3DS_I32 / SE3DS_U8. */
 int se3ds_quantize(const void* in, int in_dtype, int64_t n, int pre_clamp, float pre_lo,
                    float pre_hi, float mul, float div, float lo, float hi, void* out, int out_dtype,
                    void* stream);

@@ -162,9 +162,23 @@ class Net:
     self.bn_training = training if bn_training is None else bn_training
     self.updates = {}          # name -> new value of non-trainable variables
     self.stats_hook = stats_hook
+    # test hook: tag -> bool tensor of "output > 0" decisions to use INSTEAD of the sign of the
+    # oracle's own pre-activation (block-level parity tests run the oracle's backward under the
+    # decisions the device path took; see tests/test_blocks_gpu.py).  Tags are the names of the
+    # norm / conv layer whose output is activated.  acts: tag -> pre-activation (recorded).
+    self.decisions = None
+    self.pre_acts = None
 
   def get(self, name):
     return self.p[name]
+
+  def act(self, x, tag, alpha=0.0):
+    """ReLU (alpha 0) / LeakyReLU(alpha) of the tensor produced by layer `tag`."""
+    if self.pre_acts is not None:
+      self.pre_acts[tag] = x.detach()
+    if self.decisions is not None and tag in self.decisions:
+      return torch.where(self.decisions[tag], x, x * alpha)
+    return torch.where(x > 0, x, x * alpha) if alpha else F.relu(x)
 
   def has(self, name):
     return name in self.p
@@ -255,17 +269,17 @@ class Net:
     """layers.py:253-272."""
     residual = x
     out, um = self.partial_conv(x, mask, name + '/conv1', 1, 'SAME', spectral)
-    out = F.relu(self.sync_bn(out, name + '/bn1'))
+    out = self.act(self.sync_bn(out, name + '/bn1'), name + '/bn1')
     out = self.pad(out, 1, circular)
     um = self.pad(um, 1, circular)
     out, um = self.partial_conv(out, um, name + '/conv2', stride, 'VALID', spectral)
-    out = F.relu(self.sync_bn(out, name + '/bn2'))
+    out = self.act(self.sync_bn(out, name + '/bn2'), name + '/bn2')
     out, um = self.partial_conv(out, um, name + '/conv3', 1, 'SAME', spectral)
     out = self.sync_bn(out, name + '/bn3')
     if has_ds:
       residual, _ = self.partial_conv(x, mask, ds_name, stride, 'SAME', spectral)
       residual = self.sync_bn(residual, name + '/ds_norm')
-    return F.relu(out + residual), um
+    return self.act(out + residual, name + '/bn3'), um
 
   def res_stack(self, x, mask, name, inplanes, planes, blocks, stride, spectral, circular,
                 expansion=4):
@@ -281,7 +295,7 @@ class Net:
     """layers.py:400-455.  up_kind: None | 'convT' | 'conv1x1'."""
     conv = self.conv_fn(spectral)
     out = conv(self.pad(x, 1, circular), name + '/conv_a', 1, 'VALID')
-    out = F.relu(self.sync_bn(out, name + '/bn_a'))
+    out = self.act(self.sync_bn(out, name + '/bn_a'), name + '/bn_a')
     if up_kind is not None and stride != 1:
       out = self.conv_transpose(out, name + '/conv_b', stride)
     else:
@@ -292,7 +306,7 @@ class Net:
       residual = self.sync_bn(self.conv_transpose(x, up_name + '/conv', stride), up_name + '/bn')
     elif up_kind == 'conv1x1':
       residual = self.sync_bn(conv(x, up_name + '/conv', 1, 'VALID'), up_name + '/bn')
-    return F.relu(out + residual)
+    return self.act(out + residual, name + '/bn_b')
 
   def res_stack_transpose(self, x, name, inplanes, planes, blocks, stride, spectral, circular):
     """layers.py:458-511."""
@@ -327,7 +341,7 @@ def encoder(net, x, mask, d, version, spectral, name='encoder'):
   um = net.pad(mask, 3)
   out = net.pad(x, 3)
   out, um = net.partial_conv(out, um, name + '/conv1', 2, 'VALID')
-  out = F.relu(net.sync_bn(out, name + '/bn1'))
+  out = net.act(net.sync_bn(out, name + '/bn1'), name + '/bn1')
   b1 = out
   out, um = max_pool_same(out), max_pool_same(um)
   blocks = ENC_BLOCKS[version]
@@ -341,7 +355,7 @@ def encoder(net, x, mask, d, version, spectral, name='encoder'):
   out = net.pad(out, 1)
   um = net.pad(um, 1)
   out, um = net.partial_conv(out, um, name + '/final_conv', 1, 'VALID')
-  out = F.relu(net.sync_bn(out, name + '/final_bn'))
+  out = net.act(net.sync_bn(out, name + '/final_bn'), name + '/final_bn')
   return out, [b1, s1, s2, s3]
 
 
@@ -349,11 +363,11 @@ def decoder(net, x, skip, d, version, spectral, name):
   """image_models.py:443-488 (partial_conv=True, masks all None)."""
   conv = net.conv_fn(spectral)
   out = conv(x, name + '/upc/conv', 1, 'SAME')
-  out = leaky_relu(net.sync_bn(out, name + '/upc/bn'), 0.2)
+  out = net.act(net.sync_bn(out, name + '/upc/bn'), name + '/upc/bn', 0.2)
   out = out.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)   # UpSampling2D nearest
   def agent(t, nm):
     y, _ = net.partial_conv(t, None, name + '/' + nm, 1, 'SAME', spectral)
-    return F.relu(net.sync_bn(y, name + '/' + nm + '_bn'))
+    return net.act(net.sync_bn(y, name + '/' + nm + '_bn'), name + '/' + nm + '_bn')
   blocks = DEC_BLOCKS[version]
   out = agent(out, 'agent4')
   out = net.res_stack_transpose(out, name + '/deconv1', d * 8, d * 4, blocks[0], 1, spectral, True)
@@ -375,7 +389,7 @@ def head(net, x, name, spectral):
     x = net.sync_bn(x, name + f'/bn{i}')
     x = conv(net.pad(x, 1), name + f'/conv{i}', 1, 'VALID')
     if i < 2:
-      x = leaky_relu(x, 0.3)
+      x = net.act(x, name + f'/conv{i}', 0.3)
   return x
 
 
@@ -398,7 +412,7 @@ def generator_forward(params, cond, training, gen_dims, resnet_version='50', con
       hidden = net.sync_bn(hidden, f'context/bn{i}')
       hidden = net.spectral_conv(net.pad(hidden, 1), f'context/conv{i}', 1, 'VALID')
       if i < 3:
-        hidden = leaky_relu(hidden, 0.3)
+        hidden = net.act(hidden, f'context/conv{i}', 0.3)
   n, hh, hw, _ = hidden.shape
   out = decoder(net, hidden, skip, d, resnet_version, spectral, 'decoder')
   depth_out = decoder(net, hidden, skip, d, resnet_version, spectral, 'depth_decoder')

@@ -474,3 +474,35 @@ def compact_valid(xyz1, feats, void):
   valid = np.any(feats != void, axis=(0, 2))
   idx = np.nonzero(valid)[0]
   return xyz1[:, :, idx], feats[:, idx]
+
+
+# ------------------------------------------------- notebooks/SE3DS_RE10K_Colab.ipynb cells 15 / 17
+def notebook_cell15_pointcloud(rgb01, depth01, camera_intrinsics, rotation_matrix, eq_height,
+                               void_class=-1, depth_scale=20.0):
+  """Cell 15: two project_perspective_image calls (round_to_nearest=True, constant padding),
+  `tf.cast(rgb * 255, tf.int32)`, equirectangular_to_pointcloud.  rgb01 (h,w,3) fp32 in [0,1],
+  depth01 (h,w) fp32 in [0,1] -> xyz1 (1,4,P), feats (1,P,3) int32."""
+  rgb_t = project_perspective_image(rgb01, None, eq_height, camera_intrinsics=camera_intrinsics,
+                                    rotation_matrix=rotation_matrix, round_to_nearest=True)
+  depth_t = project_perspective_image(np.asarray(depth01, F32)[..., None], None, eq_height,
+                                      camera_intrinsics=camera_intrinsics,
+                                      rotation_matrix=rotation_matrix, round_to_nearest=True)
+  proj_depth = depth_t[None, ..., 0]
+  proj_rgb = (rgb_t[None] * F32(255)).astype(F32).astype(np.int32)   # tf.cast truncates
+  return equirectangular_to_pointcloud(proj_rgb, proj_depth, void_class, depth_scale)
+
+
+def notebook_cell17_guidance(pred_rgb, pred_depth, camera_intrinsics, new_rotation_matrix,
+                             pers_height, pers_width):
+  """Cell 17 after the splat: the three get_perspective_from_equirectangular_image gathers, the
+  `/ 255` + clip, the validity mask (depth != 1, != 0, all(rgb != 0)) gathered and compared with
+  1.0, and the products that form the generator's inputs.  pred_rgb (H,W,3), pred_depth (H,W)
+  fp32 -> proj_image (1,h,w,3), proj_depth (1,h,w,1), proj_mask (1,h,w,1)."""
+  g = lambda img: get_perspective_from_equirectangular_image(img, camera_intrinsics,
+                                                             new_rotation_matrix, pers_height,
+                                                             pers_width)
+  rgb_g = np.clip((g(pred_rgb) / F32(255)).astype(F32), 0, 1)[None]
+  depth_g = g(np.asarray(pred_depth, F32)[..., None])[None]
+  m = ((pred_depth != 1.0) & (pred_depth != 0.0) & np.all(pred_rgb != 0.0, axis=-1)).astype(F32)
+  mask_g = (g(m[..., None])[None] == 1.0).astype(F32)
+  return (mask_g * rgb_g).astype(F32), (mask_g * depth_g).astype(F32), mask_g

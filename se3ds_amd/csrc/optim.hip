@@ -51,6 +51,18 @@ tensor_sqsum_kernel(const float* __restrict__ partial, const int64_t* __restrict
 }
 
 // tf.clip_by_norm: (g * clip) / max(l2norm, clip), l2norm = sqrt(sum g^2) (0 if the sum is 0)
+constexpr int SN_RB = 64;   // row blocks for v = W u and for dot products (vpart holds 3 * SN_RB + 2)
+
+// <G, W> of one spectral layer from its SN_RB partials (sn_dots_kernel / sn_dot_kernel): ONE
+// summation order for the fix-up (sn_fix_kernel), the fused fix-up inside clip_kernel and the
+// closed-form squared norm (sn_sqnorm_kernel), so the clip denominator always matches the
+// gradient it is applied to.
+__device__ inline float sn_dot_gw(const float* __restrict__ vpart) {
+  float dot = 0.f;
+  for (int i = 0; i < SN_RB; ++i) dot += vpart[i];
+  return dot;
+}
+
 __global__ void __launch_bounds__(kB)
 clip_kernel(float* __restrict__ g, const int64_t* __restrict__ chunks,
             const float* __restrict__ sqnorm, float clip, const int64_t* __restrict__ tensor_sn) {
@@ -72,8 +84,7 @@ clip_kernel(float* __restrict__ g, const int64_t* __restrict__ chunks,
   const float* sig = (const float*)L[4];
   const float* vpart = (const float*)L[6];
   const int C = (int)L[8];
-  float dot = 0.f;
-  for (int i = 0; i < 64; ++i) dot += vpart[i];   // SN_RB partials of <G, W>
+  const float dot = sn_dot_gw(vpart);
   const float inv = sig[1];
   const float coef = inv * inv * dot;
   const int64_t e0 = (g + start) - (const float*)L[9] + threadIdx.x;   // element of the tensor
@@ -154,7 +165,6 @@ ema_kernel(float* __restrict__ ema, const float* __restrict__ var, int64_t n, fl
 //   0 W (float*)  1 u (float*)  2 v (float*, K)  3 uhat (float*, Cout)  4 sig (float*, 2)
 //   5 part (float*, SN_KB*Cout)  6 vpart (float*, SN_RB)  7 K  8 Cout  9 grad (float*)
 constexpr int SN_F = 10;
-constexpr int SN_RB = 64;   // row blocks for v = W u and for dot products
 constexpr int SN_KB = 32;   // K slabs for u' = v^T W
 constexpr float SN_EPS = 1e-10f;
 
@@ -286,8 +296,7 @@ sn_fix_kernel(const int64_t* __restrict__ tab) {
   float* G = (float*)L[9];
   const int C = (int)L[8];
   const int64_t n = L[7] * C;
-  float dot = 0.f;
-  for (int i = 0; i < SN_RB; ++i) dot += vpart[i];
+  const float dot = sn_dot_gw(vpart);
   const float inv = sig[1];
   const float coef = inv * inv * dot;
   for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)SN_RB * kB) {
@@ -361,10 +370,9 @@ sn_sqnorm_kernel(const int64_t* __restrict__ tensor_sn, int tensor_base, int T,
     if (L == nullptr) continue;
     const float* sig = (const float*)L[4];
     const float* vpart = (const float*)L[6];
-    float dot = 0.f;
+    const float dot = sn_dot_gw(vpart);   // (fp32, the order sn_fix_kernel / clip_kernel use)
     double gg = 0.0, gvu = 0.0;
     for (int i = 0; i < SN_RB; ++i) {
-      dot += vpart[i];   // (fp32, in the order sn_fix_kernel / clip_kernel use)
       gg += (double)vpart[SN_RB + i];
       gvu += (double)vpart[2 * SN_RB + i];
     }

@@ -487,23 +487,37 @@ using namespace se3ds;
 // models/models.py:289-291 (proj_rgb / 255, clip), :325-331 (int32(g * 255), clip(-1, 255);
 // int32(clip(g, 0, 1) * 255)), :198 (int / 255), :353 (cast to uint8): one rounding per reference
 // op -- optional pre-clamp, * mul, / div (IEEE division), then either a float clamp or
-// truncation toward zero (tf.cast float -> int) followed by an integer clamp.
+// truncation toward zero (tf.cast float -> int) followed by an integer clamp.  Float clamps are
+// tf.clip_by_value: min(max(v, lo), hi) in TF's NaN-PROPAGATING sense (a NaN prediction stays NaN
+// instead of turning into `lo`, so a diverged roll-out is visible).  lo > hi selects a PURE CAST for
+// integer outputs: no clamp, the value wraps modulo 2^bits as tf.cast(int32 -> uint8) does (a -1
+// void class becomes 255).
+__device__ inline float clip_by_value(float v, float lo, float hi) {
+  return v < lo ? lo : (v > hi ? hi : v);   // comparisons are false for NaN: NaN passes through
+}
+
 template <typename TI, typename TO>
 __global__ void __launch_bounds__(kB)
 quantize_kernel(const TI* __restrict__ in, int64_t n, int pre_clamp, float pre_lo, float pre_hi,
                 float mul, float div, float lo, float hi, TO* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)gridDim.x * kB) {
     float v = (float)in[i];
-    if (pre_clamp) v = fminf(fmaxf(v, pre_lo), pre_hi);
+    if (pre_clamp) v = clip_by_value(v, pre_lo, pre_hi);
     v = v * mul;
     v = v / div;
     if constexpr (std::is_floating_point<TO>::value) {
-      out[i] = (TO)fminf(fmaxf(v, lo), hi);
+      out[i] = (TO)clip_by_value(v, lo, hi);
     } else {
-      int t = (int)v;
-      const int ilo = (int)lo, ihi = (int)hi;
-      t = t < ilo ? ilo : (t > ihi ? ihi : t);
-      out[i] = (TO)t;
+      // float -> int: truncation toward zero; NaN and values outside int32 are undefined in TF
+      // (and in C): pinned here to 0 / saturation so that the result is at least deterministic
+      int t = (v != v) ? 0 : (v >= 2147483648.f ? 2147483647 : (v <= -2147483648.f ? (-2147483647 - 1) : (int)v));
+      if (lo <= hi) {
+        const int ilo = (int)lo, ihi = (int)hi;
+        t = t < ilo ? ilo : (t > ihi ? ihi : t);
+        out[i] = (TO)t;
+      } else {
+        out[i] = (TO)(unsigned int)t;   // pure cast: wraps modulo 2^bits
+      }
     }
   }
 }

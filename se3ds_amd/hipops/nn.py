@@ -217,6 +217,7 @@ class Ctx:
     self.binary_masks = True
     self.on_segment = None    # callback(name): a top-level module's parameter gradients are final
     self.batch_limit = None   # backward passes that only concern the first samples of the batch
+    self.act_taps = None      # tests: dict layer name -> activated output (sign decisions)
     self.group = group
     # Replica count of the STRATEGY that built the model, never probed from global
     # torch.distributed state: a one-device model inside an initialised process group must not
@@ -224,6 +225,13 @@ class Ctx:
     if world is None:
       world = dist.get_world_size(group) if group is not None else 1
     self.world = int(world)
+    if group is not None and self.world != dist.get_world_size(group):
+      raise ValueError(f'Ctx: world={self.world} does not match the replica group '
+                       f'({dist.get_world_size(group)} ranks)')
+    if group is None and self.world > 1 and not (dist.is_initialized() and
+                                                 dist.get_world_size() == self.world):
+      raise ValueError(f'Ctx: world={self.world} without a group needs a default process group '
+                       'of that size')
     self._ws = {}
 
   def ws(self, key, nbytes):
@@ -614,6 +622,8 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
                               _lib.ptr(um if (partial and bias is not None) else None), act,
                               float(alpha), _lib.stream()), 'se3ds_conv2d_fwd')
   out = Var(y)
+  if act != ACT_NONE and ctx.act_taps is not None:
+    ctx.act_taps[layer.name] = y
   if stats is not None:
     out.col_stats = stats   # [rows][2][cout] partial (sum, sum of squares) of y
   if recording:
@@ -849,6 +859,8 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
                           _lib.ptr(post.data if post is not None else None), act, float(alpha),
                           y.data_ptr(), _lib.ptr(amask), _lib.stream()), 'se3ds_norm_apply')
   out = Var(y)
+  if act != ACT_NONE and ctx.act_taps is not None:
+    ctx.act_taps[layer.name] = y
   if ctx.tape is not None:
     def bwd(g=g):
       dy = out.grad

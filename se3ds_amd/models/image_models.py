@@ -56,9 +56,13 @@ class _Model:
   def variables(self):
     return [self.store[n] for n in self.store.trainable_names + self.store.state_names]
 
-  def make_ctx(self, training, record=False, group=None, dtype=None, world=1) -> Ctx:
-    """`world` = strategy.num_replicas_in_sync (SyncBatchNormalization sums over that many
-    replicas of `group`; None = the default process group)."""
+  def make_ctx(self, training, record=False, group=None, dtype=None, world=None) -> Ctx:
+    """`world` = strategy.num_replicas_in_sync, the number of replicas SyncBatchNormalization
+    sums over; `group` = their process group (None with world > 1 = the default group).
+    world=None derives the count from `group` (its size; 1 without a group: a one-device model
+    never all-reduces, even inside an initialised torch.distributed job).  A world that does not
+    match the group's size (e.g. a group passed together with world=1) raises instead of
+    silently running unsynchronised batch norm."""
     return Ctx(self.device, dtype or self.dtype, training=bool(training), record=record,
                group=group, world=world)
 

@@ -16,8 +16,10 @@ from se3ds_amd.utils import pano_utils
 
 
 def _quantize(x: torch.Tensor, out_dtype, mul=1.0, div=1.0, lo=0.0, hi=0.0, pre=None):
-  """libse3ds_hip.so `se3ds_quantize`: Q(clamp?(x) * mul / div), clamped to [lo, hi]; integer
-  outputs truncate toward zero like tf.cast (reference :198,:289-291,:325-331,:353)."""
+  """libse3ds_hip.so `se3ds_quantize`: Q(clamp?(x) * mul / div), clamped to [lo, hi] (NaN
+  propagates like tf.clip_by_value); integer outputs truncate toward zero like tf.cast
+  (reference :198,:289-291,:325-331,:353); lo > hi = pure cast without a clamp (int32 -> uint8
+  wraps modulo 256 as tf.cast does)."""
   from se3ds_amd import hipops  # noqa: F401  (registers the signature)
   _lib.require_cuda(x)
   x = x.contiguous()
@@ -147,7 +149,7 @@ class SE3DSModel(object):
     if pano_rgb.dtype != torch.int32:
       pano_rgb = _quantize(pano_rgb, torch.int32, lo=0, hi=255)          # tf.cast(uint8 -> int32)
     if pano_semantic.dtype != torch.uint8:
-      pano_semantic = _quantize(pano_semantic, torch.uint8, lo=0, hi=255)  # tf.cast(int32 -> uint8)
+      pano_semantic = _quantize(pano_semantic, torch.uint8, lo=1, hi=0)  # tf.cast(int32 -> uint8): wraps
     self.prev_rgb_frame = _quantize(pano_rgb, torch.float32, div=255.0, lo=-1.0, hi=1.0)
     if mask_blurred:
       pano_rgb = pano_utils.mask_pano(pano_rgb, masked_region_value=constants.INVALID_RGB_VALUE)

@@ -70,6 +70,8 @@ class GradSync:
     self.side = torch.cuda.Stream(device=self.device)
     self.pending = []    # (arena, o, n, ready event) not yet on the side stream
     self.launched = []   # (e0, e1) ranges handed over this step (for tests)
+    self.seen = 0            # collectives of this step that called pump() so far
+    self.prev_seen = None    # ... of the previous step (None: first step, pace one per call)
 
   def _issue(self, arena, o, n, ready):
     with torch.cuda.stream(self.side):
@@ -85,14 +87,24 @@ class GradSync:
     self.launched.append((e0, e1))
     self.pump(1 if self.drip else len(self.pending))
 
-  def pump(self, k: int = 1):
-    """Moves up to k pending buckets onto the side stream (called behind every SyncBN
-    collective while gradients are pending)."""
+  def pump(self, k: int = None):
+    """Moves up to k pending buckets onto the side stream.  k=None is the call wired behind
+    every SyncBN collective of the backward pass: at least one bucket, and as many as it takes
+    to have the queue empty by the LAST collective of the step (their number is known from the
+    previous step), so that the bytes in flight follow the remaining backward time and nothing
+    but the last segments' own buckets is left for finish()."""
+    if k is None:
+      self.seen += 1
+      k = 1
+      if self.prev_seen:
+        left = max(self.prev_seen - self.seen + 1, 1)
+        k = max(1, -(-len(self.pending) // left))
     while k > 0 and self.pending:
       self._issue(*self.pending.pop(0))
       k -= 1
 
   def finish(self):
+    self.prev_seen, self.seen = (self.seen or self.prev_seen), 0
     self.pump(len(self.pending))
     torch.cuda.current_stream(self.device).wait_stream(self.side)
     self.launched = []

@@ -1,0 +1,240 @@
+"""Block-level forward + backward parity at PRODUCTION width through the default dispatch.
+
+One residual block (or decoder stage, or head) is short enough to be well conditioned even with
+batch statistics, so -- unlike the 200-layer cfg1 step, whose fp32 gradients are only comparable
+through an fp64 yardstick -- every tensor is held DIRECTLY to north_star's bar:
+
+  fp32 path : max|hip - oracle| <= 1e-3 * max|oracle|  for the output, every input gradient and
+              every parameter gradient (kernel, bias, gamma, beta; spectral fix-up applied)
+  bf16 path : <= 2e-2 on the same tensors (operands rounded to bf16, fp32 accumulation)
+
+Blocks (reference lines; widths and map sizes are those of highres.gin at 512 x 1024, batch 2):
+  Bottleneck       layers.py:220-272  stack3 block0: 1024 -> 512 -> 2048, stride 2, real mask,
+                                      1x1 strided downsample (64x128 -> 32x64)
+  TransBasicBlock  layers.py:400-455  deconv1 block: 1024 @32x64 (two 3x3 1024 -> 1024)
+  upsampling block layers.py:400-455,472-480  deconv2 last block: 512 -> 256, ConvT k3 s2 +
+                                      ConvT k2 s2 residual (32x64 -> 64x128)
+  upc + agent4, agent3 + add   image_models.py:351-441,455-462
+  head             image_models.py:79-104  128 -> 128 -> 128 -> 3 at 128x256, then (tanh+1)/2
+
+ReLU / LeakyReLU derivatives are sign DECISIONS: two correct evaluations of a pre-activation
+differ by ~1e-6 relative (fp32), so on a 4 M-element tensor one or two elements straddle zero and
+the backward passes then differ by a whole |dy| there although both are right
+(tests/test_prod_shapes_gpu.py::test_prod_norm_fwd_bwd measured it).  As there, the oracle's
+backward runs under the device path's decisions (oracle.nets_torch.Net.decisions); the test
+proves that the decisions differ from the oracle's own only inside the forward error band around
+zero and only on a vanishing fraction of the elements.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_torch as O
+from se3ds_amd.hipops import nn
+from se3ds_amd.hipops.nn import ACT_LRELU, ACT_RELU
+from se3ds_amd.models import image_models, layers
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = {torch.float32: 1e-3, torch.bfloat16: 2e-2}
+FLIP_FRAC = {torch.float32: 2e-5, torch.bfloat16: 1e-2}
+
+
+def _bf(t):
+  return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _mask(n, h, w, gen):
+  m = (torch.rand((n, h, w), generator=gen) < 0.7).float()
+  m[:, h // 3:h // 3 + max(1, h // 6)] = 0      # a band of holes as the projected masks have
+  m[:, :, w // 2:w // 2 + w // 8] *= (torch.rand((n, h, w // 8), generator=gen) < 0.2).float()
+  return m
+
+
+def _randomise(store, gen):
+  upd = {}
+  for nme in store.trainable_names:
+    shape = store[nme].shape
+    if nme.endswith('gamma'):
+      upd[nme] = (torch.rand(shape, generator=gen) + 0.5).numpy()
+    elif nme.endswith('beta') or nme.endswith('bias'):
+      upd[nme] = (torch.randn(shape, generator=gen) * 0.1).numpy()
+  store.load_dict(upd)
+
+
+class _Case:
+  """build(store) -> module-ish; hip(ctx, mod, vars, masks) -> Var; ref(net, xs, masks) -> tensor."""
+
+  def __init__(self, name, shapes, mask_shape, build, hip, ref, n_decisions):
+    self.name, self.shapes, self.mask_shape = name, shapes, mask_shape
+    self.build, self.hip, self.ref, self.n_decisions = build, hip, ref, n_decisions
+
+
+def _bottleneck_case():
+  def build(store):
+    ds = layers.PartialSpectralConv(store, 'st/downsample', 1024, 2048, 1, 2, 'SAME', use_bias=False)
+    return layers.Bottleneck(store, 'st/block0', 1024, 512, 2, 4, ds, True, layers.PartialSpectralConv)
+  def hip(ctx, mod, xs, mask):
+    out, um = mod(ctx, xs[0], mask)
+    return out, um
+  def ref(net, xs, mask):
+    out, um = net.bottleneck(xs[0], mask[..., None], 'st/block0', 2, True, 'st/downsample', True, True)
+    return out, um[..., 0]
+  return _Case('bottleneck_stack3_block0', [(2, 64, 128, 1024)], (2, 64, 128), build, hip, ref, 3)
+
+
+def _trans_block_case():
+  def build(store):
+    return layers.TransBasicBlock(store, 'dc/block0', 1024, 1024, circular_pad=True,
+                                  conv_fn=layers.SpectralConv)
+  def hip(ctx, mod, xs, mask):
+    return mod(ctx, xs[0]), None
+  def ref(net, xs, mask):
+    return net.trans_basic_block(xs[0], 'dc/block0', 1, None, None, True, True), None
+  return _Case('trans_basic_block_1024', [(2, 32, 64, 1024)], None, build, hip, ref, 2)
+
+
+def _upsampling_block_case():
+  def build(store):
+    up = layers._Upsample(store, 'dc/upsample', 512, 256, 2, layers.SpectralConv)
+    return layers.TransBasicBlock(store, 'dc/block3', 512, 256, 2, upsample=up, circular_pad=True,
+                                  conv_fn=layers.SpectralConv)
+  def hip(ctx, mod, xs, mask):
+    return mod(ctx, xs[0]), None
+  def ref(net, xs, mask):
+    return net.trans_basic_block(xs[0], 'dc/block3', 2, 'convT', 'dc/upsample', True, True), None
+  return _Case('upsampling_block_512_256', [(2, 32, 64, 512)], None, build, hip, ref, 2)
+
+
+class _UpcAgents:
+  """The decoder's entry and first skip merge (image_models.py:351-441,455-462), deconv1 left out:
+  upc (SN 1x1 -> BN -> LeakyReLU 0.2 -> nearest x2) -> agent4, then + agent3(skip s3)."""
+
+  def __init__(self, store):
+    d = 128
+    self.upc_conv = layers.SpectralConv(store, 'dec/upc/conv', d * 4, d * 2, 1, 1, 'SAME')
+    self.upc_bn = layers.SyncBatchNormalization(store, 'dec/upc/bn', d * 2)
+    self.agent4 = layers.PartialSpectralConv(store, 'dec/agent4', d * 2, d * 8, 1, 1, 'SAME', use_bias=False)
+    self.agent4_bn = layers.SyncBatchNormalization(store, 'dec/agent4_bn', d * 8)
+    self.agent3 = layers.PartialSpectralConv(store, 'dec/agent3', d * 16, d * 8, 1, 1, 'SAME', use_bias=False)
+    self.agent3_bn = layers.SyncBatchNormalization(store, 'dec/agent3_bn', d * 8)
+
+  def __call__(self, ctx, x, s3):
+    out = self.upc_conv(ctx, x)
+    out = self.upc_bn(ctx, out, act=ACT_LRELU, alpha=0.2)
+    out = nn.upsample2x(ctx, out)
+    y, _ = self.agent4(ctx, out, None)
+    out = self.agent4_bn(ctx, y, act=ACT_RELU)
+    y, _ = self.agent3(ctx, s3, None)
+    return nn.add(ctx, out, self.agent3_bn(ctx, y, act=ACT_RELU))
+
+
+def _upc_agents_case():
+  def hip(ctx, mod, xs, mask):
+    return mod(ctx, xs[0], xs[1]), None
+  def ref(net, xs, mask):
+    out = net.spectral_conv(xs[0], 'dec/upc/conv', 1, 'SAME')
+    out = net.act(net.sync_bn(out, 'dec/upc/bn'), 'dec/upc/bn', 0.2)
+    out = out.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    def agent(t, nm):
+      y, _ = net.partial_conv(t, None, 'dec/' + nm, 1, 'SAME', True)
+      return net.act(net.sync_bn(y, 'dec/' + nm + '_bn'), 'dec/' + nm + '_bn')
+    return agent(out, 'agent4') + agent(xs[1], 'agent3'), None
+  return _Case('upc_agent4_agent3_add', [(2, 16, 32, 512), (2, 32, 64, 2048)], None, _UpcAgents,
+               hip, ref, 3)
+
+
+def _head_case():
+  def build(store):
+    return image_models._Head(store, 'rgb_conv', 128, 3, True, layers.SpectralConv)
+  def hip(ctx, mod, xs, mask):
+    return mod(ctx, xs[0]), None
+  def ref(net, xs, mask):
+    return O.head(net, xs[0], 'rgb_conv', True), None
+  return _Case('head_rgb_128', [(2, 128, 256, 128)], None, build, hip, ref, 2)
+
+
+CASES = [_bottleneck_case(), _trans_block_case(), _upsampling_block_case(), _upc_agents_case(),
+         _head_case()]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', CASES, ids=[c.name for c in CASES])
+def test_block_fwd_bwd_at_production_width(case, dtype):
+  gen = torch.Generator().manual_seed(11)
+  store = nn.ParamStore()
+  mod = case.build(store)
+  store.finalize(DEV, torch.Generator().manual_seed(7))
+  _randomise(store, gen)
+  dev = torch.device(DEV)
+  sg = nn.SpectralGroup(image_models._conv_layers_of(mod), dev)
+  # activations as they arrive behind a ReLU + residual stream: non-negative, channel-dependent scale
+  xs = [_bf(torch.relu(torch.randn(s, generator=gen) * 0.7 + torch.randn(s[-1], generator=gen) * 0.5))
+        for s in case.shapes]
+  mask = _mask(*case.mask_shape, gen) if case.mask_shape else None
+  params = {k: v.detach().cpu().clone() for k, v in store.views.items()}   # before u advances
+
+  # ---- device path
+  ctx = nn.Ctx(DEV, dtype, training=True, record=True)
+  ctx.act_taps = {}
+  xv = [nn.Var(x.to(DEV).to(dtype)) for x in xs]
+  sg.power_iteration(True)
+  out, um = case.hip(ctx, mod, xv, mask.to(DEV) if mask is not None else None)
+  is_head = case.name.startswith('head')
+  if is_head:
+    y_h, push = nn.head(ctx, out, 0)
+    y_h = y_h.cpu()
+  else:
+    y_h = out.data.float().cpu()
+  gy = _bf(torch.randn(y_h.shape, generator=gen))
+  if is_head:
+    push(gy.to(DEV))
+  else:
+    out.grad = gy.to(DEV).to(dtype)
+  ctx.backward()
+  sg.backward_fixup()
+  decisions = {k: (v.float() > 0).cpu() for k, v in ctx.act_taps.items()}
+  assert len(decisions) == case.n_decisions, sorted(decisions)
+
+  # ---- oracle, backward under the device path's sign decisions
+  for k in store.trainable_names:
+    params[k].requires_grad_(True)
+  net = O.Net(params, training=True)
+  net.decisions, net.pre_acts = decisions, {}
+  xo = [x.clone().requires_grad_(True) for x in xs]
+  yo, um_o = case.ref(net, xo, mask)
+  if is_head:
+    yo = (torch.tanh(yo) + 1) / 2
+  yo.backward(gy)
+  tol = TOL[dtype]
+  flips_total = 0
+  for tag, dec in decisions.items():
+    pre = net.pre_acts[tag]
+    flip = dec != (pre > 0)
+    flips_total += int(flip.sum())
+    assert float(flip.float().mean()) <= FLIP_FRAC[dtype], (tag, int(flip.sum()), flip.numel())
+    # a decision may only differ where the pre-activation lies inside the forward error band
+    band = tol * float(pre.abs().max())
+    assert not bool((flip & (pre.abs() > band)).any()), (tag, 'sign decision outside the error band')
+
+  def err(a, b, floor=0.0):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor, 1e-30))
+
+  e = {'y': err(y_h.numpy(), yo.detach().numpy())}
+  if um is not None:
+    assert torch.equal(um.cpu(), um_o.detach()), 'update mask must be exact'
+  for i, (v, o) in enumerate(zip(xv, xo)):
+    e[f'dx{i}'] = err(v.grad.float().cpu().numpy(), o.grad.numpy())
+  gmax = max(float(params[k].grad.abs().max()) for k in store.trainable_names)
+  for k in store.trainable_names:
+    # floor: conv biases in front of a batch norm have a mathematically zero gradient (sums of
+    # +-1e-7 terms); measure those against the block's gradient scale
+    e[k] = err(store.grad_views[k].cpu().numpy(), params[k].grad.numpy(), 1e-4 * gmax)
+  for k, v in net.updates.items():   # BN moving statistics, spectral u
+    e['upd:' + k] = err(store[k].cpu().numpy(), v.detach().numpy())
+  worst = sorted(e.items(), key=lambda kv: -kv[1])[:4]
+  print(f'{case.name} {str(dtype)[6:]}: flips={flips_total} y={e["y"]:.2e} ' +
+        ' '.join(f'{k}={v:.2e}' for k, v in worst))
+  bad = {k: v for k, v in e.items() if not v <= tol}
+  assert not bad, bad

@@ -366,6 +366,64 @@ def test_cfg1_generator_gradients_well_conditioned():
   assert cos > 0.0, cos   # reported (what 8 mantissa bits leave of a 200-layer gradient)
 
 
+def test_cfg1_bf16_training_trajectory_tracks_fp32():
+  """End-to-end gate of the bf16 step, the arithmetic of the headline number (the reference trains
+  in fp32; per-layer and per-block bf16 parity is pinned in test_prod_shapes_gpu / test_blocks_gpu).
+  30 `train_g_d` steps (full lowres.gin trainer: ResNet-101 gen_dims 128, 128x256, batch 2, Adam
+  on all 1.1 B parameters, EMA) on ONE fixed batch, once on the fp32 path and once on the bf16
+  path, from identical initial weights.  Gates:
+    * the supervised part of the generator loss (depth L1 + world-consistency) falls on BOTH paths:
+      mean of the last 5 steps < 0.8 x mean of the first 3;
+    * the bf16 trajectory stays inside a band around the fp32 one: per step, depth+wc within
+      15 % (+0.05 abs), and the 30-step means of depth, wc and the discriminator loss within 10 %;
+    * everything stays finite.
+  A bf16 step that returned gradients of the wrong sign or scale (the per-tensor cosine of a
+  200-layer gradient at random init is 0.3-0.8: what 8 mantissa bits leave of a chaotic map) would
+  show here as a loss that stalls or leaves the band."""
+  steps = 30
+  batch = synth_batch(2, 128, seed=91)
+  dbatch = {k: v.to(DEV) for k, v in batch.items()}
+  traj = {}
+  theta0 = None
+  for dtype in (torch.float32, torch.bfloat16):
+    gan = _gin_gan('lowres', dtype)
+    if theta0 is None:
+      theta0 = [m.store.theta.clone() for m in (gan.generator, gan.discriminator)]
+      state0 = [m.store.state.clone() for m in (gan.generator, gan.discriminator)]
+    else:   # identical start (device-side init is seeded, this makes it explicit)
+      for m, t, st in zip((gan.generator, gan.discriminator), theta0, state0):
+        m.store.theta.copy_(t)
+        m.store.state.copy_(st)
+        m.store.version += 1
+    rows = []
+    t0 = time.time()
+    for _ in range(steps):
+      gan._reset_metrics()
+      gan.train_g_d(dbatch)
+      gan.global_step += gan.num_batched_steps
+      m = gan._save_metrics_to_dict()
+      rows.append([float(m[k]) for k in ('gen/depth_loss', 'gen/wc_loss', 'dis/disc_loss',
+                                          'gen/gen_gan_loss')])
+    torch.cuda.synchronize()
+    traj[dtype] = np.array(rows, np.float64)
+    assert np.isfinite(traj[dtype]).all() and bool(torch.isfinite(gan.generator.store.theta).all())
+    print(f'{str(dtype)[6:]}: {steps} steps in {time.time() - t0:.1f} s; depth+wc '
+          + ' '.join(f'{v:.3f}' for v in (traj[dtype][:, 0] + traj[dtype][:, 1])[::3]))
+    del gan
+    torch.cuda.empty_cache()
+  f, b = traj[torch.float32], traj[torch.bfloat16]
+  sup_f, sup_b = f[:, 0] + f[:, 1], b[:, 0] + b[:, 1]
+  for tag, sup in (('fp32', sup_f), ('bf16', sup_b)):
+    assert sup[-5:].mean() < 0.8 * sup[:3].mean(), (tag, sup[:3].mean(), sup[-5:].mean())
+  dev = np.abs(sup_b - sup_f) / (np.abs(sup_f) + 1e-12)
+  print(f'bf16 vs fp32 depth+wc: max per-step deviation {dev.max():.3f} (step {int(dev.argmax())}), '
+        f'mean {dev.mean():.3f}; disc means {f[:, 2].mean():.4f} / {b[:, 2].mean():.4f}')
+  assert (np.abs(sup_b - sup_f) <= 0.15 * np.abs(sup_f) + 0.05).all(), dev
+  for col, name in ((0, 'depth'), (1, 'wc'), (2, 'disc')):
+    mf, mb = f[:, col].mean(), b[:, col].mean()
+    assert abs(mb - mf) <= 0.10 * abs(mf) + 1e-3, (name, mf, mb)
+
+
 # ======================================================================================= cfg2
 def _randomise_inference_state(G, batch=None, seed=4):
   """Non-trivial inference state: random affine values / biases, and batch-norm moving statistics
@@ -571,6 +629,19 @@ def test_cfg5_warp_1024x2048_two_views_bit_exact(depth_kind):
   np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
   np.testing.assert_array_equal(m_g.cpu().numpy()[..., None], warp_np.proj_mask(d_o, f_o, -1))
   assert 0.2 < float(m_g.mean()) <= 1.0
+  if depth_kind == 'random':
+    # ... and once against the INDEPENDENT NumPy / libm statement (oracle/warp_np.py shares no
+    # arithmetic with the kernels: np.arctan2 / np.arccos in binary64 rounded to fp32, NumPy
+    # scatter-min / max), so the largest configuration is not only checked twin-vs-twin
+    for (rgb, depth, pos), xg, fg in zip(panos, xs_g, fs_g):
+      xn, fn = warp_np.equirectangular_to_pointcloud(rgb, depth, -1, 20.0)
+      xn = (xn + np.concatenate([pos, np.zeros((1, 1), F32)], 1)[:, :, None]).astype(F32)
+      np.testing.assert_array_equal(xg.cpu().numpy(), xn)
+      np.testing.assert_array_equal(fg.cpu().numpy(), fn)
+    rel = (mem_x - np.concatenate([target, np.zeros((1, 1), F32)], 1)[:, :, None]).astype(F32)
+    d_n, f_n = warp_np.project_feats_to_equirectangular(mem_f, rel, h, w, -1, 20.0)
+    np.testing.assert_array_equal(d_g.cpu().numpy(), d_n)
+    np.testing.assert_array_equal(f_g.cpu().numpy(), f_n)
 
 
 def test_quantize_steps_bit_exact():
@@ -602,6 +673,15 @@ def test_quantize_steps_bit_exact():
   u8 = rgb.astype(np.uint8)
   np.testing.assert_array_equal(q(torch.from_numpy(u8).to(DEV), torch.int32, lo=0, hi=255).cpu().numpy(),
                                 rgb)
+  # edge cases of tf.clip_by_value / tf.cast: a NaN prediction stays NaN through a float clamp
+  # (a diverged roll-out must be visible), and the pure int32 -> uint8 cast (lo > hi) wraps
+  # modulo 256 (a -1 void class becomes 255), as NumPy's astype does
+  nan_in = torch.tensor([float('nan'), -0.5, 0.25, 1.5, float('inf'), -float('inf')], device=DEV)
+  got = q(nan_in, torch.float32, lo=0.0, hi=1.0).cpu().numpy()
+  assert np.isnan(got[0]) and got[1:].tolist() == [0.0, 0.25, 1.0, 1.0, 0.0]
+  sem = np.array([-1, 0, 41, 255, 256, 300, -2], np.int32)
+  np.testing.assert_array_equal(q(torch.from_numpy(sem).to(DEV), torch.uint8, lo=1, hi=0).cpu().numpy(),
+                                sem.astype(np.uint8))
 
 
 @pytest.mark.parametrize('n,void', [(1, -1), (2, 0)])

@@ -25,7 +25,14 @@ def test_bench_gpus_n_launches_n_ranks(monkeypatch):
     return R()
   monkeypatch.setattr(subprocess, 'run', fake_run)
   monkeypatch.delenv('WORLD_SIZE', raising=False)
+  monkeypatch.delenv('SE3DS_BENCH_BACKEND', raising=False)
   monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '2', '--warmup', '1'])
+  # fewer GPUs than ranks: fails fast with a clear message, nothing is launched
+  monkeypatch.setattr(bench.torch.cuda, 'device_count', lambda: 1)
+  with pytest.raises(SystemExit) as e:
+    bench.main()
+  assert e.value.code == 2 and not calls
+  monkeypatch.setattr(bench.torch.cuda, 'device_count', lambda: 4)
   with pytest.raises(SystemExit) as e:
     bench.main()
   assert e.value.code == 7

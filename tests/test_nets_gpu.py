@@ -957,6 +957,14 @@ def test_grad_sync_drip_feeds_buckets():
   assert not sync.pending and not sync.launched
   torch.cuda.synchronize()
   assert torch.equal(arena, ref)          # world size 1: the collective is skipped
+  # second step: the first step saw 1 collective-paced pump() call, so the pacing now empties the
+  # queue by that call instead of leaving it to finish()
+  assert sync.prev_seen == 1
+  sync.reduce_range(arena, 0, arena.numel())
+  assert len(sync.pending) == -(-arena.numel() // 1024) - 1
+  sync.pump()
+  assert not sync.pending
+  sync.finish()
   sync = dist_utils.GradSync(DEV, None, bucket_elems=1024, drip=False)
   sync.reduce_range(arena, 0, arena.numel())
   assert not sync.pending

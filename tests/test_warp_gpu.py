@@ -372,7 +372,8 @@ def test_fused_perspective_paths_match_the_op_chain(eq_h):
   equirect -> perspective-guidance kernels are bit-identical to the chain of the individual ops
   (project_perspective_image x2, cast, equirectangular_to_pointcloud; project + 3 x
   get_perspective_from_equirectangular_image + the mask / clip glue), each of which is tested
-  against the oracle on its own (test_perspective_and_rotation_paths)."""
+  against the oracle on its own (test_bilinear_and_resampling_paths); the direct oracle check of
+  the fused kernels is test_fused_perspective_paths_vs_oracle_notebook_chain below."""
   from se3ds_amd.models.models import _quantize
   rng = np.random.default_rng(60 + eq_h)
   ph, pw = 64, 64
@@ -411,3 +412,46 @@ def test_fused_perspective_paths_match_the_op_chain(eq_h):
   pi_f, pd_f, pm_f = pano_utils.perspective_guidance(pred_rgb[0], pred_depth[0], k, new_rot, ph, pw)
   assert torch.equal(pm_f, pm) and torch.equal(pd_f, pm * g_d) and torch.equal(pi_f, pm * g_rgb)
   assert 0.05 < float(pm_f.mean()) <= 1.0
+
+
+@pytest.mark.parametrize('eq_h', [128, 512])
+def test_fused_perspective_paths_vs_oracle_notebook_chain(eq_h):
+  """the fused kernels against the ORACLE's composition of RE10K notebook cells 15 and
+  17 (oracle/warp_np.notebook_cell15_pointcloud / notebook_cell17_guidance, which chain the
+  restatements of pano_utils.py:344-476 and :164-242).  The perspective paths are not bit-exact
+  against NumPy (3x3 fp32 products are not pinned to one summation order, see
+  test_bilinear_and_resampling_paths): cell 15 rounds its sampling coordinates to integers, so
+  points are IDENTICAL except where a coordinate sits within an ulp of a half-integer; cell 17's
+  bilinear gathers agree to 1e-4 except on the heading seam.  Both bars: > 99.5 % of the elements."""
+  rng = np.random.default_rng(70 + eq_h)
+  ph, pw = 64, 64
+  k = np.array([[32., 0., 32.], [0., 32., 32.], [0., 0., 1.]], F32)
+  rot = np.array([[0.99992853, -0.01185191, 0.00158339], [0.01187317, 0.9998291, -0.01416931],
+                  [-0.00141519, 0.01418709, 0.9998984]], F32)
+  rgb01 = (rng.integers(1, 256, (ph, pw, 3)).astype(F32) / F32(255)).astype(F32)
+  depth = rng.uniform(0.02, 0.2, (ph, pw)).astype(F32)
+  # ---- cell 15
+  xyz_o, f_o = warp_np.notebook_cell15_pointcloud(rgb01, depth, k, rot, eq_h)
+  xyz_g, f_g = pano_utils.perspective_to_pointcloud(t(rgb01), t(depth), eq_h, -1, 20.0,
+                                                    camera_intrinsics=k, rotation_matrix=rot,
+                                                    round_to_nearest=True)
+  xyz_g, f_g = xyz_g.cpu().numpy(), f_g.cpu().numpy()
+  assert xyz_g.shape == xyz_o.shape and f_g.shape == f_o.shape and f_g.dtype == f_o.dtype
+  same = np.all(xyz_g == xyz_o, axis=1)[0] & np.all(f_g == f_o, axis=-1)[0]
+  covered = f_o[0, :, 0] >= 0
+  assert covered.mean() > 0.02, covered.mean()             # the frustum covers part of the panorama
+  assert same.mean() > 0.995 and same[covered].mean() > 0.995, (same.mean(), same[covered].mean())
+  # ---- cell 17: splat the ORACLE's cloud with the oracle (one input for both guidance paths)
+  rel = np.array([[0.0, 0.01, 0.0]], F32)
+  ang = 15.0 / 180.0 * np.pi
+  new_rot = (rot.astype(np.float64) @ np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0],
+                                                [-np.sin(ang), 0, np.cos(ang)]])).astype(F32)
+  d_o, r_o = warp_c.project_feats_to_equirectangular(f_o, xyz_o, eq_h, 2 * eq_h, -1, 20.0, offset=rel)
+  want = warp_np.notebook_cell17_guidance(r_o[0], d_o[0], k, new_rot, ph, pw)
+  got = pano_utils.perspective_guidance(t(r_o[0]), t(d_o[0]), k, new_rot, ph, pw)
+  assert 0.05 < float(want[2].mean()) <= 1.0
+  for name, a, b in zip(('proj_image', 'proj_depth', 'proj_mask'), got, want):
+    a = a.cpu().numpy()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    close = np.abs(a - b).max(-1) <= 1e-4
+    assert close.mean() > 0.995, (name, close.mean())
