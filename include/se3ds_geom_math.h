@@ -158,27 +158,13 @@ SE3DS_HD int32_t se3ds_splat_index(float px, float py, float pz, int width, int 
  * Fast fp32 screen for the pixel index (device hot path; the host twin exists so that the
  * CPU tests can measure its error bound).  The binary64 transcendentals above cost several
  * hundred instructions per point.  The splat only needs them for trunc(fx), trunc(fy), so the
- * kernels first evaluate the same chain with the fp32 atan2 below (same table step, Taylor to
- * t^7, error a few fp32 ulps) and accept the index when fx and fy are farther than a margin
+ * kernels first evaluate the same chain with the fp32 atan2 below (error a few fp32 ulps) and
+ * accept the index when fx and fy are farther than a margin
  * from every integer -- then no integer lies between the fast and the exact value and
  * trunc / range tests agree.  Everything else takes the exact path.  The margin
  * SE3DS_FAST_MARGIN * size is >= 16x the largest deviation tests/test_oracle_warp.py measures.
  * z (= rad) does not depend on the transcendentals and is the same op in both paths. */
 #define SE3DS_FAST_MARGIN 4.0e-6f
-
-SE3DS_HD float se3ds_atan_tab_f32(int j) {
-  switch (j) {
-    case 0: return 0.0f;
-    case 1: return 0.12435499454676144f;
-    case 2: return 0.24497866312686414f;
-    case 3: return 0.35877067027057225f;
-    case 4: return 0.46364760900080609f;
-    case 5: return 0.55859931534356244f;
-    case 6: return 0.64350110879328437f;
-    case 7: return 0.71882999962162453f;
-    default: return 0.78539816339744828f;
-  }
-}
 
 /* Reciprocal / square root of the SCREEN only: on the device the 1-ulp hardware approximations
  * (v_rcp_f32 / v_sqrt_f32: one instruction instead of the ~10-instruction IEEE sequences), on the
@@ -194,7 +180,12 @@ SE3DS_HD float se3ds_atan_tab_f32(int j) {
 #define SE3DS_SCREEN_SQRT(x) __builtin_sqrtf(x)
 #endif
 
-/* fp32 atan2 for finite inputs, no signed-zero care (callers reject the degenerate cases). */
+/* fp32 atan2 for finite inputs, no signed-zero care (callers reject the degenerate cases).
+ * Round 3: octant reduction to q = a / b in [0, 1], then atan(q) = q * P(q^2) with a degree-7
+ * polynomial in q^2 (Chebyshev fit of atan(sqrt(s)) / sqrt(s) on [0, 1]; 1.7e-7 rad max error
+ * including the fp32 Horner rounding, measured on 2 M arguments) -- ONE reciprocal and no table
+ * (the round-2 version paid a second reciprocal and a 9-way select for its table step; the count
+ * pass of the splat is ALU-bound in exactly this function). */
 SE3DS_HD float se3ds_atan2_fast(float y, float x) {
   float ay = y < 0.0f ? -y : y;
   float ax = x < 0.0f ? -x : x;
@@ -202,15 +193,16 @@ SE3DS_HD float se3ds_atan2_fast(float y, float x) {
   float a = swap ? ax : ay;
   float b = swap ? ay : ax;
   float q = a * SE3DS_SCREEN_RCP(b); /* b == 0 -> NaN/inf -> the caller's margin test fails */
-  int j = (int)(q * 8.0f + 0.5f);
-  j = j > 8 ? 8 : (j < 0 ? 0 : j);
-  float c = (float)j * 0.125f;
-  float t = __builtin_fmaf(-c, b, a) * SE3DS_SCREEN_RCP(__builtin_fmaf(c, a, b));
-  float s = t * t;
-  float p = -1.0f / 7.0f;
-  p = __builtin_fmaf(p, s, 1.0f / 5.0f);
-  p = __builtin_fmaf(p, s, -1.0f / 3.0f);
-  float r = se3ds_atan_tab_f32(j) + __builtin_fmaf(t * s, p, t);
+  float s = q * q;
+  float p = -0.004668773151934147f;
+  p = __builtin_fmaf(p, s, 0.02416618913412094f);
+  p = __builtin_fmaf(p, s, -0.0593671016395092f);
+  p = __builtin_fmaf(p, s, 0.09906096756458282f);
+  p = __builtin_fmaf(p, s, -0.14016585052013397f);
+  p = __builtin_fmaf(p, s, 0.19969235360622406f);
+  p = __builtin_fmaf(p, s, -0.33331960439682007f);
+  p = __builtin_fmaf(p, s, 0.9999998807907104f);
+  float r = q * p;
   if (swap) r = 1.57079632679489661923f - r;
   if (x < 0.0f) r = 3.14159265358979323846f - r;
   return y < 0.0f ? -r : r;
@@ -245,10 +237,11 @@ SE3DS_HD void se3ds_equirect_fxy_fast(float x, float y, float z, int width, int 
   *fy = (elevation * 0.318309886183790672f) * (float)height; /* 1 / pi */
 }
 
-/* Fast screen: returns 1 and the index (or -1) when the fast evaluation decides it, 0 when the
- * point needs the exact path.  *pz is rad in either case. */
-SE3DS_HD int se3ds_equirect_index_fast(float x, float y, float z, int width, int height,
-                                       int feat_valid, int32_t* idx, float* pz) {
+/* Fast screen: returns 1 when the fast evaluation decides the point, 0 when it needs the exact
+ * path.  Decided: *ok says whether it is a valid splat (in bounds, features valid) and (*u, *v) is
+ * its pixel.  *pz is rad in either case. */
+SE3DS_HD int se3ds_equirect_uv_fast(float x, float y, float z, int width, int height,
+                                    int feat_valid, int* u, int* v, int* ok, float* pz) {
   float fx, fy;
   se3ds_equirect_fxy_fast(x, y, z, width, height, &fx, &fy, pz);
   float rad = *pz;
@@ -259,9 +252,18 @@ SE3DS_HD int se3ds_equirect_index_fast(float x, float y, float z, int width, int
   int decided = (dx > SE3DS_FAST_MARGIN * (float)width) &&
                 (dy > SE3DS_FAST_MARGIN * (float)height) && (rad > 1.0e-30f) && (rad < 1.0e30f);
   if (!decided) return 0;
-  int ok = (fx > -1.0f) && (fx < (float)width) && (fy > -1.0f) && (fy < (float)height) &&
-           feat_valid;
-  *idx = ok ? (int32_t)fy * width + (int32_t)fx : -1;
+  *ok = (fx > -1.0f) && (fx < (float)width) && (fy > -1.0f) && (fy < (float)height) && feat_valid;
+  *u = (int)fx;
+  *v = (int)fy;
+  return 1;
+}
+
+/* ... the same, returning the flat index v * width + u (or -1). */
+SE3DS_HD int se3ds_equirect_index_fast(float x, float y, float z, int width, int height,
+                                       int feat_valid, int32_t* idx, float* pz) {
+  int u = 0, v = 0, ok = 0;
+  if (!se3ds_equirect_uv_fast(x, y, z, width, height, feat_valid, &u, &v, &ok, pz)) return 0;
+  *idx = ok ? (int32_t)v * width + (int32_t)u : -1;
   return 1;
 }
 

@@ -33,6 +33,14 @@ extern "C" {
 #define SE3DS_I32 1
 #define SE3DS_U8 2
 #define SE3DS_BF16 3
+/* OR-ed into the `feat_dtype` of the splat entry points (se3ds_project_equirect*,
+ * se3ds_project_to_feat) together with SE3DS_I32: the caller PROMISES that every feature of a
+ * valid point -- one whose channels all differ from `input_void` -- is an integer in [0, 255]
+ * (RGB memories: int32 in [-1, 255] with void -1, reference models/models.py:127-134,325-331).
+ * The splat then moves 8-byte packed records instead of 20-byte ones.  SE3DS_U8 features need no
+ * promise.  A broken promise is detected (se3ds_splat_promise_broken) but the outputs of that
+ * call are undefined. */
+#define SE3DS_FEAT_BYTE_RANGE 0x100
 
 /* Library / build identification: returns a static string "se3ds_hip <abi> gfx950". */
 const char* se3ds_version(void);
@@ -84,6 +92,16 @@ int se3ds_project_equirect(const float* xyz1, const float* offset, const void* f
                            float depth_scale, float input_void, float output_void, float* depth,
                            float* feat, float* mask, float mask_void, void* workspace,
                            size_t workspace_bytes, void* stream);
+
+/* Number of elements of an int32 / uint8 feature array that are neither `void_class` nor an
+ * integer in [0, 255]: 0 means SE3DS_FEAT_BYTE_RANGE may be promised for it.  *bad_out is a
+ * device uint32 (written, not accumulated). */
+int se3ds_feats_byte_range(const void* feats, int feat_dtype, int64_t count, float void_class,
+                           uint32_t* bad_out, void* stream);
+/* After a packed splat call (same workspace, same n / m): *broken_out (device uint32) = 1 if a
+ * valid point violated the SE3DS_FEAT_BYTE_RANGE promise, else 0. */
+int se3ds_splat_promise_broken(const void* workspace, int n, int64_t m, uint32_t* broken_out,
+                               void* stream);
 
 /* The same over the first `m` points of a preallocated point-cloud MEMORY of `capacity` points
  * per image -- xyz1 (N,4,capacity), feats (N,capacity,C) -- so that a trajectory appends frames in

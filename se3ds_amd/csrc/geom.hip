@@ -7,6 +7,8 @@
 // Reference semantics: utils/pano_utils.py, utils/point_cloud_utils.py (see the per-entry
 // citations in include/se3ds_hip.h).  Index math lives in include/se3ds_geom_math.h and is
 // shared bit-for-bit with the CPU oracle.  Built with -ffp-contract=off.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/se3ds_geom_math.h"
 
@@ -1395,14 +1397,760 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
   return check_launch("splat(binned)");
 }
 
+// ------------------------------------------------------------ packed splat (round 3, 8-byte records)
+// The three-pass binned splat above moves 3x its algorithmic bytes: (idx, z) per point written and
+// re-read (16 B), 20-byte 4-byte-aligned records written with five scattered dword stores and read
+// back with dword loads, the features read twice.  When the features of every VALID point are
+// integers in [0, 255] (uint8 features, or int32 features under the caller's SE3DS_FEAT_BYTE_RANGE
+// promise: RGB memories hold [-1, 255] with void -1) and there are at most 3 channels, a record
+// fits 64 bits -- 9-bit pixel inside a 16 x 32 tile, 31-bit z (valid => z > 0: the sign bit is
+// free), 3 x 8-bit features -- and the passes become:
+//   P1 pack + count : coordinates and features are read ONCE (16-byte loads, 4 consecutive points
+//                     per thread), the fp32 screen / binary64 queue decide the pixel, and the point's
+//                     final record (8 B) and tile number (2 B) are written in point order with
+//                     16-byte stores; one histogram row per chunk; the invalid points' sink partials.
+//   P2 column scan  : as before, and its last workgroup to finish also scans the tile totals
+//                     (tile_start) and builds the resolve's item table, so no consumer rescans.
+//   P3 permute      : a pure 8-byte permutation into tile order (no feature reads).
+//   P4 resolve      : one 256-thread workgroup per 512-pixel tile item, 8 KB of LDS, records in
+//                     registers between the z-min and the feature pass; the last workgroup to
+//                     finish folds the sink into flat pixel 0 (no separate launch).
+// Results are bit-identical to the other paths (min / max do not depend on the record order).
+constexpr int kPTileY = 16, kPTileX = 32, kPTilePx = kPTileY * kPTileX;   // 512 px
+constexpr int kPThreads = 512, kPPts = 4;
+constexpr int kPGroup = kPThreads * kPPts;     // points per workgroup iteration
+constexpr int kPResolveThreads = 256;
+constexpr int kPStash = 4;                     // records per thread kept in registers
+constexpr uint32_t kPSlice = 4096;             // records per band workgroup aimed at
+constexpr int kPMaxChannels = 3;
+constexpr uint16_t kNoTile = 0xffffu;
+constexpr uint16_t kPendingTile = 0xfffeu;   // undecided by the fp32 screen: the exact pass fills it in
+
+struct PackWs {
+  uint32_t* ctl;          // [8]: 0 colscan tickets, 1 promise violations, 2 items, 3 resolve tickets
+  uint32_t* tile_count;   // [nb]
+  uint32_t* tile_start;   // [nb + 1] exclusive prefix of tile_count
+  uint32_t* items;        // [items_max]  tile | band << 20 | log2(bands) << 24
+  uint32_t* hist;         // [n][chunks][ntiles]
+  uint32_t* fpart2;       // [items_max][C]
+  uint16_t* tile_pt;      // [n][mp]  tile of the point, kNoTile: no record
+  uint64_t* rec_pt;       // [n][mp]  records in point order
+  uint64_t* rec;          // [n * m]  records in tile order
+  int64_t mp;             // padded points per image (chunks * per)
+};
+__host__ __device__ inline ChunkGeom pack_geom(int64_t m, int n) {
+  int64_t cap = kMaxSinkBlocks / (n > 0 ? n : 1);
+  cap = cap < 1 ? 1 : (cap > kMaxChunks ? kMaxChunks : cap);
+  int64_t chunks = (m + kChunkPoints - 1) / kChunkPoints;
+  chunks = chunks < 1 ? 1 : (chunks > cap ? cap : chunks);
+  int64_t per = (m + chunks - 1) / chunks;
+  per = (per + kPGroup - 1) / kPGroup * kPGroup;
+  if (per < kPGroup) per = kPGroup;
+  chunks = (m + per - 1) / per;
+  ChunkGeom g;
+  g.chunks = (int)(chunks < 1 ? 1 : chunks);
+  g.per = per;
+  return g;
+}
+inline uint32_t pack_slice() {
+  static const uint32_t v = [] {
+    const char* e = getenv("SE3DS_SPLAT_SLICE");
+    const long x = e ? atol(e) : 0;
+    return (uint32_t)(x >= 16 ? x : (long)kPSlice);
+  }();
+  return v;
+}
+inline size_t pack_ws_bytes(int n, int64_t m, int height, int width) {
+  const size_t ntiles = (size_t)ceil_div(height, kPTileY) * ceil_div(width, kPTileX);
+  const size_t nb = (size_t)n * ntiles;
+  const ChunkGeom g = pack_geom(m, n);
+  const size_t mp = (size_t)g.chunks * (size_t)g.per;
+  const size_t items = (size_t)resolve_items_max((int64_t)nb, (int64_t)n * (m > 0 ? m : 0), pack_slice());
+  return 64 + align16(4 * nb) + align16(4 * (nb + 1)) + align16(4 * items) +
+         align16(4 * nb * (size_t)g.chunks) + align16(4 * items * kPMaxChannels) +
+         align16(2 * (size_t)n * mp) + align16(8 * (size_t)n * mp) +
+         align16(8 * (size_t)n * (size_t)(m > 0 ? m : 0));
+}
+inline PackWs carve_pack_ws(void* base, int n, int64_t m, int height, int width) {
+  const size_t ntiles = (size_t)ceil_div(height, kPTileY) * ceil_div(width, kPTileX);
+  const size_t nb = (size_t)n * ntiles;
+  const ChunkGeom g = pack_geom(m, n);
+  const size_t mp = (size_t)g.chunks * (size_t)g.per;
+  const size_t items = (size_t)resolve_items_max((int64_t)nb, (int64_t)n * (m > 0 ? m : 0), pack_slice());
+  char* p = (char*)base;
+  PackWs w;
+  w.ctl = (uint32_t*)p; p += 64;
+  w.tile_count = (uint32_t*)p; p += align16(4 * nb);
+  w.tile_start = (uint32_t*)p; p += align16(4 * (nb + 1));
+  w.items = (uint32_t*)p; p += align16(4 * items);
+  w.hist = (uint32_t*)p; p += align16(4 * nb * (size_t)g.chunks);
+  w.fpart2 = (uint32_t*)p; p += align16(4 * items * kPMaxChannels);
+  w.tile_pt = (uint16_t*)p; p += align16(2 * (size_t)n * mp);
+  w.rec_pt = (uint64_t*)p; p += align16(8 * (size_t)n * mp);
+  w.rec = (uint64_t*)p;
+  w.mp = (int64_t)mp;
+  return w;
+}
+
+// record = [ z bits (31) | pixel bit 8 ] [ pixel bits 0-7 | f0 | f1 | f2 ]
+__device__ __forceinline__ uint64_t pack_rec(uint32_t pix, float z, uint32_t f0, uint32_t f1, uint32_t f2) {
+  const uint32_t lo = __float_as_uint(z) | ((pix >> 8) << 31);
+  const uint32_t hi = ((pix & 255u) << 24) | (f0 << 16) | (f1 << 8) | f2;
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t rec_pix(uint64_t r) {
+  return (uint32_t)(r >> 56) | (((uint32_t)r >> 31) << 8);
+}
+__device__ __forceinline__ uint32_t rec_zbits(uint64_t r) { return (uint32_t)r & 0x7fffffffu; }
+__device__ __forceinline__ uint32_t rec_feat(uint64_t r, int k) {
+  return ((uint32_t)(r >> 32) >> (16 - 8 * k)) & 255u;
+}
+
+// 4 consecutive elements of a feature array as floats (through the type's conversion) and raw
+template <typename T> struct Feat4;
+template <> struct Feat4<int32_t> {
+  static __device__ __forceinline__ void load(const int32_t* p, bool vec, int32_t (&o)[4]) {
+    if (vec) {
+      const int4 v = *reinterpret_cast<const int4*>(p);
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+      for (int e = 0; e < 4; ++e) o[e] = p[e];
+    }
+  }
+};
+template <> struct Feat4<uint8_t> {
+  static __device__ __forceinline__ void load(const uint8_t* p, bool vec, int32_t (&o)[4]) {
+    if (vec) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(p);
+      o[0] = v & 255u; o[1] = (v >> 8) & 255u; o[2] = (v >> 16) & 255u; o[3] = v >> 24;
+    } else {
+      for (int e = 0; e < 4; ++e) o[e] = p[e];
+    }
+  }
+};
+
+// P1.  T in {int32_t, uint8_t}; C = channels (1..3).  vec: 16-byte loads are legal (ld % 4 == 0,
+// aligned bases).  DEBUG also writes the (idx, z) parity tap.
+template <typename T, bool EQUIRECT, int C, bool DEBUG>
+__global__ void __launch_bounds__(kPThreads)
+splat_pack_count_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
+                        const T* __restrict__ feats, int64_t m, int64_t ld, int64_t per, int height,
+                        int width, uint64_t wmagic, float input_void, int ntiles, int tiles_x,
+                        int vec, SplatWs ws, PackWs pw) {
+  extern __shared__ uint32_t s_hist[];   // [ntiles]
+  __shared__ uint32_t s_queue[kExactQueue];
+  __shared__ uint32_t s_qn;
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < ntiles; t += kPThreads) s_hist[t] = 0u;
+  if (threadIdx.x == 0) {
+    s_qn = 0u;
+    if (blockIdx.x == 0 && b == 0) {   // tickets of the later passes (this kernel runs first)
+      pw.ctl[0] = 0u;
+      pw.ctl[1] = 0u;
+      pw.ctl[3] = 0u;
+    }
+  }
+  __syncthreads();
+  const float* X = coords + (int64_t)b * 4 * ld;
+  const T* F = feats + (int64_t)b * ld * C;
+  float ox = 0.f, oy = 0.f, oz = 0.f;
+  if (EQUIRECT && offset) {
+    ox = offset[b * 3 + 0];
+    oy = offset[b * 3 + 1];
+    oz = offset[b * 3 + 2];
+  }
+  uint32_t sink = 0xffffffffu;   // ordered min z of the invalid points
+  uint32_t smax[C];              // ordered max feature of the invalid points, per channel
+#pragma unroll
+  for (int k = 0; k < C; ++k) smax[k] = 0u;
+  uint32_t bad = 0u;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
+  uint64_t* R = pw.rec_pt + (int64_t)b * pw.mp;
+  uint16_t* TP = pw.tile_pt + (int64_t)b * pw.mp;
+
+  // a point whose pixel (u, v) is known: histogram + record; invalid: sink partials
+  auto emit = [&](bool valid, int u, int v, float pz, const int32_t (&f)[C], uint64_t* rec,
+                  uint32_t* tile) {
+    if (valid) {
+      const int ty = v / kPTileY, tx = u / kPTileX;
+      const uint32_t t = (uint32_t)(ty * tiles_x + tx);
+      const uint32_t pix = (uint32_t)((v - ty * kPTileY) * kPTileX + (u - tx * kPTileX));
+      atomicAdd(&s_hist[t], 1u);
+      uint32_t fb[3] = {0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        fb[k] = (uint32_t)f[k] & 255u;
+        bad |= (uint32_t)f[k] >> 8;   // the byte-range promise (negative or > 255)
+      }
+      *rec = pack_rec(pix, pz, fb[0], fb[1], fb[2]);
+      *tile = t;
+    } else {
+      if (pz == pz) {
+        const uint32_t o = se3ds_f32_to_ordered(pz);
+        sink = o < sink ? o : sink;
+      }
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const uint32_t o = se3ds_f32_to_ordered((float)f[k]);
+        smax[k] = o > smax[k] ? o : smax[k];
+      }
+      *rec = 0ull;
+      *tile = kNoTile;
+    }
+  };
+  auto feat_valid = [&](const int32_t (&f)[C]) {
+    int v = 1;
+#pragma unroll
+    for (int k = 0; k < C; ++k) v &= ((float)f[k] != input_void);
+    return v;
+  };
+  auto exact = [&](int64_t i, float x, float y, float z, const int32_t (&f)[C], uint64_t* rec,
+                   uint32_t* tile) {
+    float px, py, pz;
+    if (EQUIRECT) {
+      se3ds_equirect_project(x, y, z, &px, &py, &pz);
+    } else {
+      px = x;
+      py = y;
+      pz = z;
+    }
+    const int32_t idx = se3ds_splat_index(px, py, pz, width, height, feat_valid(f));
+    int u = 0, v = 0;
+    if (idx >= 0) {
+      v = (int)(((uint64_t)(uint32_t)idx * wmagic) >> 40);
+      u = idx - v * width;
+    }
+    emit(idx >= 0, u, v, pz, f, rec, tile);
+    if (DEBUG) {
+      ws.idx[(int64_t)b * m + i] = idx;
+      ws.z[(int64_t)b * m + i] = pz;
+    }
+  };
+
+  for (int64_t i0 = lo + (int64_t)threadIdx.x * kPPts; i0 < hi; i0 += kPGroup) {
+    float x[kPPts], y[kPPts], z[kPPts];
+    int32_t f[kPPts][C];
+    const bool full = i0 + kPPts <= hi;
+    if (full && vec) {
+      const float4 vx = *reinterpret_cast<const float4*>(X + i0);
+      const float4 vy = *reinterpret_cast<const float4*>(X + ld + i0);
+      const float4 vz = *reinterpret_cast<const float4*>(X + 2 * ld + i0);
+      x[0] = vx.x; x[1] = vx.y; x[2] = vx.z; x[3] = vx.w;
+      y[0] = vy.x; y[1] = vy.y; y[2] = vy.z; y[3] = vy.w;
+      z[0] = vz.x; z[1] = vz.y; z[2] = vz.z; z[3] = vz.w;
+      int32_t flat[kPPts * C];
+#pragma unroll
+      for (int q = 0; q < C; ++q) {
+        int32_t o[4];
+        Feat4<T>::load(F + i0 * C + 4 * q, true, o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) flat[4 * q + e] = o[e];
+      }
+#pragma unroll
+      for (int p = 0; p < kPPts; ++p)
+#pragma unroll
+        for (int k = 0; k < C; ++k) f[p][k] = flat[p * C + k];
+    } else {
+#pragma unroll
+      for (int p = 0; p < kPPts; ++p) {
+        const int64_t i = i0 + p < hi ? i0 + p : hi - 1;   // (the tail repeats the last point)
+        x[p] = X[i];
+        y[p] = X[ld + i];
+        z[p] = X[2 * ld + i];
+#pragma unroll
+        for (int k = 0; k < C; ++k) f[p][k] = (int32_t)F[i * C + k];
+      }
+    }
+    uint64_t rec[kPPts];
+    uint32_t tile[kPPts];
+#pragma unroll
+    for (int p = 0; p < kPPts; ++p) {
+      rec[p] = 0ull;
+      tile[p] = kNoTile;
+      if (i0 + p >= hi) continue;
+      float px = x[p], py = y[p], pzz = z[p];
+      if (EQUIRECT && offset) {
+        px = px - ox;
+        py = py - oy;
+        pzz = pzz - oz;
+      }
+      if (EQUIRECT) {
+        int u = 0, v = 0, ok = 0;
+        float pz;
+        if (se3ds_equirect_uv_fast(px, py, pzz, width, height, feat_valid(f[p]), &u, &v, &ok, &pz)) {
+          emit(ok != 0, u, v, pz, f[p], &rec[p], &tile[p]);
+          if (DEBUG) {
+            ws.idx[(int64_t)b * m + i0 + p] = ok ? v * width + u : -1;
+            ws.z[(int64_t)b * m + i0 + p] = pz;
+          }
+        } else {
+          // undecided (~2.5 %): marked, and queued for the dense binary64 pass below (a divergent
+          // fallback here would make nearly every wave pay the ~700-instruction chain, and inlining
+          // it four times doubles the kernel's register count)
+          tile[p] = kPendingTile;
+          const uint32_t slot = atomicAdd(&s_qn, 1u);
+          if (slot < (uint32_t)kExactQueue) s_queue[slot] = (uint32_t)(i0 + p - lo);
+        }
+      } else {
+        exact(i0 + p, px, py, pzz, f[p], &rec[p], &tile[p]);
+      }
+    }
+    // point-order records: 2 x 16 bytes + 8 bytes of tile numbers per thread (the arrays are
+    // padded to whole groups, so the tail stores land in the padding)
+    uint4* rp = reinterpret_cast<uint4*>(R + i0);
+    rp[0] = make_uint4((uint32_t)rec[0], (uint32_t)(rec[0] >> 32), (uint32_t)rec[1], (uint32_t)(rec[1] >> 32));
+    rp[1] = make_uint4((uint32_t)rec[2], (uint32_t)(rec[2] >> 32), (uint32_t)rec[3], (uint32_t)(rec[3] >> 32));
+    *reinterpret_cast<uint2*>(TP + i0) = make_uint2(tile[0] | (tile[1] << 16), tile[2] | (tile[3] << 16));
+  }
+  if (EQUIRECT) {
+    __syncthreads();   // (also orders the group stores above before the queue's single stores)
+    // queue overflow (> 25 % undecided: lattice clouds): sweep the whole chunk for the marks
+    const bool sweep = s_qn > (uint32_t)kExactQueue;
+    const uint32_t qn = sweep ? (uint32_t)(hi - lo) : s_qn;
+    for (uint32_t q = threadIdx.x; q < qn; q += kPThreads) {
+      const int64_t i = lo + (sweep ? q : s_queue[q]);
+      if (sweep && TP[i] != kPendingTile) continue;
+      float x = X[i], y = X[ld + i], z = X[2 * ld + i];
+      if (offset) {
+        x = x - ox;
+        y = y - oy;
+        z = z - oz;
+      }
+      int32_t f[C];
+#pragma unroll
+      for (int k = 0; k < C; ++k) f[k] = (int32_t)F[i * C + k];
+      uint64_t rec;
+      uint32_t tile;
+      exact(i, x, y, z, f, &rec, &tile);
+      R[i] = rec;
+      TP[i] = (uint16_t)tile;
+    }
+  }
+  __shared__ uint32_t s_red[1 + C][kPThreads / 64];
+  sink = wave_min_u32(sink);
+  bad = wave_max_u32(bad);
+  if ((threadIdx.x & 63) == 0) s_red[0][threadIdx.x >> 6] = sink;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const uint32_t v = wave_max_u32(smax[k]);
+    if ((threadIdx.x & 63) == 0) s_red[1 + k][threadIdx.x >> 6] = v;
+  }
+  if ((threadIdx.x & 63) == 0 && bad != 0u) atomicOr(&pw.ctl[1], 1u);
+  __syncthreads();
+  const int part = blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0) {
+    uint32_t v = s_red[0][0];
+    for (int i = 1; i < kPThreads / 64; ++i) v = s_red[0][i] < v ? s_red[0][i] : v;
+    ws.zpart[part] = v;
+  }
+  if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + C) {
+    const int k = threadIdx.x - 64;
+    uint32_t v = 0u;
+    for (int i = 0; i < kPThreads / 64; ++i) v = s_red[1 + k][i] > v ? s_red[1 + k][i] : v;
+    ws.fpart[(int64_t)part * C + k] = v;
+  }
+  uint32_t* row = pw.hist + ((int64_t)b * gridDim.x + blockIdx.x) * ntiles;
+  for (int t = threadIdx.x; t < ntiles; t += kPThreads) row[t] = s_hist[t];
+}
+
+// P2.  Column scan as splat_bin_colscan_kernel, then (P2b, one workgroup) the exclusive scan of the
+// tile totals into tile_start[0 .. nb] and the resolve's item table (a tile with more than `slice`
+// records is cut into 2 / 4 / 8 bands of rows).  Measured and rejected: doing P2b in the last
+// workgroup of P2 to finish (ticket + __threadfence) -- on this multi-XCD part an agent-scope
+// release is an L2 write-back per workgroup: 51 us for P2, 613 us for a resolve with the same
+// pattern.
+__global__ void __launch_bounds__(64 * kScanWaves)
+splat_pack_colscan_kernel(PackWs pw, int chunks, int ntiles, int nb) {
+  __shared__ uint32_t s_sum[kScanWaves][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int gt = blockIdx.x * 64 + lane;
+  const bool ok = gt < nb;
+  const int b = ok ? gt / ntiles : 0, t = ok ? gt - b * ntiles : 0;
+  const int rows = ceil_div(chunks, kScanWaves);
+  const int c0 = w * rows, c1 = c0 + rows < chunks ? c0 + rows : chunks;
+  uint32_t* H = pw.hist + (int64_t)b * chunks * ntiles + t;
+  uint32_t sum = 0;
+  if (ok) {
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) sum += H[(int64_t)c * ntiles];
+  }
+  s_sum[w][lane] = sum;
+  __syncthreads();
+  uint32_t run = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < kScanWaves; ++i) {
+    const uint32_t v = s_sum[i][lane];
+    if (i < w) run += v;
+    total += v;
+  }
+  if (ok) {
+#pragma unroll 8
+    for (int c = c0; c < c1; ++c) {
+      const uint32_t v = H[(int64_t)c * ntiles];
+      H[(int64_t)c * ntiles] = run;
+      run += v;
+    }
+    if (w == 0) pw.tile_count[gt] = total;
+  }
+}
+
+__global__ void __launch_bounds__(64 * kScanWaves)
+splat_pack_tilescan_kernel(PackWs pw, int nb, uint32_t slice) {
+  __shared__ uint32_t s_w[kScanWaves];
+  constexpr int NT = 64 * kScanWaves;
+  const int per = ceil_div(nb, NT);
+  const int t0 = threadIdx.x * per, t1 = t0 + per < nb ? t0 + per : nb;
+  uint32_t sum_c = 0, sum_s = 0;
+  for (int i = t0; i < t1; ++i) {
+    const uint32_t c = pw.tile_count[i];
+    sum_c += c;
+    sum_s += 1u << tile_bands_log2(c, slice);
+  }
+  uint32_t tot_c, tot_s;
+  uint32_t run_c = block_excl_scan_u32<kScanWaves>(sum_c, s_w, &tot_c);
+  uint32_t run_s = block_excl_scan_u32<kScanWaves>(sum_s, s_w, &tot_s);
+  for (int i = t0; i < t1; ++i) {
+    const uint32_t c = pw.tile_count[i];
+    const int lg = tile_bands_log2(c, slice);
+    pw.tile_start[i] = run_c;
+    for (uint32_t band = 0; band < (1u << lg); ++band)
+      pw.items[run_s + band] = (uint32_t)i | (band << 20) | ((uint32_t)lg << 24);
+    run_c += c;
+    run_s += 1u << lg;
+  }
+  if (threadIdx.x == 0) {
+    pw.tile_start[nb] = tot_c;
+    pw.ctl[2] = tot_s;
+  }
+}
+
+// P3.  Pure permutation: point-order records -> tile order.
+__global__ void __launch_bounds__(kPThreads)
+splat_pack_permute_kernel(int64_t m, int64_t per, int ntiles, PackWs pw) {
+  extern __shared__ uint32_t s_base[];   // [ntiles] next free record of this chunk, per tile
+  const int b = blockIdx.y;
+  {
+    const uint32_t* start = pw.tile_start + (int64_t)b * ntiles;
+    const uint32_t* row = pw.hist + ((int64_t)b * gridDim.x + blockIdx.x) * ntiles;
+    for (int t = threadIdx.x; t < ntiles; t += kPThreads) s_base[t] = start[t] + row[t];
+  }
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
+  const uint64_t* R = pw.rec_pt + (int64_t)b * pw.mp;
+  const uint16_t* TP = pw.tile_pt + (int64_t)b * pw.mp;
+  constexpr int kU = 2;   // two groups of 4 points in flight per thread
+  for (int64_t i0 = lo + (int64_t)threadIdx.x * kPPts; i0 < hi; i0 += kU * kPGroup) {
+    uint4 ra[kU], rb[kU];
+    uint2 tl[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int64_t i = i0 + (int64_t)u * kPGroup;
+      const int64_t j = i < hi ? i : lo;   // (padded arrays: whole groups are readable)
+      const uint4* rp = reinterpret_cast<const uint4*>(R + j);
+      ra[u] = rp[0];
+      rb[u] = rp[1];
+      tl[u] = *reinterpret_cast<const uint2*>(TP + j);
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      if (i0 + (int64_t)u * kPGroup >= hi) continue;
+      const uint32_t t[4] = {tl[u].x & 0xffffu, tl[u].x >> 16, tl[u].y & 0xffffu, tl[u].y >> 16};
+      const uint64_t r[4] = {((uint64_t)ra[u].y << 32) | ra[u].x, ((uint64_t)ra[u].w << 32) | ra[u].z,
+                             ((uint64_t)rb[u].y << 32) | rb[u].x, ((uint64_t)rb[u].w << 32) | rb[u].z};
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (t[p] != kNoTile) pw.rec[atomicAdd(&s_base[t[p]], 1u)] = r[p];
+    }
+  }
+}
+
+// P4.  One workgroup per resolve item (tile, band of rows).
+template <int C>
+__global__ void __launch_bounds__(kPResolveThreads)
+splat_pack_resolve_kernel(int height, int width, int ntiles, int tiles_x, float depth_scale,
+                          float output_void, float mask_void, float* __restrict__ depth,
+                          float* __restrict__ feat, float* __restrict__ mask, SplatWs ws, PackWs pw,
+                          uint32_t zpart_count, uint32_t items_max) {
+  __shared__ uint32_t s_z[kPTilePx];
+  __shared__ uint32_t s_fe[C][kPTilePx];
+  __shared__ uint32_t s_w[kPResolveThreads / 64];
+  __shared__ uint32_t s_c[C][kPResolveThreads / 64];
+  const uint32_t item = blockIdx.x;
+  const uint32_t nitems = pw.ctl[2];
+  if (item < nitems) {
+    const uint32_t it = pw.items[item];
+    const int bt = (int)(it & 0xfffffu), band = (int)((it >> 20) & 15u), lg = (int)(it >> 24);
+    const int band_shift = 4 - lg;   // rows per band = 16 >> log2(bands)
+    const bool banded = lg != 0;
+    const uint32_t r0 = pw.tile_start[bt], r1 = pw.tile_start[bt + 1];
+    const int b = bt / ntiles, t = bt - b * ntiles;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    auto mine = [&](uint32_t li) { return !banded || (int)((li >> 5) >> band_shift) == band; };
+    const bool first = bt == 0 && band == 0;   // holds flat pixel 0, which also receives the sink
+    uint32_t sink_o = 0xffffffffu;
+    if (first) {
+      uint32_t v = 0xffffffffu;
+      for (uint32_t i = threadIdx.x; i < zpart_count; i += kPResolveThreads) {
+        const uint32_t z = ws.zpart[i];
+        v = z < v ? z : v;
+      }
+      v = wave_min_u32(v);
+      if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+      __syncthreads();
+      for (int i = 0; i < kPResolveThreads / 64; ++i) sink_o = s_w[i] < sink_o ? s_w[i] : sink_o;
+    }
+    const bool have_sink_z = sink_o != 0xffffffffu;
+    const float sink_z = se3ds_ordered_to_f32(sink_o);
+    for (int p = threadIdx.x; p < kPTilePx; p += kPResolveThreads) {
+      s_z[p] = __float_as_uint(depth_scale);
+#pragma unroll
+      for (int k = 0; k < C; ++k) s_fe[k][p] = 0u;
+    }
+    __syncthreads();
+    // pass A: z-min; a thread's first kPStash records stay in registers for pass B
+    uint64_t st[kPStash];
+#pragma unroll
+    for (int k = 0; k < kPStash; ++k) {
+      const uint32_t q = r0 + threadIdx.x + k * kPResolveThreads;
+      st[k] = q < r1 ? pw.rec[q] : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < kPStash; ++k) {
+      const uint32_t q = r0 + threadIdx.x + k * kPResolveThreads;
+      const uint32_t li = rec_pix(st[k]);
+      if (q < r1 && mine(li)) atomicMin(&s_z[li], rec_zbits(st[k]));   // valid => z > 0
+    }
+    const uint32_t rest = r0 + threadIdx.x + kPStash * kPResolveThreads;
+    for (uint32_t q0 = rest; q0 < r1; q0 += 4 * kPResolveThreads) {
+      uint64_t r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t q = q0 + u * kPResolveThreads;
+        r[u] = q < r1 ? pw.rec[q] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t li = rec_pix(r[u]);
+        if (q0 + u * kPResolveThreads < r1 && mine(li)) atomicMin(&s_z[li], rec_zbits(r[u]));
+      }
+    }
+    __syncthreads();
+    // pass B: survivors (z < zmin + 0.1) max their features; the rest feed the sink
+    uint32_t smax[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) smax[k] = 0u;
+    auto passb = [&](uint64_t r) {
+      const uint32_t li = rec_pix(r);
+      if (!mine(li)) return;
+      const float z = __uint_as_float(rec_zbits(r));
+      float zm = __uint_as_float(s_z[li]);
+      if (first && li == 0 && have_sink_z) zm = sink_z < zm ? sink_z : zm;
+      const bool keep = z < zm + 0.1f;
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const uint32_t fv = rec_feat(r, k);
+        if (keep) {
+          if (fv != 0u) atomicMax(&s_fe[k][li], fv);
+        } else {
+          const uint32_t o = se3ds_f32_to_ordered((float)fv);
+          smax[k] = o > smax[k] ? o : smax[k];
+        }
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < kPStash; ++k)
+      if (r0 + threadIdx.x + k * kPResolveThreads < r1) passb(st[k]);
+    for (uint32_t q0 = rest; q0 < r1; q0 += 4 * kPResolveThreads) {
+      uint64_t r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t q = q0 + u * kPResolveThreads;
+        r[u] = q < r1 ? pw.rec[q] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u * kPResolveThreads < r1) passb(r[u]);
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const uint32_t v = wave_max_u32(smax[k]);
+      if ((threadIdx.x & 63) == 0) s_c[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+      uint32_t v = 0u;
+      for (int i = 0; i < kPResolveThreads / 64; ++i) v = s_c[threadIdx.x][i] > v ? s_c[threadIdx.x][i] : v;
+      pw.fpart2[(int64_t)item * C + threadIdx.x] = v;
+    }
+    // finalize this item's pixels
+    const int64_t hw = (int64_t)height * width;
+    for (int p = threadIdx.x; p < kPTilePx; p += kPResolveThreads) {
+      const int y = ty * kPTileY + p / kPTileX, x = tx * kPTileX + (p % kPTileX);
+      if (y >= height || x >= width || !mine((uint32_t)p)) continue;
+      const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
+      float z = __uint_as_float(s_z[p]);
+      if (i == 0 && have_sink_z) z = sink_z < z ? sink_z : z;
+      float d = z < 0.0f ? 0.0f : (z > depth_scale ? depth_scale : z);
+      d = d / depth_scale;
+      depth[i] = d;
+      bool all_ok = true;
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        // scatter_max over fill(output_void >= 0): a feature of 0 and "no survivor" coincide
+        const float fv = (float)s_fe[k][p];
+        const float v = fv > output_void ? fv : output_void;
+        feat[i * C + k] = v;
+        all_ok = all_ok && (v != mask_void);
+      }
+      if (mask) mask[i] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+    }
+  }
+}
+
+// P5 (one workgroup).  Folds the sink features into flat pixel 0 (point_cloud_utils.py:151-152:
+// invalid and occluded points scatter into flat index 0) and redoes its mask.
+template <int C>
+__global__ void __launch_bounds__(1024)
+splat_pack_sink_kernel(float* __restrict__ depth, float* __restrict__ feat, float* __restrict__ mask,
+                       float mask_void, SplatWs ws, PackWs pw, uint32_t zpart_count) {
+  __shared__ uint32_t s_c[C][16];
+  const uint32_t nitems = pw.ctl[2];
+  uint32_t fm[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) fm[k] = 0u;
+  for (uint32_t i = threadIdx.x; i < zpart_count * C; i += 1024) {
+    const uint32_t v = ws.fpart[i];
+    const int k = i % C;
+#pragma unroll
+    for (int kk = 0; kk < C; ++kk)
+      if (kk == k) fm[kk] = v > fm[kk] ? v : fm[kk];
+  }
+  for (uint32_t i = threadIdx.x; i < nitems * C; i += 1024) {
+    const uint32_t v = pw.fpart2[i];
+    const int k = i % C;
+#pragma unroll
+    for (int kk = 0; kk < C; ++kk)
+      if (kk == k) fm[kk] = v > fm[kk] ? v : fm[kk];
+  }
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const uint32_t v = wave_max_u32(fm[k]);
+    if ((threadIdx.x & 63) == 0) s_c[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float d = depth[0];
+    bool all_ok = true;
+    for (int k = 0; k < C; ++k) {
+      uint32_t sv = 0u;
+      for (int i = 0; i < 16; ++i) sv = s_c[k][i] > sv ? s_c[k][i] : sv;
+      float v = feat[k];
+      if (sv != 0u) {
+        const float sf = se3ds_ordered_to_f32(sv);
+        v = sf > v ? sf : v;
+      }
+      feat[k] = v;
+      all_ok = all_ok && (v != mask_void);
+    }
+    if (mask) mask[0] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+feats_byte_range_kernel(const T* __restrict__ f, int64_t count, float void_class,
+                        uint32_t* __restrict__ bad_out) {
+  uint32_t bad = 0u;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count;
+       i += (int64_t)gridDim.x * kBlock) {
+    const int32_t v = (int32_t)f[i];
+    bad += ((float)v != void_class && ((uint32_t)v >> 8) != 0u) ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) bad += (uint32_t)__shfl_xor((int)bad, o, 64);
+  if ((threadIdx.x & 63) == 0 && bad != 0u) atomicAdd(bad_out, bad);
+}
+
+__global__ void splat_promise_kernel(PackWs pw, uint32_t* out) { out[0] = pw.ctl[1] != 0u ? 1u : 0u; }
+
+template <typename T, bool EQUIRECT>
+int launch_splat_packed(const float* coords, const float* offset, const T* feats, int n, int64_t m,
+                        int64_t ld, int channels, int height, int width, float depth_scale,
+                        float input_void, float output_void, float* depth, float* feat,
+                        float* mask, float mask_void, void* workspace, hipStream_t stream) {
+  SplatWs ws = carve_ws(workspace, n, m);
+  const size_t base = splat_hdr_bytes() + (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)m;
+  PackWs pw = carve_pack_ws((char*)workspace + align16(base), n, m, height, width);
+  const int tiles_x = ceil_div(width, kPTileX), tiles_y = ceil_div(height, kPTileY);
+  const int ntiles = tiles_x * tiles_y, nb = n * ntiles;
+  const ChunkGeom cg = pack_geom(m, n);
+  const uint64_t wmagic = ((uint64_t)1 << 40) / (uint64_t)width + 1;
+  const dim3 g_pt((unsigned)cg.chunks, (unsigned)n);
+  const int nparts = cg.chunks * n;
+  const uint32_t slice = pack_slice();
+  const int items = (int)resolve_items_max(nb, (int64_t)n * m, slice);
+  const int vec = (ld % 4 == 0) && ((uintptr_t)coords % 16 == 0) &&
+                  ((uintptr_t)feats % (sizeof(T) == 1 ? 4 : 16) == 0);
+  static const bool dbg = [] {
+    const char* e = getenv("SE3DS_SPLAT_DEBUG");
+    return e && atoi(e) != 0;
+  }();
+#define SE3DS_P1(CC, DBG)                                                                         \
+  hipLaunchKernelGGL((splat_pack_count_kernel<T, EQUIRECT, CC, DBG>), g_pt, dim3(kPThreads),      \
+                     4 * ntiles, stream, coords, offset, feats, m, ld, cg.per, height, width,     \
+                     wmagic, input_void, ntiles, tiles_x, vec, ws, pw)
+  switch (channels) {
+    case 1: if (dbg) SE3DS_P1(1, true); else SE3DS_P1(1, false); break;
+    case 2: if (dbg) SE3DS_P1(2, true); else SE3DS_P1(2, false); break;
+    default: if (dbg) SE3DS_P1(3, true); else SE3DS_P1(3, false); break;
+  }
+#undef SE3DS_P1
+  hipLaunchKernelGGL(splat_pack_colscan_kernel, dim3(ceil_div(nb, 64)), dim3(64 * kScanWaves), 0,
+                     stream, pw, cg.chunks, ntiles, nb);
+  hipLaunchKernelGGL(splat_pack_tilescan_kernel, dim3(1), dim3(64 * kScanWaves), 0, stream, pw, nb,
+                     slice);
+  hipLaunchKernelGGL(splat_pack_permute_kernel, g_pt, dim3(kPThreads), 4 * ntiles, stream, m, cg.per,
+                     ntiles, pw);
+#define SE3DS_P4(CC)                                                                              \
+  hipLaunchKernelGGL((splat_pack_resolve_kernel<CC>), dim3(items), dim3(kPResolveThreads), 0,     \
+                     stream, height, width, ntiles, tiles_x, depth_scale, output_void, mask_void,  \
+                     depth, feat, mask, ws, pw, (uint32_t)nparts, (uint32_t)items);                \
+  hipLaunchKernelGGL((splat_pack_sink_kernel<CC>), dim3(1), dim3(1024), 0, stream, depth, feat,   \
+                     mask, mask_void, ws, pw, (uint32_t)nparts)
+  switch (channels) {
+    case 1: SE3DS_P4(1); break;
+    case 2: SE3DS_P4(2); break;
+    default: SE3DS_P4(3); break;
+  }
+#undef SE3DS_P4
+  return check_launch("splat(packed)");
+}
+
 template <typename T, bool EQUIRECT>
 int launch_splat(const float* coords, const float* offset, const T* feats, int n, int64_t m,
                  int64_t ld,
                  int channels, int height, int width, float depth_scale, float input_void,
                  float output_void, float* depth, float* feat, float* mask, float mask_void,
-                 void* workspace, hipStream_t stream) {
+                 void* workspace, hipStream_t stream, bool byte_range = false) {
   {
     static const bool no_bin = getenv("SE3DS_SPLAT_SCATTER") != nullptr;
+    // 8-byte packed records (round 3): features of valid points are bytes by type (uint8) or by
+    // the caller's promise (int32 | SE3DS_FEAT_BYTE_RANGE), <= 3 channels, non-negative output
+    // void.  SE3DS_SPLAT_PACKED=0 keeps the 20-byte-record path (A/B runs, parity tests).
+    if constexpr (!std::is_same<T, float>::value) {
+      static const bool no_pack = [] {
+        const char* e = getenv("SE3DS_SPLAT_PACKED");
+        return e && atoi(e) == 0;
+      }();
+      const int64_t ptiles = (int64_t)ceil_div(height, kPTileY) * ceil_div(width, kPTileX);
+      if (!no_bin && !no_pack && m > 0 && channels <= kPMaxChannels && ptiles <= kMaxTiles &&
+          (std::is_same<T, uint8_t>::value || byte_range) && output_void >= 0.0f &&
+          (int64_t)n * ptiles < ((int64_t)1 << 20) && (int64_t)n * m < ((int64_t)1 << 31) &&
+          (int64_t)height * width * width < ((int64_t)1 << 40))
+        return launch_splat_packed<T, EQUIRECT>(coords, offset, feats, n, m, ld, channels, height,
+                                                width, depth_scale, input_void, output_void, depth,
+                                                feat, mask, mask_void, workspace, stream);
+    }
     const int64_t ntiles = (int64_t)ceil_div(height, kTileY) * ceil_div(width, kTileX);
     if (!no_bin && m > 0 && channels <= kMaxBinChannels && ntiles <= kMaxTiles &&
         (int64_t)n * m < ((int64_t)1 << 31) &&
@@ -1454,6 +2202,8 @@ int dispatch_splat(const float* coords, const float* offset, const void* feats, 
   if (n <= 0 || m < 0 || ld < m || channels <= 0 || channels > 60 || height <= 0 || width <= 0)
     return SE3DS_E_BADSHAPE;
   if ((int64_t)n * height * width >= (int64_t)1 << 31) return SE3DS_E_BADSHAPE;
+  const bool byte_range = (feat_dtype & SE3DS_FEAT_BYTE_RANGE) != 0;
+  feat_dtype &= ~SE3DS_FEAT_BYTE_RANGE;
   if (workspace_bytes < se3ds_splat_workspace_bytes(n, m, height, width, channels))
     return SE3DS_E_WORKSPACE;
   hipStream_t s = as_stream(stream);
@@ -1465,7 +2215,7 @@ int dispatch_splat(const float* coords, const float* offset, const void* feats, 
     case SE3DS_I32:
       return launch_splat<int32_t, EQUIRECT>(coords, offset, (const int32_t*)feats, n, m, ld, channels,
                                              height, width, depth_scale, input_void, output_void,
-                                             depth, feat, mask, mask_void, workspace, s);
+                                             depth, feat, mask, mask_void, workspace, s, byte_range);
     case SE3DS_U8:
       return launch_splat<uint8_t, EQUIRECT>(coords, offset, (const uint8_t*)feats, n, m, ld, channels,
                                              height, width, depth_scale, input_void, output_void,
@@ -1932,7 +2682,10 @@ size_t se3ds_splat_workspace_bytes(int n, int64_t m, int height, int width, int 
   const int c = channels > 0 ? channels : 1;
   const size_t three_pass = bin_ws_bytes(n, m, height, width, c);
   const size_t single_pass = fused_ws_bytes(n, m, height, width, c);
-  return align16(base) + (three_pass > single_pass ? three_pass : single_pass) + 16;
+  const size_t packed = pack_ws_bytes(n, m, height, width);
+  size_t bins = three_pass > single_pass ? three_pass : single_pass;
+  if (packed > bins) bins = packed;
+  return align16(base) + bins + 16;
 }
 
 int se3ds_project_equirect(const float* xyz1, const float* offset, const void* feats,
@@ -1964,6 +2717,34 @@ int se3ds_project_to_feat(const float* coords, const void* feats, int feat_dtype
   return dispatch_splat<false>(coords, nullptr, feats, feat_dtype, n, m, m, channels, height, width,
                                depth_scale, input_void, output_void, depth, feat, mask, mask_void,
                                workspace, workspace_bytes, stream);
+}
+
+int se3ds_feats_byte_range(const void* feats, int feat_dtype, int64_t count, float void_class,
+                           uint32_t* bad_out, void* stream) {
+  if (count < 0 || !bad_out) return SE3DS_E_BADSHAPE;
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(bad_out, 0, sizeof(uint32_t), s) != hipSuccess) return SE3DS_E_LAUNCH;
+  if (count == 0) return SE3DS_OK;
+  const dim3 g((unsigned)grid_for(count, kBlock));
+  if (feat_dtype == SE3DS_I32)
+    hipLaunchKernelGGL(feats_byte_range_kernel<int32_t>, g, dim3(kBlock), 0, s,
+                       (const int32_t*)feats, count, void_class, bad_out);
+  else if (feat_dtype == SE3DS_U8)
+    hipLaunchKernelGGL(feats_byte_range_kernel<uint8_t>, g, dim3(kBlock), 0, s,
+                       (const uint8_t*)feats, count, void_class, bad_out);
+  else
+    return SE3DS_E_BADDTYPE;
+  return check_launch("feats_byte_range");
+}
+
+int se3ds_splat_promise_broken(const void* workspace, int n, int64_t m, uint32_t* broken_out,
+                               void* stream) {
+  if (n <= 0 || m <= 0 || !broken_out) return SE3DS_E_BADSHAPE;
+  const size_t base = splat_hdr_bytes() + (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)m;
+  PackWs pw;
+  pw.ctl = (uint32_t*)((char*)const_cast<void*>(workspace) + align16(base));
+  hipLaunchKernelGGL(splat_promise_kernel, dim3(1), dim3(1), 0, as_stream(stream), pw, broken_out);
+  return check_launch("splat_promise_broken");
 }
 
 int se3ds_splat_debug_indices(const void* workspace, int n, int64_t m, int32_t* idx_out,

@@ -187,7 +187,7 @@ def truncated_normal_init(shape, gen, std=0.05):
 # --------------------------------------------------------------------------------- context
 class Var:
   """Activation handle: NHWC tensor in the compute dtype plus its (lazy) gradient."""
-  __slots__ = ('data', 'grad', 'requires_grad', 'col_stats', 'grad_pre_act')
+  __slots__ = ('data', 'grad', 'requires_grad', 'col_stats', 'grad_pre_act', 'shared', 'grad_ev')
 
   def __init__(self, data, requires_grad=True):
     self.data = data
@@ -195,6 +195,8 @@ class Var:
     self.requires_grad = requires_grad
     self.col_stats = None   # conv outputs: partial column sums for a following batch norm
     self.grad_pre_act = False   # the consumer already applied this tensor's activation derivative
+    self.shared = False     # consumed by branches that run on different HIP streams (Ctx.streams)
+    self.grad_ev = None     # ... then: event behind the last write of .grad
 
   @property
   def shape(self):
@@ -218,6 +220,12 @@ class Ctx:
     self.on_segment = None    # callback(name): a top-level module's parameter gradients are final
     self.batch_limit = None   # backward passes that only concern the first samples of the batch
     self.act_taps = None      # tests: dict layer name -> activated output (sign decisions)
+    # Independent branches of the graph (the generator's two decoders) on their own HIP streams:
+    # {tag: torch.cuda.Stream}, None = everything on the current stream.  Ops record the branch
+    # they ran in; backward() replays each branch's closures on its stream (see branch()).
+    self.streams = None
+    self.branch_tag = 0
+    self._forked = set()
     self.group = group
     # Replica count of the STRATEGY that built the model, never probed from global
     # torch.distributed state: a one-device model inside an initialised process group must not
@@ -235,6 +243,8 @@ class Ctx:
     self._ws = {}
 
   def ws(self, key, nbytes):
+    if self.streams is not None:   # scratch is per stream: branches run concurrently
+      key = (key, torch.cuda.current_stream(self.device).cuda_stream)
     t = self._ws.get(key)
     if t is None or t.numel() < nbytes:
       t = torch.empty((int(nbytes),), dtype=torch.uint8, device=self.device)
@@ -246,12 +256,43 @@ class Ctx:
 
   def record(self, fn):
     if self.tape is not None:
-      self.tape.append(fn)
+      self.tape.append((fn, self.branch_tag))
+
+  def branch(self, tag):
+    """with ctx.branch(tag): ops of one independent branch.  With Ctx.streams the branch's
+    kernels go to streams[tag], which first waits for everything issued on the main stream (fork);
+    join() makes the main stream wait for the branches.  While branches are open nothing may be
+    issued on the main stream.  Why: the two decoders are ~90 % of the generator and independent,
+    so the tail of one's kernel overlaps the ramp of the other's, and the HBM-bound normalisation
+    kernels of one run under the MFMA-bound convolutions of the other."""
+    return _Branch(self, tag)
+
+  def join(self):
+    if self._forked:
+      main = torch.cuda.current_stream(self.device)
+      for tag in sorted(self._forked):
+        main.wait_stream(self.streams[tag])
+      self._forked.clear()
 
   def backward(self):
     tape, self.tape = self.tape, []
-    for fn in reversed(tape):
+    cur, scope = 0, None
+    for fn, tag in reversed(tape):
+      t = tag if self.streams is not None else 0
+      if t != cur:   # (one stream switch per run of closures, not per closure)
+        if scope is not None:
+          scope.__exit__(None, None, None)
+          scope = None
+        if t == 0:
+          self.join()
+        else:
+          scope = self.branch(t)
+          scope.__enter__()
+        cur = t
       fn()
+    if scope is not None:
+      scope.__exit__(None, None, None)
+    self.join()
 
   def mark_segment(self, name):
     """Call BEFORE running a top-level module in the forward pass: in the backward pass the
@@ -260,7 +301,7 @@ class Ctx:
       def fire():
         if self.on_segment is not None and self.param_grads:
           self.on_segment(name)
-      self.tape.append(fire)
+      self.tape.append((fire, self.branch_tag))
 
   def allreduce_sum(self, t):
     if self.world > 1:
@@ -268,6 +309,40 @@ class Ctx:
       cb = getattr(self, 'after_collective', None)
       if cb is not None:
         cb()   # (GradSync.pump: one pending gradient bucket goes out behind this collective)
+
+
+class _Branch:
+  def __init__(self, ctx, tag):
+    self.ctx, self.tag, self.scope, self.prev = ctx, tag, None, 0
+
+  def __enter__(self):
+    ctx = self.ctx
+    self.prev, ctx.branch_tag = ctx.branch_tag, self.tag
+    if ctx.streams is not None and self.tag:
+      s = ctx.streams[self.tag]
+      if self.tag not in ctx._forked:
+        s.wait_stream(torch.cuda.current_stream(ctx.device))
+        ctx._forked.add(self.tag)
+      self.scope = torch.cuda.stream(s)
+      self.scope.__enter__()
+    return self
+
+  def __exit__(self, *a):
+    if self.scope is not None:
+      self.scope.__exit__(*a)
+    self.ctx.branch_tag = self.prev
+
+
+def _grad_wait(var):
+  """Before reading or modifying the gradient of a Var that several stream branches feed."""
+  if var.grad_ev is not None:
+    torch.cuda.current_stream().wait_event(var.grad_ev)
+
+
+def _grad_mark(var):
+  if var.shared:
+    var.grad_ev = torch.cuda.Event()
+    var.grad_ev.record()
 
 
 _WS = {}
@@ -322,6 +397,10 @@ def set_conv_profiler(p):
   _PROF = p
 
 
+def conv_profiler():
+  return _PROF
+
+
 class _Timed:
   """with _Timed(kind, flops): launch  -- no-op unless a profiler is installed."""
 
@@ -337,7 +416,7 @@ class _Timed:
 
 
 def _global_ws(device, key, nbytes):
-  k = (str(device), key)
+  k = (str(device), key, torch.cuda.current_stream(device).cuda_stream)
   t = _WS.get(k)
   if t is None or t.numel() < nbytes:
     t = torch.empty((int(nbytes),), dtype=torch.uint8, device=device)
@@ -352,8 +431,10 @@ def accumulate(var: Var, g: torch.Tensor):
   if var.grad is None:
     var.grad = g
   else:
+    _grad_wait(var)
     _chk(_L().se3ds_add(var.grad.data_ptr(), g.data_ptr(), _lib.dtype_code(g), g.numel(),
                         var.grad.data_ptr(), _lib.stream()), 'se3ds_add')
+  _grad_mark(var)
 
 
 def to_var(ctx: Ctx, t: torch.Tensor, requires_grad=False) -> Var:
@@ -699,12 +780,14 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
         if prev is not None and tuple(prev.shape) == shape and prev.dtype == xd.dtype:
           # second contribution (e.g. a ResNet block's input: residual branch first, then this
           # conv): the epilogue adds the existing gradient in place instead of a separate pass
+          _grad_wait(x)
           with _Timed('dgrad', flops * n / xd.shape[0], tag):
             _chk(L.se3ds_conv2d_dgrad_acc(dys.data_ptr(), wn.data_ptr(), prev.data_ptr(), ctx.code,
                                           n, h, w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
                                           1 if wrap else 0, _lib.ptr(row_scale), _lib.ptr(scale),
                                           None, _lib.ptr(in_mask), ACT_NONE, 0.0, prev.data_ptr(),
                                           _lib.stream()), 'se3ds_conv2d_dgrad_acc')
+          _grad_mark(x)
         else:
           dx = ctx.empty(shape)
           with _Timed('dgrad', flops * n / xd.shape[0], tag):

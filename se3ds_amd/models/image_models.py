@@ -3,6 +3,7 @@ models/image_models.py: ResNetGenerator (partial-conv ResNet encoder, global con
 RedNet-style decoders, RGB / depth heads) and the spectral-normalised multi-scale PatchGAN
 discriminator.  Constructor arguments, call signatures, return structure and error behaviour
 follow the reference; see the line citations on each class."""
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -13,6 +14,10 @@ from se3ds_amd import gin_lite as gin
 from se3ds_amd.hipops import nn
 from se3ds_amd.hipops.nn import ACT_LRELU, ACT_NONE, ACT_RELU, Ctx, ParamStore, Var
 from se3ds_amd.models import layers
+
+
+# independent branches of a model on their own HIP streams (SE3DS_DUAL_STREAM=0: one stream)
+_DUAL_STREAM = os.environ.get('SE3DS_DUAL_STREAM', '1') != '0'
 
 
 def _conv_layers_of(obj, out=None, seen=None):
@@ -63,8 +68,15 @@ class _Model:
     never all-reduces, even inside an initialised torch.distributed job).  A world that does not
     match the group's size (e.g. a group passed together with world=1) raises instead of
     silently running unsynchronised batch norm."""
-    return Ctx(self.device, dtype or self.dtype, training=bool(training), record=record,
-               group=group, world=world)
+    ctx = Ctx(self.device, dtype or self.dtype, training=bool(training), record=record,
+              group=group, world=world)
+    if ctx.world == 1 and _DUAL_STREAM and nn.conv_profiler() is None:
+      # (not while the bench times single convolution launches: overlapped kernels would be
+      # charged each other's time)
+      if getattr(self, '_branch_streams', None) is None:
+        self._branch_streams = {1: torch.cuda.Stream(self.device), 2: torch.cuda.Stream(self.device)}
+      ctx.streams = self._branch_streams
+    return ctx
 
 
 # --------------------------------------------------------------------------------- encoder
@@ -296,18 +308,29 @@ class ResNetGenerator(_Model):
         hidden = self.ctx_conv[i](ctx, hidden, pad=self.ctx_pad,
                                   act=ACT_LRELU if i < 3 else ACT_NONE, alpha=0.3)
     hh, hw = hidden.shape[1], hidden.shape[2]
-    ctx.mark_segment('decoder')
-    out = self.decoder(ctx, hidden, skip)
-    ctx.mark_segment('depth_decoder')
-    depth_out = self.depth_decoder(ctx, hidden, skip)
+    # The two decoders (+ their heads) are independent branches: each runs on its own HIP stream
+    # when the context has them (Ctx.branch; one replica only).  Their common inputs receive
+    # gradients from both streams.
+    if ctx.streams is not None:
+      for v in list(skip) + [hidden]:
+        v.shared = True
+    with ctx.branch(1):
+      ctx.mark_segment('decoder')
+      out = self.decoder(ctx, hidden, skip)
+    with ctx.branch(2):
+      ctx.mark_segment('depth_decoder')
+      depth_out = self.depth_decoder(ctx, hidden, skip)
     if taps is not None:
       taps.update(ctx=hidden, dec=out, ddec=depth_out)
-    ctx.mark_segment('rgb_conv')
-    rgb_pre = self.rgb_conv(ctx, out)
-    ctx.mark_segment('depth_conv')
-    depth_pre = self.depth_conv(ctx, depth_out)
-    rgb, push_rgb = nn.head(ctx, rgb_pre, 0)
-    depth, push_depth = nn.head(ctx, depth_pre, 1)
+    with ctx.branch(1):
+      ctx.mark_segment('rgb_conv')
+      rgb_pre = self.rgb_conv(ctx, out)
+      rgb, push_rgb = nn.head(ctx, rgb_pre, 0)
+    with ctx.branch(2):
+      ctx.mark_segment('depth_conv')
+      depth_pre = self.depth_conv(ctx, depth_out)
+      depth, push_depth = nn.head(ctx, depth_pre, 1)
+    ctx.join()
     dev = ctx.device
     zeros = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
     mu = zeros(n, hh, hw, self.z_dim)

@@ -145,7 +145,7 @@ class GAN(gan_manager.GANManager):
   def _backward_tape(self, ctx, tape, seeds, logits):
     for sub, g in zip(logits, seeds):
       sub[-1].grad = g
-    for fn in reversed(tape):
+    for fn, _ in reversed(tape):   # (entries carry the stream branch they were recorded in: none here)
       fn()
 
   # ------------------------------------------------------------------------------ train_g_d

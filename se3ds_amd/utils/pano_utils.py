@@ -122,6 +122,16 @@ def equirectangular_to_pointcloud(feats: torch.Tensor, depth: torch.Tensor, void
       base + 8 * h, base + 8 * h + 4 * w, _lib.ptr(position), n, h, w, c, float(void_class),
       float(depth_scale), _lib.ptr(xyz1), _lib.ptr(res), m_total, off, _lib.stream())
   _lib.check(rc, 'se3ds_unproject_equirect')
+  if res.dtype == torch.int32:
+    # the written features are the source's or void_class: the 8-byte splat's byte-range promise
+    # carries over from the source (checked once per source tensor) to the written tensor; a
+    # memory filled window by window keeps it only while every window had it
+    ok = point_cloud_utils.byte_range(feats, void_class)
+    if out is not None:
+      prev = getattr(res, '_se3ds_byte_range', None)
+      same = prev is not None and prev[1:] == (res.data_ptr(), res._version, tuple(res.shape))
+      ok = ok and (prev[0] if same else off == 0)
+    point_cloud_utils.set_byte_range(res, ok)
   if out is not None:
     xyz1, res = xyz1[:, :, off:off + h * w], res[:, off:off + h * w]
   if is_scalar:

@@ -57,6 +57,39 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
   return ws
 
 
+FEAT_BYTE_RANGE = 0x100   # include/se3ds_hip.h SE3DS_FEAT_BYTE_RANGE
+
+
+def set_byte_range(t: torch.Tensor, ok: Optional[bool]):
+  """Records on the tensor whether its elements are all `void` or integers in [0, 255] (what the
+  8-byte packed splat needs from int32 features).  Writers that fill a tensor through raw
+  pointers (se3ds_unproject_equirect_into) call this; None forgets."""
+  t._se3ds_byte_range = None if ok is None else (bool(ok), t.data_ptr(), t._version, tuple(t.shape))
+
+
+def byte_range(t: torch.Tensor, void_class: float) -> bool:
+  """True when the splat may be promised SE3DS_FEAT_BYTE_RANGE for `t` (uint8: by type; int32:
+  every element is `void_class` or in [0, 255]).  The int32 answer is computed ONCE per tensor
+  (`se3ds_feats_byte_range` + one host read) and cached on the tensor object, keyed by its
+  storage pointer, shape and torch version counter; the library's own in-place writers keep the
+  cache current."""
+  if t.dtype == torch.uint8:
+    return True
+  if t.dtype != torch.int32:
+    return False
+  ent = getattr(t, '_se3ds_byte_range', None)
+  if ent is not None and ent[1:] == (t.data_ptr(), t._version, tuple(t.shape)):
+    return ent[0]
+  bad = torch.empty(1, dtype=torch.int32, device=t.device)
+  tc = t.contiguous()
+  rc = _lib.lib().se3ds_feats_byte_range(_lib.ptr(tc), _lib.dtype_code(tc), tc.numel(),
+                                         float(void_class), _lib.ptr(bad), _lib.stream())
+  _lib.check(rc, 'se3ds_feats_byte_range')
+  ok = int(bad.item()) == 0
+  set_byte_range(t, ok)
+  return ok
+
+
 def _splat(entry: str, coords, offset, feats, height, width, depth_scale, input_void_class,
            output_void_class, with_mask=False, mask_void=constants.INVALID_RGB_VALUE):
   if feats.dim() != 2 and feats.dim() != 3:
@@ -68,6 +101,8 @@ def _splat(entry: str, coords, offset, feats, height, width, depth_scale, input_
     feats = feats[..., None]
   if feats.dtype not in (torch.float32, torch.int32, torch.uint8):
     feats = feats.to(torch.float32)
+  hint = FEAT_BYTE_RANGE if (feats.dtype == torch.int32 and feats.shape[-1] <= 3 and
+                             byte_range(feats, input_void_class)) else 0
   feats = feats.contiguous()
   coords = coords.to(torch.float32).contiguous()
   n, four, m = coords.shape
@@ -85,14 +120,14 @@ def _splat(entry: str, coords, offset, feats, height, width, depth_scale, input_
     if offset is not None:
       offset = offset.to(torch.float32).contiguous()
     rc = L.se3ds_project_equirect(_lib.ptr(coords), _lib.ptr(offset), _lib.ptr(feats),
-                                  _lib.dtype_code(feats), n, m, c, height, width,
+                                  _lib.dtype_code(feats) | hint, n, m, c, height, width,
                                   float(depth_scale), float(input_void_class),
                                   float(output_void_class), _lib.ptr(depth), _lib.ptr(out),
                                   _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(),
                                   _lib.stream())
     _lib.check(rc, 'se3ds_project_equirect')
   else:
-    rc = L.se3ds_project_to_feat(_lib.ptr(coords), _lib.ptr(feats), _lib.dtype_code(feats), n, m,
+    rc = L.se3ds_project_to_feat(_lib.ptr(coords), _lib.ptr(feats), _lib.dtype_code(feats) | hint, n, m,
                                  c, height, width, float(depth_scale), float(input_void_class),
                                  float(output_void_class), _lib.ptr(depth), _lib.ptr(out),
                                  _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(),
@@ -155,6 +190,7 @@ class PointCloudMemory:
                capacity: int = 0):
     self.n, self.c, self.dtype, self.device = batch_size, channels, dtype, torch.device(device)
     self.m = 0
+    self.byte_range = True   # every appended frame's features were void or in [0, 255]
     self._x = torch.empty((batch_size, 4, 0), dtype=torch.float32, device=self.device)
     self._f = torch.empty((batch_size, 0, channels), dtype=dtype, device=self.device)
     if capacity:
@@ -192,6 +228,8 @@ class PointCloudMemory:
     self.reserve(self.m + p)
     if feats.dim() == 3:
       feats = feats[..., None]
+    # (the unprojected features are the source's, or void: the promise carries over)
+    self.byte_range = self.byte_range and byte_range(feats, void_class)
     pano_utils.equirectangular_to_pointcloud(feats, depth, void_class, depth_scale,
                                              position=position, out=(self._x, self._f, self.m))
     self.m += p
@@ -214,8 +252,9 @@ class PointCloudMemory:
     if self.capacity == 0:   # empty memory: any valid pointer pair will do (m = 0)
       x = torch.empty((n, 4, 1), dtype=torch.float32, device=dev)
       f = torch.empty((n, 1, c), dtype=self.dtype, device=dev)
+    hint = FEAT_BYTE_RANGE if (f.dtype == torch.int32 and c <= 3 and self.byte_range) else 0
     rc = L.se3ds_project_equirect_memory(
-        _lib.ptr(x), _lib.ptr(position), _lib.ptr(f), _lib.dtype_code(f), n, self.m, x.shape[2], c,
+        _lib.ptr(x), _lib.ptr(position), _lib.ptr(f), _lib.dtype_code(f) | hint, n, self.m, x.shape[2], c,
         height, width, float(depth_scale), float(void_class), float(output_void_class),
         _lib.ptr(depth), _lib.ptr(out), _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(),
         _lib.stream())

@@ -226,11 +226,28 @@ def test_block_fwd_bwd_at_production_width(case, dtype):
     assert torch.equal(um.cpu(), um_o.detach()), 'update mask must be exact'
   for i, (v, o) in enumerate(zip(xv, xo)):
     e[f'dx{i}'] = err(v.grad.float().cpu().numpy(), o.grad.numpy())
-  gmax = max(float(params[k].grad.abs().max()) for k in store.trainable_names)
-  for k in store.trainable_names:
-    # floor: conv biases in front of a batch norm have a mathematically zero gradient (sums of
-    # +-1e-7 terms); measure those against the block's gradient scale
-    e[k] = err(store.grad_views[k].cpu().numpy(), params[k].grad.numpy(), 1e-4 * gmax)
+  # Parameter gradients are measured against max|oracle| of the tensor, floored at a fraction of
+  # the largest gradient entry of the tensor's CLASS in this block (kernels / per-channel vectors).
+  # The floor matters for per-channel vectors only: the bias of a conv that feeds a batch norm has
+  # a mathematically ZERO gradient (the norm removes the mean; with a partial-conv mask or a
+  # LeakyReLU in between, nearly zero), i.e. what both sides compute is the rounding residue of a
+  # column sum over N*H*W rows whose natural scale is that of the non-cancelling column sums
+  # next to it (dbeta, dgamma).  fp32: 1e-2 of that scale -- the cancelling sums are still pinned
+  # to 1e-5 of the terms they add up; bf16 (dy rounded to 8 bits before the sum): 5e-2.
+  names = store.trainable_names
+  is_vec = {k: params[k].grad.dim() <= 1 for k in names}
+  scale = {c: max([float(params[k].grad.abs().max()) for k in names if is_vec[k] == c] or [0.0])
+           for c in (False, True)}
+  floor = {False: 1e-4 * scale[False],
+           True: (1e-2 if dtype == torch.float32 else 5e-2) * scale[True]}
+  for k in names:
+    fl = floor[is_vec[k]]
+    if dtype == torch.bfloat16 and is_vec[k] and float(params[k].grad.abs().max()) < 1e-5 * scale[True]:
+      # numerically ZERO in the oracle (a conv bias straight in front of a batch norm): what the
+      # bf16 path returns is the rounding residue of summing N*H*W bf16-rounded terms; it must stay
+      # below 2 % of the block's per-channel gradient scale (fp32 pins the same tensor to 1e-5)
+      fl = scale[True]
+    e[k] = err(store.grad_views[k].cpu().numpy(), params[k].grad.numpy(), fl)
   for k, v in net.updates.items():   # BN moving statistics, spectral u
     e['upd:' + k] = err(store[k].cpu().numpy(), v.detach().numpy())
   worst = sorted(e.items(), key=lambda kv: -kv[1])[:4]

@@ -298,17 +298,23 @@ def test_bilinear_and_resampling_paths():
   assert (np.abs(e_g.cpu().numpy() - e_o).max(-1) <= 1e-4).mean() > 0.995
 
 
+_OLD = dict(SE3DS_SPLAT_PACKED='0')   # the 20-byte-record paths behind the 8-byte packed default
 @pytest.mark.parametrize('env_extra', [
-    dict(SE3DS_SPLAT_SLICE='48'),                          # every tile banded
-    dict(SE3DS_SPLAT_FUSED='8'),                           # single-pass binning kernel, 8 points / thread
-    dict(SE3DS_SPLAT_FUSED='16', SE3DS_SPLAT_CAP='64'),    # ... 16 points, bins overflow into the list
-    dict(SE3DS_SPLAT_FUSED='8', SE3DS_SPLAT_CAP='64', SE3DS_SPLAT_SLICE='48'),   # overflow + bands
-], ids=['banded', 'single-pass', 'single-pass-overflow', 'single-pass-overflow-banded'])
+    dict(SE3DS_SPLAT_SLICE='48'),                          # packed records, every tile banded
+    dict(_OLD),                                            # three-pass, 20-byte records
+    dict(_OLD, SE3DS_SPLAT_SLICE='48'),                    # ... every tile banded
+    dict(_OLD, SE3DS_SPLAT_FUSED='8'),                     # single-pass binning kernel, 8 points / thread
+    dict(_OLD, SE3DS_SPLAT_FUSED='16', SE3DS_SPLAT_CAP='64'),    # ... 16 points, bins overflow into the list
+    dict(_OLD, SE3DS_SPLAT_FUSED='8', SE3DS_SPLAT_CAP='64', SE3DS_SPLAT_SLICE='48'),   # overflow + bands
+], ids=['packed-banded', 'three-pass', 'three-pass-banded', 'single-pass', 'single-pass-overflow',
+        'single-pass-overflow-banded'])
 def test_splat_banded_tiles_bit_exact(env_extra):
   """The splat parity tests re-run in a child process under switches that are read once per
-  process: tiny slices (every tile of the small parity images is cut into bands of rows,
-  splat_tile_resolve_kernel), and the opt-in single-pass binning kernel (SE3DS_SPLAT_FUSED) with
-  tiny bin capacities (records spill into its overflow list)."""
+  process: tiny slices (every tile of the small parity images is cut into bands of rows, in the
+  packed and in the 20-byte-record resolve kernels), the 20-byte-record three-pass path that the
+  8-byte packed path replaced as the default (SE3DS_SPLAT_PACKED=0; still what float features
+  and more than 3 channels take), and the opt-in single-pass binning kernel (SE3DS_SPLAT_FUSED)
+  with tiny bin capacities (records spill into its overflow list)."""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -319,6 +325,55 @@ def test_splat_banded_tiles_bit_exact(env_extra):
                      env=env, cwd=root, capture_output=True, text=True, timeout=600)
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
   assert ' passed' in r.stdout
+
+
+def test_packed_splat_variants_and_byte_range_promise():
+  """The 8-byte packed-record splat (se3ds_amd/csrc/geom.hip, round 3) on the inputs that decide
+  its dispatch: point counts that are not a multiple of 4 (scalar loads, padded tails), 1 / 2 / 3
+  channels, uint8 (packed by type) and int32 (packed under the byte-range promise, which the
+  wrapper establishes with se3ds_feats_byte_range and caches on the tensor); int32 features
+  OUTSIDE [0, 255] must take the 20-byte path and stay exact; a broken promise at the C ABI is
+  reported by se3ds_splat_promise_broken."""
+  from se3ds_amd import _lib
+  rng = np.random.default_rng(31)
+  h, w = 48, 96
+  for m, c, dt, void, hi_val in [(70001, 3, np.int32, -1, 256), (4099, 1, np.uint8, 0, 42),
+                                 (12345, 2, np.int32, -1, 256), (8192, 3, np.uint8, 0, 256),
+                                 (30000, 3, np.int32, -1, 100000)]:
+    xyz = (rng.standard_normal((1, 4, m)) * rng.uniform(0.05, 6, (1, 1, m))).astype(F32)
+    feats = rng.integers(0, hi_val, (1, m, c)).astype(dt)
+    feats[rng.uniform(size=(1, m)) < 0.05] = void
+    off = (rng.standard_normal((1, 3)) * 0.3).astype(F32)
+    tf = t(feats)
+    want_packable = dt == np.uint8 or hi_val <= 256
+    assert point_cloud_utils.byte_range(tf, void) == want_packable
+    d_o, f_o = warp_c.project_feats_to_equirectangular(feats, xyz, h, w, void, DEPTH_SCALE, offset=off)
+    d_g, f_g, m_g = pano_utils.project_feats_to_equirectangular(tf, t(xyz), h, w, void, DEPTH_SCALE,
+                                                                 offset=t(off), with_mask=True,
+                                                                 mask_void=0)
+    np.testing.assert_array_equal(d_g.cpu().numpy(), d_o, err_msg=str((m, c, dt)))
+    np.testing.assert_array_equal(f_g.cpu().numpy(), f_o, err_msg=str((m, c, dt)))
+  # the cache follows torch's version counter: an in-place edit re-runs the check
+  tf = t(rng.integers(0, 256, (1, 1000, 3)).astype(np.int32))
+  assert point_cloud_utils.byte_range(tf, -1)
+  tf[0, 5, 1] = 300
+  assert not point_cloud_utils.byte_range(tf, -1)
+  # a broken promise at the C ABI is visible afterwards (outputs of that call are undefined)
+  m = 5000
+  xyz = t((rng.standard_normal((1, 4, m)) * 3).astype(F32))
+  L = _lib.lib()
+  ws = torch.empty(L.se3ds_splat_workspace_bytes(1, m, h, w, 3), dtype=torch.uint8, device=dev())
+  depth = torch.empty((1, h, w), device=dev())
+  out = torch.empty((1, h, w, 3), device=dev())
+  flag = torch.zeros(1, dtype=torch.int32, device=dev())
+  for feats, want in ((rng.integers(0, 256, (1, m, 3)), 0), (rng.integers(0, 5000, (1, m, 3)), 1)):
+    f = t(feats.astype(np.int32))
+    rc = L.se3ds_project_equirect(_lib.ptr(xyz), None, _lib.ptr(f), _lib.I32 | point_cloud_utils.FEAT_BYTE_RANGE,
+                                  1, m, 3, h, w, DEPTH_SCALE, -1.0, 0.0, _lib.ptr(depth), _lib.ptr(out),
+                                  None, -1.0, _lib.ptr(ws), ws.numel(), _lib.stream())
+    assert rc == 0
+    assert L.se3ds_splat_promise_broken(_lib.ptr(ws), 1, m, _lib.ptr(flag), _lib.stream()) == 0
+    assert int(flag.item()) == want
 
 
 @pytest.mark.parametrize('h', [64, 1024])
