@@ -1423,16 +1423,20 @@ constexpr int kPResolveThreads = 256;
 constexpr int kPStash = 4;                     // records per thread kept in registers
 constexpr uint32_t kPSlice = 4096;             // records per band workgroup aimed at
 constexpr int kPMaxChannels = 3;
+constexpr int kSinkSlots = 64;
 constexpr uint16_t kNoTile = 0xffffu;
 constexpr uint16_t kPendingTile = 0xfffeu;   // undecided by the fp32 screen: the exact pass fills it in
 
 struct PackWs {
   uint32_t* ctl;          // [8]: 0 colscan tickets, 1 promise violations, 2 items, 3 resolve tickets
   uint32_t* tile_count;   // [nb]
-  uint32_t* tile_start;   // [nb + 1] exclusive prefix of tile_count
+  uint32_t* tile_start;   // [nb + 1] exclusive prefix of tile_count (published by the permute pass)
+  uint32_t* tile_lstart;  // [nb]  ... within the tile's group of 64
+  uint32_t* tile_litem;   // [nb]  first resolve item of the tile within its group
+  uint32_t* group_tot;    // [ngroups][2] records, items per group of 64 tiles
   uint32_t* items;        // [items_max]  tile | band << 20 | log2(bands) << 24
   uint32_t* hist;         // [n][chunks][ntiles]
-  uint32_t* fpart2;       // [items_max][C]
+  uint32_t* fpart2;       // [kSinkSlots][C] ordered max feature of the occluded points (slot = item % kSinkSlots)
   uint16_t* tile_pt;      // [n][mp]  tile of the point, kNoTile: no record
   uint64_t* rec_pt;       // [n][mp]  records in point order
   uint64_t* rec;          // [n * m]  records in tile order
@@ -1466,8 +1470,9 @@ inline size_t pack_ws_bytes(int n, int64_t m, int height, int width) {
   const ChunkGeom g = pack_geom(m, n);
   const size_t mp = (size_t)g.chunks * (size_t)g.per;
   const size_t items = (size_t)resolve_items_max((int64_t)nb, (int64_t)n * (m > 0 ? m : 0), pack_slice());
-  return 64 + align16(4 * nb) + align16(4 * (nb + 1)) + align16(4 * items) +
-         align16(4 * nb * (size_t)g.chunks) + align16(4 * items * kPMaxChannels) +
+  return 64 + align16(4 * nb) + align16(4 * (nb + 1)) + 2 * align16(4 * nb) +
+         align16(8 * (size_t)ceil_div(nb, 64)) + align16(4 * items) +
+         align16(4 * nb * (size_t)g.chunks) + align16(4 * kSinkSlots * kPMaxChannels) +
          align16(2 * (size_t)n * mp) + align16(8 * (size_t)n * mp) +
          align16(8 * (size_t)n * (size_t)(m > 0 ? m : 0));
 }
@@ -1482,9 +1487,12 @@ inline PackWs carve_pack_ws(void* base, int n, int64_t m, int height, int width)
   w.ctl = (uint32_t*)p; p += 64;
   w.tile_count = (uint32_t*)p; p += align16(4 * nb);
   w.tile_start = (uint32_t*)p; p += align16(4 * (nb + 1));
+  w.tile_lstart = (uint32_t*)p; p += align16(4 * nb);
+  w.tile_litem = (uint32_t*)p; p += align16(4 * nb);
+  w.group_tot = (uint32_t*)p; p += align16(8 * (size_t)ceil_div(nb, 64));
   w.items = (uint32_t*)p; p += align16(4 * items);
   w.hist = (uint32_t*)p; p += align16(4 * nb * (size_t)g.chunks);
-  w.fpart2 = (uint32_t*)p; p += align16(4 * items * kPMaxChannels);
+  w.fpart2 = (uint32_t*)p; p += align16(4 * kSinkSlots * kPMaxChannels);
   w.tile_pt = (uint16_t*)p; p += align16(2 * (size_t)n * mp);
   w.rec_pt = (uint64_t*)p; p += align16(8 * (size_t)n * mp);
   w.rec = (uint64_t*)p;
@@ -1542,13 +1550,10 @@ splat_pack_count_kernel(const float* __restrict__ coords, const float* __restric
   __shared__ uint32_t s_qn;
   const int b = blockIdx.y;
   for (int t = threadIdx.x; t < ntiles; t += kPThreads) s_hist[t] = 0u;
-  if (threadIdx.x == 0) {
-    s_qn = 0u;
-    if (blockIdx.x == 0 && b == 0) {   // tickets of the later passes (this kernel runs first)
-      pw.ctl[0] = 0u;
-      pw.ctl[1] = 0u;
-      pw.ctl[3] = 0u;
-    }
+  if (threadIdx.x == 0) s_qn = 0u;
+  if (blockIdx.x == 0 && b == 0) {   // state of the later passes (this kernel runs first)
+    if (threadIdx.x == 0) pw.ctl[1] = 0u;
+    if ((int)threadIdx.x < kSinkSlots * C) pw.fpart2[threadIdx.x] = 0u;
   }
   __syncthreads();
   const float* X = coords + (int64_t)b * 4 * ld;
@@ -1627,9 +1632,9 @@ splat_pack_count_kernel(const float* __restrict__ coords, const float* __restric
     }
   };
 
-  for (int64_t i0 = lo + (int64_t)threadIdx.x * kPPts; i0 < hi; i0 += kPGroup) {
-    float x[kPPts], y[kPPts], z[kPPts];
-    int32_t f[kPPts][C];
+  // one group of 4 consecutive points: 3 + C 16-byte loads
+  auto load_group = [&](int64_t i0, float (&x)[kPPts], float (&y)[kPPts], float (&z)[kPPts],
+                        int32_t (&f)[kPPts][C]) {
     const bool full = i0 + kPPts <= hi;
     if (full && vec) {
       const float4 vx = *reinterpret_cast<const float4*>(X + i0);
@@ -1661,6 +1666,13 @@ splat_pack_count_kernel(const float* __restrict__ coords, const float* __restric
         for (int k = 0; k < C; ++k) f[p][k] = (int32_t)F[i * C + k];
       }
     }
+  };
+  // (measured: issuing the next group's loads before working on the current one changes nothing,
+  // 39.2 -> 40.3 us; two workgroups per CU already overlap their loads and their arithmetic)
+  for (int64_t i0 = lo + (int64_t)threadIdx.x * kPPts; i0 < hi; i0 += kPGroup) {
+    float x[kPPts], y[kPPts], z[kPPts];
+    int32_t f[kPPts][C];
+    load_group(i0, x, y, z, f);
     uint64_t rec[kPPts];
     uint32_t tile[kPPts];
 #pragma unroll
@@ -1753,14 +1765,19 @@ splat_pack_count_kernel(const float* __restrict__ coords, const float* __restric
   for (int t = threadIdx.x; t < ntiles; t += kPThreads) row[t] = s_hist[t];
 }
 
-// P2.  Column scan as splat_bin_colscan_kernel, then (P2b, one workgroup) the exclusive scan of the
-// tile totals into tile_start[0 .. nb] and the resolve's item table (a tile with more than `slice`
-// records is cut into 2 / 4 / 8 bands of rows).  Measured and rejected: doing P2b in the last
-// workgroup of P2 to finish (ticket + __threadfence) -- on this multi-XCD part an agent-scope
-// release is an L2 write-back per workgroup: 51 us for P2, 613 us for a resolve with the same
-// pattern.
+// P2.  Column scan: per tile, exclusive prefix of the chunk rows (in place) and the tile total.
+// One workgroup per GROUP of 64 tiles (lanes, coalesced rows); its 16 waves split the chunks.  It
+// also leaves everything a consumer needs to place a tile without a scan over all tiles: the
+// exclusive prefix of the totals (and of the resolve items: a tile with more than `slice` records
+// is cut into 2 / 4 / 8 bands of rows) WITHIN the group, and the group's sums -- a consumer then
+// scans <= a few hundred group sums in one wave.  (Measured and rejected: a one-workgroup scan
+// kernel over all tiles, 6 us as its own launch; every permute workgroup redoing the full scan in
+// LDS, +10 us; rows held in registers for a single read of the table, 10 -> 19 us; the last
+// workgroup to finish publishing the scan behind a ticket + __threadfence -- on this multi-XCD
+// part an agent-scope release is an L2 write-back per workgroup: 51 us here, 613 us in a resolve
+// with the same pattern.)
 __global__ void __launch_bounds__(64 * kScanWaves)
-splat_pack_colscan_kernel(PackWs pw, int chunks, int ntiles, int nb) {
+splat_pack_colscan_kernel(PackWs pw, int chunks, int ntiles, int nb, uint32_t slice) {
   __shared__ uint32_t s_sum[kScanWaves][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int gt = blockIdx.x * 64 + lane;
@@ -1790,49 +1807,87 @@ splat_pack_colscan_kernel(PackWs pw, int chunks, int ntiles, int nb) {
       H[(int64_t)c * ntiles] = run;
       run += v;
     }
-    if (w == 0) pw.tile_count[gt] = total;
+  }
+  if (w == 0) {
+    const uint32_t cnt = ok ? total : 0u;
+    const uint32_t bands = ok ? (1u << tile_bands_log2(cnt, slice)) : 0u;
+    const uint32_t ic = wave_incl_scan_u32(cnt), is = wave_incl_scan_u32(bands);
+    if (ok) {
+      pw.tile_count[gt] = cnt;
+      pw.tile_lstart[gt] = ic - cnt;
+      pw.tile_litem[gt] = is - bands;
+    }
+    if (lane == 63) {
+      pw.group_tot[2 * blockIdx.x] = ic;
+      pw.group_tot[2 * blockIdx.x + 1] = is;
+    }
   }
 }
 
-__global__ void __launch_bounds__(64 * kScanWaves)
-splat_pack_tilescan_kernel(PackWs pw, int nb, uint32_t slice) {
-  __shared__ uint32_t s_w[kScanWaves];
-  constexpr int NT = 64 * kScanWaves;
-  const int per = ceil_div(nb, NT);
-  const int t0 = threadIdx.x * per, t1 = t0 + per < nb ? t0 + per : nb;
-  uint32_t sum_c = 0, sum_s = 0;
-  for (int i = t0; i < t1; ++i) {
-    const uint32_t c = pw.tile_count[i];
-    sum_c += c;
-    sum_s += 1u << tile_bands_log2(c, slice);
+// exclusive prefix of the group sums (records, items) for group g, from one wave's scan over all
+// groups; s_g: [2][ngroups + 1] words of LDS, filled by wave 0 and published by a barrier
+__device__ __forceinline__ void scan_groups(const PackWs& pw, int ngroups, uint32_t* s_g) {
+  if (threadIdx.x < 64) {
+    uint32_t run_c = 0, run_s = 0;
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+      const int g = g0 + threadIdx.x;
+      const uint32_t c = g < ngroups ? pw.group_tot[2 * g] : 0u;
+      const uint32_t sb = g < ngroups ? pw.group_tot[2 * g + 1] : 0u;
+      const uint32_t ic = wave_incl_scan_u32(c), is = wave_incl_scan_u32(sb);
+      if (g < ngroups) {
+        s_g[g] = run_c + ic - c;
+        s_g[ngroups + 1 + g] = run_s + is - sb;
+      }
+      run_c += (uint32_t)__shfl((int)ic, 63, 64);
+      run_s += (uint32_t)__shfl((int)is, 63, 64);
+    }
+    if (threadIdx.x == 0) {
+      s_g[ngroups] = run_c;
+      s_g[2 * ngroups + 1] = run_s;
+    }
   }
-  uint32_t tot_c, tot_s;
-  uint32_t run_c = block_excl_scan_u32<kScanWaves>(sum_c, s_w, &tot_c);
-  uint32_t run_s = block_excl_scan_u32<kScanWaves>(sum_s, s_w, &tot_s);
-  for (int i = t0; i < t1; ++i) {
-    const uint32_t c = pw.tile_count[i];
-    const int lg = tile_bands_log2(c, slice);
-    pw.tile_start[i] = run_c;
-    for (uint32_t band = 0; band < (1u << lg); ++band)
-      pw.items[run_s + band] = (uint32_t)i | (band << 20) | ((uint32_t)lg << 24);
-    run_c += c;
-    run_s += 1u << lg;
-  }
-  if (threadIdx.x == 0) {
-    pw.tile_start[nb] = tot_c;
-    pw.ctl[2] = tot_s;
-  }
+  __syncthreads();
 }
 
-// P3.  Pure permutation: point-order records -> tile order.
+// P3.  Pure permutation: point-order records -> tile order.  The first workgroup of every image
+// also publishes tile_start and the resolve's item table.
 __global__ void __launch_bounds__(kPThreads)
-splat_pack_permute_kernel(int64_t m, int64_t per, int ntiles, PackWs pw) {
-  extern __shared__ uint32_t s_base[];   // [ntiles] next free record of this chunk, per tile
+splat_pack_permute_kernel(int64_t m, int64_t per, int ntiles, int nimages, PackWs pw) {
+  extern __shared__ uint32_t s_dyn[];   // [ntiles] next free record of this chunk, per tile; group bases
+  uint32_t* s_base = s_dyn;
+  const int nb = nimages * ntiles, ngroups = (int)ceil_div(nb, 64);
+  uint32_t* s_g = s_dyn + ntiles;       // [2][ngroups + 1]
   const int b = blockIdx.y;
+  scan_groups(pw, ngroups, s_g);
   {
-    const uint32_t* start = pw.tile_start + (int64_t)b * ntiles;
     const uint32_t* row = pw.hist + ((int64_t)b * gridDim.x + blockIdx.x) * ntiles;
-    for (int t = threadIdx.x; t < ntiles; t += kPThreads) s_base[t] = start[t] + row[t];
+    const bool publish = blockIdx.x == 0;
+    for (int t = threadIdx.x; t < ntiles; t += kPThreads) {
+      const int gt = b * ntiles + t;
+      const uint32_t start = s_g[gt >> 6] + pw.tile_lstart[gt];
+      s_base[t] = start + row[t];
+      if (publish) {
+        pw.tile_start[gt] = start;
+      }
+    }
+    if (publish) {
+      // items of this image's tiles (bands per tile from the difference of consecutive first items)
+      for (int t = threadIdx.x; t < ntiles; t += kPThreads) {
+        const int gt = b * ntiles + t;
+        const uint32_t first = s_g[ngroups + 1 + (gt >> 6)] + pw.tile_litem[gt];
+        const uint32_t next = gt + 1 < nb ? s_g[ngroups + 1 + ((gt + 1) >> 6)] + pw.tile_litem[gt + 1]
+                                          : s_g[2 * ngroups + 1];
+        const uint32_t bands = next - first;
+        uint32_t lg = 0;
+        while ((1u << lg) < bands) ++lg;
+        for (uint32_t band = 0; band < bands; ++band)
+          pw.items[first + band] = (uint32_t)gt | (band << 20) | (lg << 24);
+      }
+      if (b == nimages - 1 && threadIdx.x == 0) {
+        pw.tile_start[nb] = s_g[ngroups];
+        pw.ctl[2] = s_g[2 * ngroups + 1];
+      }
+    }
   }
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
@@ -1870,7 +1925,7 @@ __global__ void __launch_bounds__(kPResolveThreads)
 splat_pack_resolve_kernel(int height, int width, int ntiles, int tiles_x, float depth_scale,
                           float output_void, float mask_void, float* __restrict__ depth,
                           float* __restrict__ feat, float* __restrict__ mask, SplatWs ws, PackWs pw,
-                          uint32_t zpart_count, uint32_t items_max) {
+                          uint32_t zpart_count, int vec_out) {
   __shared__ uint32_t s_z[kPTilePx];
   __shared__ uint32_t s_fe[C][kPTilePx];
   __shared__ uint32_t s_w[kPResolveThreads / 64];
@@ -1980,29 +2035,63 @@ splat_pack_resolve_kernel(int height, int width, int ntiles, int tiles_x, float 
     if ((int)threadIdx.x < C) {
       uint32_t v = 0u;
       for (int i = 0; i < kPResolveThreads / 64; ++i) v = s_c[threadIdx.x][i] > v ? s_c[threadIdx.x][i] : v;
-      pw.fpart2[(int64_t)item * C + threadIdx.x] = v;
+      // a few thousand atomics spread over kSinkSlots x C words (one word per channel would
+      // serialise at ~12 ns each; a row per item costs the fold kernel 12 K loads)
+      if (v != 0u) atomicMax(&pw.fpart2[(item % kSinkSlots) * C + threadIdx.x], v);
     }
-    // finalize this item's pixels
+    // finalize this item's pixels: a thread owns 4 consecutive pixels of a row (16-byte stores of
+    // depth, mask and the 4 C feature floats) when the outputs allow it
     const int64_t hw = (int64_t)height * width;
-    for (int p = threadIdx.x; p < kPTilePx; p += kPResolveThreads) {
-      const int y = ty * kPTileY + p / kPTileX, x = tx * kPTileX + (p % kPTileX);
-      if (y >= height || x >= width || !mine((uint32_t)p)) continue;
-      const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
+    auto pixel = [&](int p, int64_t i, float* d_out, float (&f_out)[C], float* m_out) {
       float z = __uint_as_float(s_z[p]);
       if (i == 0 && have_sink_z) z = sink_z < z ? sink_z : z;
       float d = z < 0.0f ? 0.0f : (z > depth_scale ? depth_scale : z);
       d = d / depth_scale;
-      depth[i] = d;
       bool all_ok = true;
 #pragma unroll
       for (int k = 0; k < C; ++k) {
         // scatter_max over fill(output_void >= 0): a feature of 0 and "no survivor" coincide
         const float fv = (float)s_fe[k][p];
         const float v = fv > output_void ? fv : output_void;
-        feat[i * C + k] = v;
+        f_out[k] = v;
         all_ok = all_ok && (v != mask_void);
       }
-      if (mask) mask[i] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+      *d_out = d;
+      *m_out = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+    };
+    if (vec_out) {
+      for (int q = threadIdx.x; q < kPTilePx / 4; q += kPResolveThreads) {
+        const int p0 = 4 * q;
+        const int y = ty * kPTileY + p0 / kPTileX, x = tx * kPTileX + (p0 % kPTileX);
+        if (y >= height || x >= width || !mine((uint32_t)p0)) continue;   // (width % 4 == 0)
+        const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
+        float d[4], mk[4], f[4][C];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pixel(p0 + e, i + e, &d[e], f[e], &mk[e]);
+        *reinterpret_cast<float4*>(depth + i) = make_float4(d[0], d[1], d[2], d[3]);
+        if (mask) *reinterpret_cast<float4*>(mask + i) = make_float4(mk[0], mk[1], mk[2], mk[3]);
+        float flat[4 * C];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < C; ++k) flat[e * C + k] = f[e][k];
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+          *reinterpret_cast<float4*>(feat + i * C + 4 * k) =
+              make_float4(flat[4 * k], flat[4 * k + 1], flat[4 * k + 2], flat[4 * k + 3]);
+      }
+    } else {
+      for (int p = threadIdx.x; p < kPTilePx; p += kPResolveThreads) {
+        const int y = ty * kPTileY + p / kPTileX, x = tx * kPTileX + (p % kPTileX);
+        if (y >= height || x >= width || !mine((uint32_t)p)) continue;
+        const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
+        float d, mk, f[C];
+        pixel(p, i, &d, f, &mk);
+        depth[i] = d;
+#pragma unroll
+        for (int k = 0; k < C; ++k) feat[i * C + k] = f[k];
+        if (mask) mask[i] = mk;
+      }
     }
   }
 }
@@ -2014,7 +2103,6 @@ __global__ void __launch_bounds__(1024)
 splat_pack_sink_kernel(float* __restrict__ depth, float* __restrict__ feat, float* __restrict__ mask,
                        float mask_void, SplatWs ws, PackWs pw, uint32_t zpart_count) {
   __shared__ uint32_t s_c[C][16];
-  const uint32_t nitems = pw.ctl[2];
   uint32_t fm[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) fm[k] = 0u;
@@ -2025,7 +2113,7 @@ splat_pack_sink_kernel(float* __restrict__ depth, float* __restrict__ feat, floa
     for (int kk = 0; kk < C; ++kk)
       if (kk == k) fm[kk] = v > fm[kk] ? v : fm[kk];
   }
-  for (uint32_t i = threadIdx.x; i < nitems * C; i += 1024) {
+  for (uint32_t i = threadIdx.x; i < (uint32_t)kSinkSlots * C; i += 1024) {
     const uint32_t v = pw.fpart2[i];
     const int k = i % C;
 #pragma unroll
@@ -2091,6 +2179,11 @@ int launch_splat_packed(const float* coords, const float* offset, const T* feats
   const int items = (int)resolve_items_max(nb, (int64_t)n * m, slice);
   const int vec = (ld % 4 == 0) && ((uintptr_t)coords % 16 == 0) &&
                   ((uintptr_t)feats % (sizeof(T) == 1 ? 4 : 16) == 0);
+  // 16-byte output stores (4 pixels per thread) measured 2 % SLOWER than one pixel per thread with
+  // dword stores (100.3 vs 98.2 us per render, same box): opt-in for A/B runs only
+  static const bool want_vec_out = getenv("SE3DS_PACK_VEC_OUT") != nullptr;
+  const int vec_out = want_vec_out && (width % 4 == 0) && ((uintptr_t)depth % 16 == 0) &&
+                      ((uintptr_t)feat % 16 == 0) && (mask == nullptr || (uintptr_t)mask % 16 == 0);
   static const bool dbg = [] {
     const char* e = getenv("SE3DS_SPLAT_DEBUG");
     return e && atoi(e) != 0;
@@ -2106,15 +2199,13 @@ int launch_splat_packed(const float* coords, const float* offset, const T* feats
   }
 #undef SE3DS_P1
   hipLaunchKernelGGL(splat_pack_colscan_kernel, dim3(ceil_div(nb, 64)), dim3(64 * kScanWaves), 0,
-                     stream, pw, cg.chunks, ntiles, nb);
-  hipLaunchKernelGGL(splat_pack_tilescan_kernel, dim3(1), dim3(64 * kScanWaves), 0, stream, pw, nb,
-                     slice);
-  hipLaunchKernelGGL(splat_pack_permute_kernel, g_pt, dim3(kPThreads), 4 * ntiles, stream, m, cg.per,
-                     ntiles, pw);
+                     stream, pw, cg.chunks, ntiles, nb, slice);
+  hipLaunchKernelGGL(splat_pack_permute_kernel, g_pt, dim3(kPThreads),
+                     4 * (ntiles + 2 * ((int)ceil_div(nb, 64) + 1)), stream, m, cg.per, ntiles, n, pw);
 #define SE3DS_P4(CC)                                                                              \
   hipLaunchKernelGGL((splat_pack_resolve_kernel<CC>), dim3(items), dim3(kPResolveThreads), 0,     \
                      stream, height, width, ntiles, tiles_x, depth_scale, output_void, mask_void,  \
-                     depth, feat, mask, ws, pw, (uint32_t)nparts, (uint32_t)items);                \
+                     depth, feat, mask, ws, pw, (uint32_t)nparts, vec_out);                        \
   hipLaunchKernelGGL((splat_pack_sink_kernel<CC>), dim3(1), dim3(1024), 0, stream, depth, feat,   \
                      mask, mask_void, ws, pw, (uint32_t)nparts)
   switch (channels) {

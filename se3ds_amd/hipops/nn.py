@@ -6,6 +6,7 @@ each op appends a closure; gradient accumulation for tensors with several consum
 `se3ds_add`, parameter gradients are written straight into a flat fp32 arena.
 """
 import math
+import threading
 from typing import List, Optional
 
 import numpy as np
@@ -224,8 +225,16 @@ class Ctx:
     # {tag: torch.cuda.Stream}, None = everything on the current stream.  Ops record the branch
     # they ran in; backward() replays each branch's closures on its stream (see branch()).
     self.streams = None
-    self.branch_tag = 0
+    self.stream_phases = ('fwd', 'bwd')   # debugging: restrict the branch streams to one pass
+    self._tl = threading.local()   # branch_tag is per host thread (paired branches run in two)
     self._forked = set()
+    # Several replicas: two structurally identical branches run in lockstep so that their k-th
+    # SyncBatchNormalization sums share ONE all-reduce (run_branches / _PairSync forward,
+    # allreduce_then backward).  collectives counts the all-reduces issued through this context.
+    self.pair = None
+    self.collectives = 0
+    self._bwd_pending = None
+    self._cur_paired = False
     self.group = group
     # Replica count of the STRATEGY that built the model, never probed from global
     # torch.distributed state: a one-device model inside an initialised process group must not
@@ -245,6 +254,8 @@ class Ctx:
   def ws(self, key, nbytes):
     if self.streams is not None:   # scratch is per stream: branches run concurrently
       key = (key, torch.cuda.current_stream(self.device).cuda_stream)
+    elif self.pair is not None:    # ... or per branch: two host threads issue them in lockstep
+      key = (key, self.branch_tag)
     t = self._ws.get(key)
     if t is None or t.numel() < nbytes:
       t = torch.empty((int(nbytes),), dtype=torch.uint8, device=self.device)
@@ -254,9 +265,41 @@ class Ctx:
   def empty(self, shape, dtype=None):
     return torch.empty(shape, dtype=dtype or self.dtype, device=self.device)
 
-  def record(self, fn):
+  @property
+  def branch_tag(self):
+    return getattr(self._tl, 'tag', 0)
+
+  @branch_tag.setter
+  def branch_tag(self, tag):
+    self._tl.tag = tag
+
+  def record(self, fn, sync=False):
+    """sync: the closure issues one cross-replica all-reduce through allreduce_then."""
     if self.tape is not None:
-      self.tape.append((fn, self.branch_tag))
+      self.tape.append((fn, self.branch_tag, 1 if sync else 0))
+
+  def run_branches(self, fns):
+    """fns = {tag: callable}: independent branches of the graph; returns {tag: result}.  One
+    replica: one after the other, each under branch(tag) (its own HIP stream when the context has
+    streams).  Several replicas and exactly two branches: in two host threads in LOCKSTEP -- both
+    reach their k-th SyncBatchNormalization before either continues, and the two [2][C] sums go
+    out as one all-reduce (the two decoders hold 168 of the generator's 279 batch
+    norms).  The kernels of both threads go to the current stream; what a branch touches is its
+    own (layers, activations, per-branch scratch)."""
+    if self.world > 1 and _PAIR_SYNCBN and len(fns) == 2:
+      return _run_paired(self, fns)
+    out = {}
+    keep = self.streams
+    if 'fwd' not in self.stream_phases:
+      self.streams = None
+    try:
+      for tag, fn in fns.items():
+        with self.branch(tag):
+          out[tag] = fn()
+      self.join()
+    finally:
+      self.streams = keep
+    return out
 
   def branch(self, tag):
     """with ctx.branch(tag): ops of one independent branch.  With Ctx.streams the branch's
@@ -268,7 +311,7 @@ class Ctx:
     return _Branch(self, tag)
 
   def join(self):
-    if self._forked:
+    if self._forked and self.streams is not None:
       main = torch.cuda.current_stream(self.device)
       for tag in sorted(self._forked):
         main.wait_stream(self.streams[tag])
@@ -276,8 +319,20 @@ class Ctx:
 
   def backward(self):
     tape, self.tape = self.tape, []
+    if self.world > 1 and _PAIR_SYNCBN:
+      tape = _merge_paired(tape)
+    keep = self.streams
+    if 'bwd' not in self.stream_phases:
+      self.streams = None
+    try:
+      self._replay(tape)
+    finally:
+      self.streams = keep
+
+  def _replay(self, tape):
     cur, scope = 0, None
-    for fn, tag in reversed(tape):
+    for fn, tag, sync in reversed(tape):
+      self._cur_paired = sync == 2
       t = tag if self.streams is not None else 0
       if t != cur:   # (one stream switch per run of closures, not per closure)
         if scope is not None:
@@ -292,6 +347,8 @@ class Ctx:
       fn()
     if scope is not None:
       scope.__exit__(None, None, None)
+    self._cur_paired = False
+    assert self._bwd_pending is None, 'unpaired SyncBN backward'
     self.join()
 
   def mark_segment(self, name):
@@ -301,14 +358,48 @@ class Ctx:
       def fire():
         if self.on_segment is not None and self.param_grads:
           self.on_segment(name)
-      self.tape.append((fire, self.branch_tag))
+      self.tape.append((fire, self.branch_tag, 0))
+
+  def _allreduce_joint(self, a, b):
+    """ONE all-reduce for two tensors (a pair of SyncBN sums)."""
+    buf = torch.cat([a.reshape(-1), b.reshape(-1)])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+    a.copy_(buf[:a.numel()].view_as(a))
+    b.copy_(buf[a.numel():].view_as(b))
+    self._after_collective()
+
+  def _after_collective(self):
+    self.collectives += 1
+    cb = getattr(self, 'after_collective', None)
+    if cb is not None:
+      cb()   # (GradSync.pump: pending gradient buckets go out behind this collective)
 
   def allreduce_sum(self, t):
     if self.world > 1:
+      pair = self.pair
+      if pair is not None and self.branch_tag:
+        pair.allreduce(t, self.branch_tag)   # forward of two branches in lockstep threads
+        return
       dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-      cb = getattr(self, 'after_collective', None)
-      if cb is not None:
-        cb()   # (GradSync.pump: one pending gradient bucket goes out behind this collective)
+      self._after_collective()
+
+  def allreduce_then(self, t, cont):
+    """Backward closures: all-reduce `t`, then run cont().  When backward() has placed this
+    closure next to its twin of the other branch (_merge_paired), the first of the two only parks
+    (t, cont); the second reduces both tensors in one collective and runs both continuations."""
+    if self.world > 1:
+      if self._cur_paired:
+        if self._bwd_pending is None:
+          self._bwd_pending = (t, cont)
+          return
+        t0, cont0 = self._bwd_pending
+        self._bwd_pending = None
+        self._allreduce_joint(t0, t)
+        cont0()
+        cont()
+        return
+      self.allreduce_sum(t)
+    cont()
 
 
 class _Branch:
@@ -331,6 +422,101 @@ class _Branch:
     if self.scope is not None:
       self.scope.__exit__(*a)
     self.ctx.branch_tag = self.prev
+
+
+_PAIR_SYNCBN = os.environ.get('SE3DS_PAIR_SYNCBN', '1') != '0'
+
+
+class _PairSync:
+  """Rendezvous of two branch threads at their SyncBN sums (forward pass)."""
+
+  def __init__(self, ctx, lead, other):
+    self.ctx, self.lead, self.other = ctx, lead, other
+    self.barrier = threading.Barrier(2)
+    self.slot = {}
+
+  def allreduce(self, t, tag):
+    self.slot[tag] = t
+    self.barrier.wait()
+    if tag == self.lead:
+      # both statistics kernels are already enqueued on the (one) stream
+      self.ctx._allreduce_joint(self.slot[self.lead], self.slot[self.other])
+    self.barrier.wait()   # the partner continues only behind the enqueued copy-back
+
+
+def _run_paired(ctx, fns):
+  lead, other = sorted(fns)
+  pair = _PairSync(ctx, lead, other)
+  res, err = {}, []
+  on_gpu = ctx.device.type == 'cuda'
+  dev, stream = ctx.device, (torch.cuda.current_stream(ctx.device) if on_gpu else None)
+
+  def work(tag):
+    try:
+      if on_gpu:
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(stream):
+          with ctx.branch(tag):
+            res[tag] = fns[tag]()
+      else:   # (host-only contexts: the CPU tests of the pairing logic)
+        with ctx.branch(tag):
+          res[tag] = fns[tag]()
+    except BaseException as e:   # noqa: B902  (re-raised in the caller's thread)
+      err.append(e)
+      pair.barrier.abort()
+
+  ctx.pair = pair
+  try:
+    th = threading.Thread(target=work, args=(other,), name='se3ds-branch')
+    th.start()
+    work(lead)
+    th.join()
+  finally:
+    ctx.pair = None
+  if err:
+    real = [e for e in err if not isinstance(e, threading.BrokenBarrierError)]
+    raise (real or err)[0]
+  return res
+
+
+def _merge_paired(tape):
+  """Reorders every run of branch-tagged tape entries (two branches, recorded by two threads in
+  arbitrary interleaving) so that the k-th sync closure of one branch sits NEXT to the k-th of
+  the other: a_seg0, b_seg0, a_sync0, b_sync0, a_seg1, ...  Per-branch order is kept (the
+  branches are independent), and the adjacent sync closures are flagged 2 = paired."""
+  out, i, n = [], 0, len(tape)
+  while i < n:
+    if tape[i][1] == 0:
+      out.append(tape[i])
+      i += 1
+      continue
+    j = i
+    while j < n and tape[j][1] != 0:
+      j += 1
+    run = tape[i:j]
+    tags = sorted({e[1] for e in run})
+    merged = None
+    if len(tags) == 2:
+      parts = {t: [e for e in run if e[1] == t] for t in tags}
+      if sum(e[2] for e in parts[tags[0]]) == sum(e[2] for e in parts[tags[1]]):
+        def segments(entries):
+          segs, cur = [], []
+          for e in entries:
+            if e[2]:
+              segs.append((cur, e))
+              cur = []
+            else:
+              cur.append(e)
+          return segs, cur
+        sa, ta = segments(parts[tags[0]])
+        sb, tb = segments(parts[tags[1]])
+        merged = []
+        for (seg_a, sync_a), (seg_b, sync_b) in zip(sa, sb):
+          merged += seg_a + seg_b + [(sync_a[0], sync_a[1], 2), (sync_b[0], sync_b[1], 2)]
+        merged += ta + tb
+    out += merged if merged is not None else run
+    i = j
+  return out
 
 
 def _grad_wait(var):
@@ -521,17 +707,24 @@ class ConvLayer:
     ent = self._copies.get(ctx.dtype)
     if ent is not None and ent[0] == self.store.version:
       return ent[1], ent[2]
+    return self.prep(ctx.dtype, self.store.version)
+
+  def prep(self, dtype, version):
+    """Writes the operand copies from the current master weights and stamps them `version` (the
+    trainer refreshes a module's copies right behind its Adam update, on the optimiser's side
+    stream, stamped with the version the store will have when the step ends)."""
+    ent = self._copies.get(dtype)
     w = self.kernel
     K = w.shape[0] * w.shape[1] * w.shape[2]
     co = w.shape[3]
     if ent is None:
-      wt = torch.empty((co, K), dtype=ctx.dtype, device=ctx.device)
-      wn = torch.empty((K, co), dtype=ctx.dtype, device=ctx.device)
+      wt = torch.empty((co, K), dtype=dtype, device=w.device)
+      wn = torch.empty((K, co), dtype=dtype, device=w.device)
     else:
       wt, wn = ent[1], ent[2]
-    _chk(_L().se3ds_weight_prep(w.data_ptr(), K, co, ctx.code, wt.data_ptr(), wn.data_ptr(),
-                                _lib.stream()), 'se3ds_weight_prep')
-    self._copies[ctx.dtype] = (self.store.version, wt, wn)
+    _chk(_L().se3ds_weight_prep(w.data_ptr(), K, co, _lib.dtype_code(wt), wt.data_ptr(),
+                                wn.data_ptr(), _lib.stream()), 'se3ds_weight_prep')
+    self._copies[dtype] = (version, wt, wn)
     return wt, wn
 
 
@@ -944,6 +1137,7 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
   out = Var(y)
   if act != ACT_NONE and ctx.act_taps is not None:
     ctx.act_taps[layer.name] = y
+  sync_bwd = (not inst) and ctx.world > 1 and not use_moving   # the backward all-reduces too
   if ctx.tape is not None:
     def bwd(g=g):
       dy = out.grad
@@ -994,20 +1188,28 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
           tot = _colsum(ctx, bs.data_ptr(), _lib.F32, g, 2 * c)
           st.grad_views[layer.name + '/beta'].copy_(tot[0, 0, :c])
           st.grad_views[layer.name + '/gamma'].copy_(tot[0, 0, c:])
-        if not inst and ctx.world > 1:
-          ctx.allreduce_sum(bs)   # SyncBN backward: statistics gradients are global
-        _chk(L.se3ds_norm_bwd_apply(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c,
-                                    mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                                    bs.data_ptr(), count, act, float(alpha), dx.data_ptr(),
-                                    _lib.ptr(dres), _lib.ptr(amask),
-                                    in_act[0] if in_act else 0, float(in_act[1]) if in_act else 0.0,
-                                    _lib.stream()), 'se3ds_norm_bwd_apply')
-        if in_act:
-          x.grad_pre_act = True
+
+        def finish():
+          _chk(L.se3ds_norm_bwd_apply(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c,
+                                      mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                      bs.data_ptr(), count, act, float(alpha), dx.data_ptr(),
+                                      _lib.ptr(dres), _lib.ptr(amask),
+                                      in_act[0] if in_act else 0, float(in_act[1]) if in_act else 0.0,
+                                      _lib.stream()), 'se3ds_norm_bwd_apply')
+          if in_act:
+            x.grad_pre_act = True
+          accumulate(x, dx)
+          if want_res:
+            accumulate(res, dres)
+        if sync_bwd:
+          ctx.allreduce_then(bs, finish)   # SyncBN backward: statistics gradients are global
+        else:
+          finish()
+        return
       accumulate(x, dx)
       if want_res:
         accumulate(res, dres)
-    ctx.record(bwd)
+    ctx.record(bwd, sync=sync_bwd)
   return out
 
 

@@ -18,6 +18,7 @@ from se3ds_amd.models import layers
 
 # independent branches of a model on their own HIP streams (SE3DS_DUAL_STREAM=0: one stream)
 _DUAL_STREAM = os.environ.get('SE3DS_DUAL_STREAM', '1') != '0'
+_DUAL_PHASES = os.environ.get('SE3DS_DUAL_PHASES', '')   # debugging: 'fwd' or 'bwd' only
 
 
 def _conv_layers_of(obj, out=None, seen=None):
@@ -70,12 +71,20 @@ class _Model:
     silently running unsynchronised batch norm."""
     ctx = Ctx(self.device, dtype or self.dtype, training=bool(training), record=record,
               group=group, world=world)
+    if record:
+      # The gradient arena is created on first use.  That must happen HERE, on the stream the
+      # step runs on: created lazily by the first backward closure it would be zero-filled on a
+      # BRANCH stream while the other branch already writes its gradients into it (found as an
+      # intermittent 1e-10 difference of the step-0 update, tools/step_compare.py).
+      self.store.grad
     if ctx.world == 1 and _DUAL_STREAM and nn.conv_profiler() is None:
       # (not while the bench times single convolution launches: overlapped kernels would be
       # charged each other's time)
       if getattr(self, '_branch_streams', None) is None:
         self._branch_streams = {1: torch.cuda.Stream(self.device), 2: torch.cuda.Stream(self.device)}
       ctx.streams = self._branch_streams
+      if _DUAL_PHASES:
+        ctx.stream_phases = tuple(_DUAL_PHASES.split(','))
     return ctx
 
 
@@ -161,8 +170,15 @@ class ResNetDecoder:
     else:
       agent_fn = conv_fn
     d = hidden_dims
+    self.name = name
     self.upc_conv = conv_fn(store, name + '/upc/conv', d * 4, d * 2, 1, 1, 'SAME')
     self.upc_bn = layers.SyncBatchNormalization(store, name + '/upc/bn', d * 2)
+    def agent(nm, cin, cout):
+      conv = agent_fn(store, name + '/' + nm, cin, cout, 1, 1, 'SAME', use_bias=False)
+      return conv, layers.SyncBatchNormalization(store, name + '/' + nm + '_bn', cout)
+    # (agent4 runs between upc and deconv1: registered there, so that the parameters of the
+    # modules whose backward ends LAST -- upc, agent4 -- are contiguous in the arena, see segments())
+    self.agent4, self.agent4_bn = agent('agent4', d * 2, d * 8)
     if resnet_version == '50':
       filters = [6, 4, 3, 3]
     elif resnet_version == '101':
@@ -180,18 +196,29 @@ class ResNetDecoder:
                                             strides=2, circular_pad=circular_pad, conv_fn=conv_fn)
     self.deconv4 = layers.ResStackTranspose(store, name + '/deconv4', d, d, filters[3],
                                             strides=2, circular_pad=circular_pad, conv_fn=conv_fn)
-    def agent(nm, cin, cout):
-      conv = agent_fn(store, name + '/' + nm, cin, cout, 1, 1, 'SAME', use_bias=False)
-      return conv, layers.SyncBatchNormalization(store, name + '/' + nm + '_bn', cout)
     self.agent0, self.agent0_bn = agent('agent0', d, d)            # skip b1 (d)
     self.agent1, self.agent1_bn = agent('agent1', d * 4, d)        # skip s1 (4d)
     self.agent2, self.agent2_bn = agent('agent2', d * 8, d * 2)    # skip s2 (8d)
     self.agent3, self.agent3_bn = agent('agent3', d * 16, d * 4)   # skip s3 (16d)
-    self.agent4, self.agent4_bn = agent('agent4', d * 2, d * 8)
     self.final_conv = layers.ResStackTranspose(store, name + '/final_conv', d, d, 3,
                                                circular_pad=circular_pad)   # plain Conv2D
     self.final_deconv = layers.Conv2DTranspose(store, name + '/final_deconv', d, output_dim, 2, 2,
                                                use_bias=True)
+
+  def segments(self):
+    """{segment: parameter-name prefixes}, each contiguous in the arena.  deconv1 holds 0.96 of a
+    decoder's parameters and its blocks finish one after the other during the last 3/4 of the
+    decoder's backward pass: one segment per block lets their gradients (and, on one replica,
+    their Adam updates) stream out under the rest of it."""
+    n = self.name
+    segs = {n + '_head': (n + '/upc', n + '/agent4', n + '/agent4_bn', n + '/deconv1/upsample')}
+    for i in range(len(self.deconv1.block)):
+      segs[f'{n}/deconv1/block{i}'] = (f'{n}/deconv1/block{i}',)
+    tail = [n + '/deconv2', n + '/deconv3', n + '/deconv4']
+    for k in range(4):
+      tail += [f'{n}/agent{k}', f'{n}/agent{k}_bn']
+    segs[n + '_tail'] = tuple(tail + [n + '/final_conv', n + '/final_deconv'])
+    return segs
 
   def _agent(self, ctx, conv, bn, x, mask):
     if self.partial_conv:
@@ -203,11 +230,15 @@ class ResNetDecoder:
   def __call__(self, ctx: Ctx, x: Var, skip: List[Var], masks=None) -> Var:
     if masks is None:
       masks = [None] * len(skip)
+    # gradient-synchronisation segments in the order their backward passes END (segments()):
+    # tail (everything behind deconv1), deconv1's blocks from the last to the first, head
+    ctx.mark_segment(self.name + '_head')
     out = self.upc_conv(ctx, x)
     out = self.upc_bn(ctx, out, act=ACT_LRELU, alpha=0.2)
     out = nn.upsample2x(ctx, out)
     out = self._agent(ctx, self.agent4, self.agent4_bn, out, None)
-    out = self.deconv1(ctx, out)
+    out = self.deconv1(ctx, out, mark=self.name + '/deconv1')
+    ctx.mark_segment(self.name + '_tail')
     out = nn.add(ctx, out, self._agent(ctx, self.agent3, self.agent3_bn, skip[3], masks[3]))
     out = self.deconv2(ctx, out)
     out = nn.add(ctx, out, self._agent(ctx, self.agent2, self.agent2_bn, skip[2], masks[2]))
@@ -243,13 +274,13 @@ class ResNetGenerator(_Model):
   """ResNet generator model with partial convs (reference :27-193)."""
   # name -> parameter-name prefixes (contiguous in registration order).  The encoder is split per
   # stage so that only its first, tiny stages are reduced after the backward pass has ended.
-  SEGMENTS = {
+  _SEGMENTS = {
       'encoder_head': ('encoder/conv1', 'encoder/bn1'),
       'encoder/stack1': ('encoder/stack1',), 'encoder/stack2': ('encoder/stack2',),
       'encoder/stack3': ('encoder/stack3',), 'encoder/stack4': ('encoder/stack4',),
       'encoder_tail': ('encoder/final_conv', 'encoder/final_bn'),
-      'decoder': ('decoder',), 'depth_decoder': ('depth_decoder',), 'rgb_conv': ('rgb_conv',),
-      'depth_conv': ('depth_conv',), 'context': ('context',)}
+      'rgb_conv': ('rgb_conv',), 'depth_conv': ('depth_conv',), 'context': ('context',)}
+  # (+ the decoders' own segments: SEGMENTS is completed per instance in __init__)
 
   def __init__(self, image_size: int = 256, gen_dims: int = 96, z_dim: int = 128,
                resnet_version: str = '50', context_layer: str = 'convs',
@@ -284,6 +315,9 @@ class ResNetGenerator(_Model):
       self.ctx_pad = layers.PadLayer(1, circular_pad=True)
       self.ctx_conv = [layers.SpectralConv(s, f'context/conv{i}', chans[i], chans[i + 1], 3, 1,
                                            'VALID') for i in range(4)]
+    self.SEGMENTS = dict(self._SEGMENTS)
+    self.SEGMENTS.update(self.decoder.segments())
+    self.SEGMENTS.update(self.depth_decoder.segments())
     self._finish(device, seed, dtype)
 
   # -- differentiable forward used by the trainer
@@ -314,29 +348,35 @@ class ResNetGenerator(_Model):
     if ctx.streams is not None:
       for v in list(skip) + [hidden]:
         v.shared = True
-    with ctx.branch(1):
-      ctx.mark_segment('decoder')
-      out = self.decoder(ctx, hidden, skip)
-    with ctx.branch(2):
-      ctx.mark_segment('depth_decoder')
-      depth_out = self.depth_decoder(ctx, hidden, skip)
+    def rgb_branch():
+      o = self.decoder(ctx, hidden, skip)   # (marks its own segments)
+      ctx.mark_segment('rgb_conv')
+      pre = self.rgb_conv(ctx, o)
+      return (o,) + nn.head(ctx, pre, 0)
+    def depth_branch():
+      o = self.depth_decoder(ctx, hidden, skip)
+      ctx.mark_segment('depth_conv')
+      pre = self.depth_conv(ctx, o)
+      return (o,) + nn.head(ctx, pre, 1)
+    # one replica: each branch on its own HIP stream; several: lockstep, paired SyncBN sums
+    res = ctx.run_branches({1: rgb_branch, 2: depth_branch})
+    ctx.join()
+    out, rgb, push_rgb = res[1]
+    depth_out, depth, push_depth = res[2]
     if taps is not None:
       taps.update(ctx=hidden, dec=out, ddec=depth_out)
-    with ctx.branch(1):
-      ctx.mark_segment('rgb_conv')
-      rgb_pre = self.rgb_conv(ctx, out)
-      rgb, push_rgb = nn.head(ctx, rgb_pre, 0)
-    with ctx.branch(2):
-      ctx.mark_segment('depth_conv')
-      depth_pre = self.depth_conv(ctx, depth_out)
-      depth, push_depth = nn.head(ctx, depth_pre, 1)
-    ctx.join()
-    dev = ctx.device
-    zeros = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+    # mu / logvar / kld / seg / depth_seg are constant zeros (reference :308-312, :191-193): one
+    # allocation per shape instead of 1.4 GB of memset per 512 x 1024 batch-8 step.  Consumers
+    # only read them (as the reference's do: tf.zeros are immutable).
+    zc = self.__dict__.setdefault('_zeros', {})
+    def zeros(*shape):
+      key = (shape, str(ctx.device))
+      if key not in zc:
+        zc[key] = torch.zeros(shape, dtype=torch.float32, device=ctx.device)
+      return zc[key]
     mu = zeros(n, hh, hw, self.z_dim)
     seg = zeros(n, h, w, constants.NUM_MP3D_CLASSES)
-    outs = [mu, zeros(n, hh, hw, self.z_dim), zeros(n, hh, hw, self.z_dim), depth, seg,
-            torch.zeros_like(seg), rgb]
+    outs = [mu, mu, mu, depth, seg, seg, rgb]
     return outs, (push_rgb, push_depth)
 
   def __call__(self, inputs, sample_noise: bool = False, training=None) -> List[torch.Tensor]:

@@ -232,7 +232,12 @@ class ResStackTranspose:
                                       upsample=upsample, circular_pad=circular_pad,
                                       conv_fn=conv_fn))
 
-  def __call__(self, ctx: Ctx, x: Var) -> Var:
-    for b in self.block:
+  def __call__(self, ctx: Ctx, x: Var, mark: Optional[str] = None) -> Var:
+    """mark: segment-name prefix; a gradient-synchronisation marker `mark/block{i}` is placed in
+    front of every block (ResNetGenerator.SEGMENTS), so that a block's parameter gradients can be
+    clipped / reduced / applied as soon as the backward pass has left the block."""
+    for i, b in enumerate(self.block):
+      if mark is not None:
+        ctx.mark_segment(f'{mark}/block{i}')
       x = b(ctx, x)
     return x

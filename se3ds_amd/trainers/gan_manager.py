@@ -54,6 +54,7 @@ class AdamState:
     self.partial = torch.empty(self.chunks.shape[0], dtype=torch.float32, device=dev)
     self.sqnorm = torch.empty(len(model.store.trainable_names), dtype=torch.float32, device=dev)
     self.mean_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+    self.on_update = None   # tests: f(e0, e1), called right before Adam consumes grad[e0:e1]
 
   def _sn_ptr(self, fused_sn):
     """fused_sn: the model's spectral layers only ran SpectralGroup.backward_fixup(dots_only=True);
@@ -107,6 +108,29 @@ class AdamState:
         self.mean_norm.data_ptr(), _lib.stream()), 'se3ds_mean_clipped_norm')
     return self.mean_norm
 
+  def begin_step(self):
+    """Per-segment updates (apply_segment): the Adam step counter advances once per step."""
+    self.iterations += 1
+
+  def apply_segment(self, e0, e1, ema_theta=None, one_minus_decay=0.0):
+    """The Keras Adam update (+ the EMA of the same variables) on elements [e0, e1) of the arena:
+    a module is updated as soon as the backward pass has left it (se3ds_trainer.train_g_d), on a
+    side stream, while the rest of the backward pass still runs.  Element-wise, so the result is
+    bit-identical to one pass over the whole arena.  Call begin_step() first, end_step() last."""
+    st = self.model.store
+    if e1 <= e0:
+      return
+    if self.on_update is not None:
+      self.on_update(e0, e1)
+    _lib.check(_lib.lib().se3ds_multi_adam_keras_ema(
+        st.theta.data_ptr() + 4 * e0, st.grad.data_ptr() + 4 * e0, self.m.data_ptr() + 4 * e0,
+        self.v.data_ptr() + 4 * e0, e1 - e0, self.lr, self.beta_1, self.beta_2, self.epsilon,
+        self.iterations, (ema_theta.data_ptr() + 4 * e0) if ema_theta is not None else None,
+        float(one_minus_decay), _lib.stream()), 'se3ds_multi_adam_keras_ema')
+
+  def end_step(self):
+    self.model.store.version += 1
+
   def apply_gradients(self, group=None, world=1, ema_theta=None, one_minus_decay=0.0):
     """Cross-replica SUM of the (already clipped, already 1/R-scaled) gradients, then the
     Keras Adam update (reference se3ds_trainer.py:253-257).  With `ema_theta` (the EMA model's
@@ -114,6 +138,8 @@ class AdamState:
     st = self.model.store
     if world > 1:
       dist_utils.allreduce_arena_sum(st.grad, group)
+    if self.on_update is not None:
+      self.on_update(0, st.theta.numel())
     self.iterations += 1
     _lib.check(_lib.lib().se3ds_multi_adam_keras_ema(
         st.theta.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),

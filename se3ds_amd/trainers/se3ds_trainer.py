@@ -29,6 +29,8 @@ from se3ds_amd.trainers.gan_manager import Mean
 # the generator's spectral gradient fix-up rides on the clip pass (SE3DS_FUSED_SN_CLIP=0: separate passes)
 FUSED_SN_CLIP = os.environ.get('SE3DS_FUSED_SN_CLIP', '1') != '0'
 GRAD_CLIP_NORM = 5.0   # _clip_grad default, reference :27
+# one replica: per-module clip + Adam on a side stream under the backward pass (0: after it)
+SEGMENT_OPTIMIZER = os.environ.get('SE3DS_SEGMENT_OPTIMIZER', '1') != '0'
 
 
 def _L():
@@ -104,6 +106,38 @@ class GAN(gan_manager.GANManager):
       seeds_g.append(gg)
     return sums, seeds_d, seeds_g
 
+  def _segments(self):
+    """{module: (first tensor, end tensor, first element, end element)} of the generator's arena."""
+    if getattr(self, '_g_segments', None) is None:
+      G = self.generator
+      self._g_segments = G.store.segments(G.SEGMENTS)
+      covered = sum(t1 - t0 for t0, t1, _, _ in self._g_segments.values())
+      assert covered == len(G.store.trainable_names), 'generator segments miss some tensors'
+    return self._g_segments
+
+  def _all_conv_layers(self, model):
+    cache = self.__dict__.setdefault('_conv_layer_cache', {})
+    if id(model) not in cache:
+      from se3ds_amd.models import image_models
+      cache[id(model)] = image_models._conv_layers_of(model)
+    return cache[id(model)]
+
+  def _segment_layers(self, G):
+    """{module: [its ConvLayers]} by parameter-name prefix."""
+    if getattr(self, '_seg_layers', None) is None:
+      layers = self._all_conv_layers(G)
+      self._seg_layers = {
+          name: [l for l in layers if any(l.name.startswith(pre + '/') or l.name == pre
+                                          for pre in prefixes)]
+          for name, prefixes in G.SEGMENTS.items()}
+      assert sum(len(v) for v in self._seg_layers.values()) == len(layers), 'segments miss conv layers'
+    return self._seg_layers
+
+  def _optimizer_stream(self, dev):
+    if getattr(self, '_opt_stream', None) is None:
+      self._opt_stream = torch.cuda.Stream(dev)
+    return self._opt_stream
+
   def _grad_sync(self):
     """GradSync when gradients cross replicas (or SE3DS_FORCE_GRAD_SYNC=1, which exercises the
     segment-wise clip / side-stream path on one GPU), else None."""
@@ -129,9 +163,7 @@ class GAN(gan_manager.GANManager):
         torch.cuda.synchronize(G.store.theta.device)
       # shared communicator: buckets are drip-fed behind the SyncBN collectives (GradSync)
       self._sync = dist_utils.GradSync(G.store.theta.device, group, drip=not own)
-      self._g_segments = G.store.segments(G.SEGMENTS)
-      covered = sum(t1 - t0 for t0, t1, _, _ in self._g_segments.values())
-      assert covered == len(G.store.trainable_names), 'generator segments miss some tensors'
+      self._segments()
     return self._sync
 
   def _sync_discriminator(self, sync):
@@ -145,8 +177,8 @@ class GAN(gan_manager.GANManager):
   def _backward_tape(self, ctx, tape, seeds, logits):
     for sub, g in zip(logits, seeds):
       sub[-1].grad = g
-    for fn, _ in reversed(tape):   # (entries carry the stream branch they were recorded in: none here)
-      fn()
+    for entry in reversed(tape):   # (fn, stream branch, sync flag): no branches in the discriminator
+      entry[0]()
 
   # ------------------------------------------------------------------------------ train_g_d
   def train_g_d(self, inputs: Dict[str, torch.Tensor]) -> None:
@@ -257,7 +289,49 @@ class GAN(gan_manager.GANManager):
     push_depth(d_depth)
     # ---- clip per tensor (per replica), aggregate, apply (:238-257)
     ema_theta, ema_omd = self.ema_fused_args()   # EMA of the trainable variables rides on Adam
-    if sync is None:
+    if sync is None and SEGMENT_OPTIMIZER and nn.conv_profiler() is None:
+      # (not while the bench times single convolution launches: see _Model.make_ctx)
+      # One replica: a module's spectral fix-up, per-tensor clip and Adam (+ EMA) update run on a
+      # SIDE STREAM as soon as the backward pass has left the module, under the rest of the
+      # backward pass (HBM-bound optimiser passes under MFMA-bound convolutions; the two decoders
+      # hold 0.9 of the parameters and finish first).  Per-tensor clipping needs no global norm,
+      # so the update is bit-identical to the serial order below.
+      segs = self._segments()
+      opt = self._optimizer_stream(dev)
+      main = torch.cuda.current_stream(dev)
+      ev = torch.cuda.Event()
+      ev.record()
+      with torch.cuda.stream(opt):   # discriminator: its gradients are final since pass 1
+        opt.wait_event(ev)
+        d_norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
+        self.d_optimizer.apply_gradients(group, 1)
+      self.g_optimizer.begin_step()
+      def segment_done(name):
+        if name not in segs:
+          return
+        t0, t1, e0, e1 = segs[name]
+        done = torch.cuda.Event()
+        done.record()   # on the stream that ran the module's backward (main or a decoder branch)
+        with torch.cuda.stream(opt):
+          opt.wait_event(done)
+          G.spectral.backward_fixup(prefix=G.SEGMENTS[name], dots_only=FUSED_SN_CLIP)
+          self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP)
+          self.g_optimizer.apply_segment(e0, e1, ema_theta, ema_omd)
+          # ... and the module's compute-dtype operand copies for the NEXT step (its backward is
+          # over, nothing reads the old copies any more): 315 launches leave the critical path
+          for layer in self._segment_layers(G)[name]:
+            layer.prep(ctx_g.dtype, G.store.version + 1)
+      ctx_g.on_segment = segment_done
+      ctx_g.backward()
+      ctx_g.on_segment = None
+      with torch.cuda.stream(opt):   # (the discriminator's pass 2 read its old copies until now)
+        opt.wait_stream(main)
+        for layer in self._all_conv_layers(D):
+          layer.prep(ctx_d.dtype, D.store.version)
+      main.wait_stream(opt)
+      self.g_optimizer.end_step()
+      g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
+    elif sync is None:
       ctx_g.backward()
       G.spectral.backward_fixup(dots_only=FUSED_SN_CLIP)
       g_norm = self.g_optimizer.clip_gradients(GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP).clone()
@@ -283,6 +357,7 @@ class GAN(gan_manager.GANManager):
       sync.finish()
       self.g_optimizer.apply_gradients(group, 1, ema_theta, ema_omd)
       self.d_optimizer.apply_gradients(group, 1)
+    self.last_collectives = ctx_g.collectives   # SyncBN all-reduces of this step (tests)
     if self.global_step == 0:
       # builds the EMA model's variables in the reference (:258-259): a throw-away forward
       self.ema_generator.forward(self.ema_generator.make_ctx(training=True, group=group, world=R), inputs)

@@ -81,16 +81,22 @@ image_models.SNMultiScaleDiscriminator.n_layers = 3
   ref64 = _oracle_sum(gp, dp, shard, world, True)
 
   # ---- product step; capture the summed gradient arenas as Adam consumes them
-  cap = {}
-  for opt, tag in ((gan.g_optimizer, 'g_grads'), (gan.d_optimizer, 'd_grads')):
-    orig = opt.apply_gradients
-    def wrap(*a, _orig=orig, _opt=opt, _tag=tag, **kw):
-      if _tag not in cap:
-        cap[_tag] = _opt.model.store.grad.detach().cpu().clone()
-      return _orig(*a, **kw)
-    opt.apply_gradients = wrap
+  from tests.test_nets_gpu import capture_clipped_grads
+  cap = {tag: capture_clipped_grads(opt)[0]
+         for opt, tag in ((gan.g_optimizer, 'g_grads'), (gan.d_optimizer, 'd_grads'))}
   gan.train_g_d(batch)
   torch.cuda.synchronize()
+  # the two decoders (+ heads) run in lockstep and their k-th SyncBatchNormalization
+  # sums share one all-reduce, forward and backward: a step issues 2 x (all batch norms - those of
+  # one decoder branch) collectives instead of 2 x all
+  gnames = gan.generator.store.trainable_names
+  n_bn = sum(1 for k in gnames if k.endswith('/gamma'))
+  n_branch = sum(1 for k in gnames if k.endswith('/gamma') and k.startswith(('decoder/', 'rgb_conv/')))
+  if rank == 0:
+    print(f'SyncBN all-reduces per step: {gan.last_collectives} (unpaired: {2 * n_bn}; '
+          f'{n_bn} batch norms, {n_branch} per decoder branch)')
+  assert n_branch > 0.25 * n_bn
+  assert gan.last_collectives == 2 * (n_bn - n_branch), (gan.last_collectives, n_bn, n_branch)
   for key, model in (('g_grads', gan.generator), ('d_grads', gan.discriminator)):
     names, shapes, f32 = ref32[key]
     _, _, f64 = ref64[key]

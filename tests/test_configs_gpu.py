@@ -84,14 +84,11 @@ def _cpu_params(model):
 def _capture_step(gan, batch):
   """Runs train_g_d and returns the clipped gradient arenas (as Adam consumed them) and the
   parameter arenas before the update."""
+  from tests.test_nets_gpu import capture_clipped_grads
   cap = {}
   for opt, tag in ((gan.g_optimizer, 'g'), (gan.d_optimizer, 'd')):
     cap[tag + '_theta0'] = opt.model.store.theta.detach().cpu().clone()
-    orig = opt.apply_gradients
-    def wrap(*args, _orig=orig, _opt=opt, _tag=tag, **kw):
-      cap[_tag + '_grad'] = _opt.model.store.grad.detach().cpu().clone()
-      return _orig(*args, **kw)
-    opt.apply_gradients = wrap
+    cap[tag + '_grad'] = capture_clipped_grads(opt)[0]
   gan.train_g_d({k: v.to(DEV) for k, v in batch.items()})
   torch.cuda.synchronize()
   return cap

@@ -22,6 +22,23 @@ def _free_port():
   return p
 
 
+def test_merge_paired_orders_sync_closures_next_to_their_twin():
+  from se3ds_amd.hipops import nn
+  e = lambda name, tag, sync=0: (name, tag, sync)
+  # two branches recorded by two threads in arbitrary interleaving, main-stream entries around
+  tape = [e('m0', 0), e('a0', 1), e('b0', 2), e('b1', 2), e('A', 1, 1), e('a1', 1), e('B', 2, 1),
+          e('b2', 2), e('a2', 1), e('A2', 1, 1), e('B2', 2, 1), e('b3', 2), e('m1', 0)]
+  out = nn._merge_paired(tape)
+  names = [x[0] for x in out]
+  assert names == ['m0', 'a0', 'b0', 'b1', 'A', 'B', 'a1', 'a2', 'b2', 'A2', 'B2', 'b3', 'm1'], names
+  assert [x[2] for x in out if x[0] in ('A', 'B', 'A2', 'B2')] == [2, 2, 2, 2]
+  for tag in (1, 2):   # per-branch order untouched
+    assert [x[0] for x in out if x[1] == tag] == [x[0] for x in tape if x[1] == tag]
+  # unequal numbers of sync closures: left alone (plain, unpaired all-reduces)
+  odd = [e('a0', 1), e('A', 1, 1), e('b0', 2)]
+  assert nn._merge_paired(odd) == odd
+
+
 def _toy_params(seed=0):
   from se3ds_amd.models import image_models
   G = image_models.ResNetGenerator(image_size=64, gen_dims=4, z_dim=4, device='cpu', seed=seed)
@@ -70,6 +87,40 @@ def _worker(rank, world, port, mode, out):
       dist_utils.allreduce_arena_sum(a, g2, bucket_elems=128)
       dist.all_reduce(b)
       assert a.tolist() == [3.0] * 300 and b.tolist() == [3.0] * 3
+    elif mode == 'paired_syncbn':
+      # Ctx.run_branches / allreduce_then (se3ds_amd/hipops/nn.py): two structurally identical
+      # branches in lockstep share ONE all-reduce per pair of SyncBN sums, forward and backward
+      from se3ds_amd.hipops import nn
+      ctx = nn.Ctx('cpu', torch.float32, training=True, record=True, world=world)
+      seen = {}
+      def branch(tag):
+        def run():
+          vals = []
+          for k in range(3):
+            t = torch.full((2, 4), float(100 * tag + 10 * k + rank))
+            ctx.record(lambda: seen.setdefault('plain', []).append(tag))   # ops between the norms
+            ctx.allreduce_sum(t)
+            vals.append(t.clone())
+            g = torch.full((2, 4), float(1000 * tag + 10 * k + rank))
+            def bwd(g=g, k=k, tag=tag):
+              ctx.allreduce_then(g, lambda: seen.setdefault('bwd', []).append((tag, k, g.clone())))
+            ctx.record(bwd, sync=True)
+          return vals
+        return run
+      res = ctx.run_branches({1: branch(1), 2: branch(2)})
+      for tag in (1, 2):
+        for k, v in enumerate(res[tag]):
+          assert torch.equal(v, torch.full((2, 4), float(2 * (100 * tag + 10 * k) + 1))), (tag, k)
+      assert ctx.collectives == 3, ctx.collectives          # 6 sums, 3 all-reduces
+      ctx.backward()
+      assert ctx.collectives == 6, ctx.collectives          # ... and 3 more for the 6 backward sums
+      got = sorted((tag, k, float(g[0, 0])) for tag, k, g in seen['bwd'])
+      assert got == sorted((tag, k, float(2 * (1000 * tag + 10 * k) + 1)) for tag in (1, 2)
+                           for k in range(3)), got
+      # per-branch order of the backward closures is kept: k = 2, 1, 0
+      for tag in (1, 2):
+        assert [k for t_, k, _ in seen['bwd'] if t_ == tag] == [2, 1, 0]
+      out[rank] = np.array([ctx.collectives])
     elif mode == 'replica_step':
       gp, dp = _toy_params()
       full = _batch(2, 64, 5)
@@ -125,3 +176,11 @@ def test_two_replica_step_semantics_gloo():
   np.testing.assert_allclose(out[0]['mm'], out[1]['mm'], rtol=0, atol=0)
   assert out[0]['local_norms'].max() <= 5.0 + 1e-4 and out[1]['local_norms'].max() <= 5.0 + 1e-4
   assert np.isfinite(out[0]['sum']).all()
+
+
+def test_paired_syncbn_collectives_gloo():
+  """the SyncBN sums of two lockstep branches go out as one all-reduce per pair,
+  forward (two host threads meeting at a barrier) and backward (twin closures placed next to each
+  other): 12 reduced tensors, 6 collectives, every value the cross-replica sum."""
+  out = _run('paired_syncbn')
+  assert int(out[0][0]) == 6 and int(out[1][0]) == 6

@@ -339,6 +339,21 @@ def synth_batch(n, h, seed=1234):
               proj_depth=depth * pm, blurred_mask=bm)
 
 
+def capture_clipped_grads(opt):
+  """CPU copy of the gradient arena exactly as Adam consumes it (AdamState.on_update fires per
+  updated range: once for the whole arena, or per module when the trainer updates modules on its
+  side stream).  Returns (arena tensor filled during the step, name -> view function)."""
+  st = opt.model.store
+  buf = torch.zeros(st.theta.numel(), dtype=torch.float32)
+  def hook(e0, e1):
+    buf[e0:e1] = st.grad[e0:e1].detach().cpu()
+  opt.on_update = hook
+  def view(name):
+    o, n, shape = st._off_tr[name]
+    return buf[o:o + n].view(shape)
+  return buf, view
+
+
 def _oracle_params(model):
   return {k: v.detach().cpu().clone() for k, v in model.store.views.items()}
 
@@ -527,15 +542,12 @@ def test_train_g_d_gradients_and_update_fp32():
   with fp64_oracle():
     ref64 = O.train_g_d(_f64(gp), _f64(dp), _f64(batch), cfg)
   # capture the clipped gradients before Adam consumes them
-  captured = {}
-  for opt, tag in ((gan.g_optimizer, 'g'), (gan.d_optimizer, 'd')):
-    orig = opt.apply_gradients
-    def wrap(*args, _orig=orig, _opt=opt, _tag=tag, **kw):
-      captured[_tag] = {n: _opt.model.store.grad_views[n].detach().cpu().numpy().copy()
-                        for n in _opt.model.store.trainable_names}
-      return _orig(*args, **kw)
-    opt.apply_gradients = wrap
+  views = {tag: capture_clipped_grads(opt)[1]
+           for opt, tag in ((gan.g_optimizer, 'g'), (gan.d_optimizer, 'd'))}
   gan.train_g_d({k: v.to(DEV) for k, v in batch.items()})
+  torch.cuda.synchronize()
+  captured = {tag: {n: views[tag](n).numpy().copy() for n in opt.model.store.trainable_names}
+              for opt, tag in ((gan.g_optimizer, 'g'), (gan.d_optimizer, 'd'))}
   # Training-mode gradients of this toy network are noise-limited in fp32 (see fp64_oracle):
   # per-tensor strictness lives in test_generator_backward_well_conditioned_fp32 and the
   # kernel-level tests; here the whole gradient vector must be as close to the fp64 result as
@@ -597,14 +609,10 @@ def test_train_d_only_updates_discriminator():
   with fp64_oracle():
     ref64 = O.train_d(_f64(gp), _f64(dp), _f64(batch), cfg)
   theta_g = gan.generator.store.theta.clone()
-  captured = {}
-  orig = gan.d_optimizer.apply_gradients
-  def wrap(group=None, world=1):
-    st = gan.discriminator.store
-    captured.update({n: st.grad_views[n].detach().cpu().numpy().copy() for n in st.trainable_names})
-    return orig(group, world)
-  gan.d_optimizer.apply_gradients = wrap
+  _, dview = capture_clipped_grads(gan.d_optimizer)
   gan.train_d({k: v.to(DEV) for k, v in batch.items()})
+  torch.cuda.synchronize()
+  captured = {n: dview(n).numpy().copy() for n in gan.discriminator.store.trainable_names}
   assert torch.equal(theta_g, gan.generator.store.theta)
   assert gan.d_optimizer.iterations == 1 and gan.g_optimizer.iterations == 0
   # G ran in training mode: BN moving statistics / u advanced (se3ds_trainer.py:292-293)
@@ -849,14 +857,12 @@ def test_adam_and_ema_recurrences_vs_oracle(num_batched_steps, steps):
   ema = cpu(gan.ema_generator)
   slots = {t: {k: (torch.zeros_like(p[t][k]), torch.zeros_like(p[t][k]))
                for k in m.store.trainable_names} for t, m in (('g', G), ('d', D))}
-  cap = {}
-  for opt, tag in ((gan.g_optimizer, 'g'), (gan.d_optimizer, 'd')):
-    orig = opt.apply_gradients
-    def wrap(*a, _orig=orig, _opt=opt, _tag=tag, **kw):
-      cap[_tag] = {n: _opt.model.store.grad_views[n].detach().cpu().clone()
-                   for n in _opt.model.store.trainable_names}
-      return _orig(*a, **kw)
-    opt.apply_gradients = wrap
+  gviews = {tag: capture_clipped_grads(opt)[1]
+            for opt, tag in ((gan.g_optimizer, 'g'), (gan.d_optimizer, 'd'))}
+  class _Cap(dict):   # cap[tag][name]: the gradient Adam consumed in the LAST step
+    def __getitem__(self, tag):
+      return {n: gviews[tag](n).clone() for n in (G if tag == 'g' else D).store.trainable_names}
+  cap = _Cap()
   # parameters: 3e-5 of the step size (the update's own fp32 noise: fused vs separate multiply-
   # add in the slot recurrences) + 2.5 ulp; slots / averages: 1e-5 of the tensor's scale
   close_p = lambda a, b, lr: torch.allclose(a, b, rtol=3e-7, atol=3e-5 * lr)
@@ -1069,3 +1075,23 @@ def test_norm_reduce_rows_finalize_matches_the_pair():
       outs.append([t.clone() for t in o] + [mm, mv])
     for a, b in zip(*outs):
       assert torch.equal(a, b), (rows, c)
+
+
+def test_scheduling_switches_are_bit_identical():
+  """One replica: the decoders' two HIP streams (Ctx.branch) and the per-module optimiser on its
+  side stream (GAN.train_g_d) only reorder independent work, so every combination of the switches
+  must leave the SAME losses and the same parameter / EMA / state checksums as the serial order,
+  bit for bit, step after step (tools/step_compare.py; this is the test that found the gradient
+  arena being zero-filled on a branch stream).  Small widths keep it to a few seconds per run;
+  the full-size comparison is `python tools/step_compare.py 512 8 14`."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, PYTHONPATH=root,
+             SE3DS_CMP_GIN='image_models.ResNetGenerator.gen_dims = 16;'
+                           'image_models.ResNetGenerator.resnet_version = "50";'
+                           'image_models.SNMultiScaleDiscriminator.dis_dims = 16')
+  r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'step_compare.py'), '128', '2', '4'],
+                     env=env, cwd=root, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+  assert r.stdout.count('IDENTICAL to serial') == 6, r.stdout[-2000:]
