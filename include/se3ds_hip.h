@@ -213,6 +213,12 @@ int se3ds_compact_valid(const float* xyz1, const void* feats, int feat_dtype, in
  * wt [cout][K] (forward operand) and, if non-NULL, wn [K][cout] (input-gradient operand). */
 int se3ds_weight_prep(const float* w, int64_t k, int cout, int dtype, void* wt, void* wn,
                       void* stream);
+/* The same for MANY layers in one launch (bf16 only; every layer needs k % 8 == 0, cout % 4 == 0,
+ * 16-byte aligned w / wt, 8-byte aligned wn): `table` is a device int64 [nlayers][6] =
+ * {w, k, cout, wt, wn, first 64 x 64 tile}, total_tiles the sum of ceil(k/64) * ceil(cout/64).
+ * The trainer refreshes a whole module's operand copies behind its Adam update with it. */
+#define SE3DS_WEIGHT_PREP_FIELDS 6
+int se3ds_weight_prep_multi(const int64_t* table, int nlayers, int64_t total_tiles, void* stream);
 
 /* y = epilogue(conv(x * in_mask, W)).  Replaces tf.nn.conv2d at models/layers.py:193-198
  * (PartialConv), :334-339 (SpectralConv), Keras Conv2D (image_models.py:513-517,542-543),

@@ -2184,10 +2184,9 @@ int launch_splat_packed(const float* coords, const float* offset, const T* feats
   static const bool want_vec_out = getenv("SE3DS_PACK_VEC_OUT") != nullptr;
   const int vec_out = want_vec_out && (width % 4 == 0) && ((uintptr_t)depth % 16 == 0) &&
                       ((uintptr_t)feat % 16 == 0) && (mask == nullptr || (uintptr_t)mask % 16 == 0);
-  static const bool dbg = [] {
-    const char* e = getenv("SE3DS_SPLAT_DEBUG");
-    return e && atoi(e) != 0;
-  }();
+  // (read per call: the parity tests switch the tap on for single calls)
+  const char* e_dbg = getenv("SE3DS_SPLAT_DEBUG");
+  const bool dbg = e_dbg && atoi(e_dbg) != 0;
 #define SE3DS_P1(CC, DBG)                                                                         \
   hipLaunchKernelGGL((splat_pack_count_kernel<T, EQUIRECT, CC, DBG>), g_pt, dim3(kPThreads),      \
                      4 * ntiles, stream, coords, offset, feats, m, ld, cg.per, height, width,     \

@@ -478,6 +478,63 @@ hinge_kernel(const T* __restrict__ logits, int64_t half, float cd, float cg,
   if (threadIdx.x == 0) { sums[0] = sg; sums[1] = sd; }
 }
 
+// fp32 master HWIO [K][Cout] -> bf16 operand copies wt [Cout][K] and wn [K][Cout] for MANY layers
+// in one launch (64 x 64 LDS-tiled transpose per block, as weight_prep_vec_kernel in conv.hip;
+// blockIdx -> layer by binary search over the layers' first-tile column of the table).
+__global__ void __launch_bounds__(256)
+weight_prep_multi_kernel(const int64_t* __restrict__ table, int nlayers) {
+  __shared__ float tile[64][65];
+  const int64_t blk = blockIdx.x;
+  int lo = 0, hi = nlayers - 1;
+  while (lo < hi) {   // last layer whose first tile <= blk
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[(int64_t)mid * 6 + 5] <= blk) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* L = table + (int64_t)lo * 6;
+  const float* __restrict__ w = (const float*)L[0];
+  const int64_t K = L[1];
+  const int Cout = (int)L[2];
+  uint16_t* __restrict__ wt = (uint16_t*)L[3];
+  uint16_t* __restrict__ wn = (uint16_t*)L[4];
+  const int64_t local = blk - L[5];
+  const int64_t tiles_k = (K + 63) / 64;
+  const int64_t k0 = (local % tiles_k) * 64;
+  const int c0 = (int)(local / tiles_k) * 64;
+  const int tid = threadIdx.x;
+  {
+    const int cq = (tid & 15) * 4, r0 = tid >> 4;   // 16 lanes x float4 cover 64 columns
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + 16 * i;
+      const int64_t k = k0 + r;
+      const int c = c0 + cq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && c < Cout) {
+        v = *reinterpret_cast<const float4*>(w + k * Cout + c);
+        uint16_t o[4] = {f32_to_bf16(v.x), f32_to_bf16(v.y), f32_to_bf16(v.z), f32_to_bf16(v.w)};
+        *reinterpret_cast<uint2*>(wn + k * Cout + c) = *reinterpret_cast<const uint2*>(o);
+      }
+      tile[r][cq] = v.x; tile[r][cq + 1] = v.y; tile[r][cq + 2] = v.z; tile[r][cq + 3] = v.w;
+    }
+  }
+  __syncthreads();
+  {
+    const int kq = (tid & 7) * 8, cr0 = tid >> 3;   // 8 lanes x 8 bf16 cover 64 k of one channel
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cr = cr0 + 32 * j;
+      const int c = c0 + cr;
+      const int64_t k = k0 + kq;
+      if (c < Cout && k < K) {
+        uint16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = f32_to_bf16(tile[kq + e][cr]);
+        *reinterpret_cast<uint4*>(wt + (int64_t)c * K + k) = *reinterpret_cast<const uint4*>(o);
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace se3ds
 
@@ -710,6 +767,14 @@ int se3ds_quantize(const void* in, int in_dtype, int64_t n, int pre_clamp, float
   } else return SE3DS_E_BADDTYPE;
 #undef Q
   return check_launch("quantize");
+}
+
+int se3ds_weight_prep_multi(const int64_t* table, int nlayers, int64_t total_tiles, void* stream) {
+  if (nlayers <= 0 || total_tiles <= 0) return SE3DS_OK;
+  if (total_tiles >= ((int64_t)1 << 31)) return SE3DS_E_BADSHAPE;
+  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0,
+                     as_stream(stream), table, nlayers);
+  return check_launch("weight_prep_multi");
 }
 
 int se3ds_pad2d(const void* x, int dtype, int n, int h, int w, int c, int pad, int mode, int wrap_w,

@@ -226,6 +226,10 @@ class Ctx:
     # they ran in; backward() replays each branch's closures on its stream (see branch()).
     self.streams = None
     self.stream_phases = ('fwd', 'bwd')   # debugging: restrict the branch streams to one pass
+    # Weight gradients leave the backward pass's dependency chain (dgrad -> norm backward ->
+    # dgrad ...): with a stream here, every conv layer's wgrad goes to it behind an event on dy,
+    # and MFMA-bound wgrads run under the HBM-bound normalisation kernels of the chain.
+    self.wgrad_stream = None
     self._tl = threading.local()   # branch_tag is per host thread (paired branches run in two)
     self._forked = set()
     # Several replicas: two structurally identical branches run in lockstep so that their k-th
@@ -317,6 +321,21 @@ class Ctx:
         main.wait_stream(self.streams[tag])
       self._forked.clear()
 
+  def on_wgrad_stream(self, *reads):
+    """with ctx.on_wgrad_stream(dy, ...): a weight-gradient launch.  Returns a context manager
+    that switches to the wgrad stream behind an event on the current stream; `reads` are tensors
+    of the current stream's allocator that the launch reads (they may be freed by the caller
+    right away: record_stream keeps their memory until the wgrad stream has passed)."""
+    return _WgradScope(self, reads)
+
+  def wgrad_event(self):
+    """Event behind everything issued to the wgrad stream so far (None without one)."""
+    if self.wgrad_stream is None:
+      return None
+    ev = torch.cuda.Event()
+    ev.record(self.wgrad_stream)
+    return ev
+
   def backward(self):
     tape, self.tape = self.tape, []
     if self.world > 1 and _PAIR_SYNCBN:
@@ -328,6 +347,8 @@ class Ctx:
       self._replay(tape)
     finally:
       self.streams = keep
+    if self.wgrad_stream is not None:   # every gradient is final when backward() returns
+      torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
 
   def _replay(self, tape):
     cur, scope = 0, None
@@ -400,6 +421,28 @@ class Ctx:
         return
       self.allreduce_sum(t)
     cont()
+
+
+class _WgradScope:
+  def __init__(self, ctx, reads):
+    self.ctx, self.reads, self.scope = ctx, reads, None
+
+  def __enter__(self):
+    ws = self.ctx.wgrad_stream
+    if ws is not None:
+      ev = torch.cuda.Event()
+      ev.record()
+      ws.wait_event(ev)
+      for t in self.reads:
+        if t is not None:
+          t.record_stream(ws)
+      self.scope = torch.cuda.stream(ws)
+      self.scope.__enter__()
+    return self
+
+  def __exit__(self, *a):
+    if self.scope is not None:
+      self.scope.__exit__(*a)
 
 
 class _Branch:
@@ -728,6 +771,45 @@ class ConvLayer:
     return wt, wn
 
 
+class OperandGroup:
+  """The conv layers of one module: their bf16 operand copies refreshed in ONE launch
+  (`se3ds_weight_prep_multi`) instead of one launch per layer; layers the batched kernel does not
+  take (fp32 compute, thin heads with cout % 4 != 0) keep their own launch."""
+
+  def __init__(self, layers: List['ConvLayer'], dtype, device):
+    self.dtype = dtype
+    self.batched, self.single, rows, tile0 = [], [], [], 0
+    for l in layers:
+      w = l.kernel
+      K, co = w.shape[0] * w.shape[1] * w.shape[2], w.shape[3]
+      if dtype == torch.bfloat16 and K % 8 == 0 and co % 4 == 0:
+        ent = l._copies.get(dtype)
+        if ent is None:
+          wt = torch.empty((co, K), dtype=dtype, device=w.device)
+          wn = torch.empty((K, co), dtype=dtype, device=w.device)
+          l._copies[dtype] = (-1, wt, wn)
+        else:
+          wt, wn = ent[1], ent[2]
+        if (w.data_ptr() | wt.data_ptr()) % 16 == 0 and wn.data_ptr() % 8 == 0:
+          rows.append([w.data_ptr(), K, co, wt.data_ptr(), wn.data_ptr(), tile0])
+          tile0 += ((K + 63) // 64) * ((co + 63) // 64)
+          self.batched.append(l)
+          continue
+      self.single.append(l)
+    self.tiles = tile0
+    self.table = torch.tensor(rows, dtype=torch.int64, device=device) if rows else None
+
+  def prep(self, version):
+    if self.table is not None:
+      _chk(_L().se3ds_weight_prep_multi(self.table.data_ptr(), len(self.batched), self.tiles,
+                                        _lib.stream()), 'se3ds_weight_prep_multi')
+      for l in self.batched:
+        ent = l._copies[self.dtype]
+        l._copies[self.dtype] = (version, ent[1], ent[2])
+    for l in self.single:
+      l.prep(self.dtype, version)
+
+
 class SpectralGroup:
   """All spectrally-normalised layers of one model: batched power iteration (layers.py:312-331)
   and the batched gradient fix-up through sigma."""
@@ -948,25 +1030,26 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
         gk = st.grad_views[layer.name + '/kernel']
         thin_out = (layer.cout <= 16 and cin > 16 and s == 1 and ho == h and wo == w and
                     pt == pl and not wrap and not partial)
-        if thin_out:
-          # 128->3 / 128->1 output convs: role-swapped weight gradient (x streamed once)
-          wsz = L.se3ds_conv2d_wgrad_swapped_workspace_bytes(n, h, w, cin, layer.cout, k)
-          ws = _global_ws(ctx.device, 'wgrad', wsz)
-          with _Timed('wgrad', flops, tag):
-            _chk(L.se3ds_conv2d_wgrad_swapped(xd.data_ptr(), dys.data_ptr(), gk.data_ptr(),
-                                              ctx.code, n, h, w, cin, layer.cout, k, pt, 0,
-                                              ws.data_ptr(), ws.numel(), _lib.stream()),
-                 'se3ds_conv2d_wgrad_swapped')
-        else:
-          wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, layer.cout, k, k)
-          ws = _global_ws(ctx.device, 'wgrad', wsz)
-          with _Timed('wgrad', flops, tag):
-            _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dys.data_ptr(), gk.data_ptr(), ctx.code, n, h,
-                                      w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
-                                      1 if wrap else 0, _lib.ptr(in_mask),
-                                      1 if ctx.binary_masks else 0, _lib.ptr(row_scale),
-                                      None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
-                 'se3ds_conv2d_wgrad')
+        with ctx.on_wgrad_stream(dys, row_scale):   # (scratch below is per stream)
+          if thin_out:
+            # 128->3 / 128->1 output convs: role-swapped weight gradient (x streamed once)
+            wsz = L.se3ds_conv2d_wgrad_swapped_workspace_bytes(n, h, w, cin, layer.cout, k)
+            ws = _global_ws(ctx.device, 'wgrad', wsz)
+            with _Timed('wgrad', flops, tag):
+              _chk(L.se3ds_conv2d_wgrad_swapped(xd.data_ptr(), dys.data_ptr(), gk.data_ptr(),
+                                                ctx.code, n, h, w, cin, layer.cout, k, pt, 0,
+                                                ws.data_ptr(), ws.numel(), _lib.stream()),
+                   'se3ds_conv2d_wgrad_swapped')
+          else:
+            wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, layer.cout, k, k)
+            ws = _global_ws(ctx.device, 'wgrad', wsz)
+            with _Timed('wgrad', flops, tag):
+              _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dys.data_ptr(), gk.data_ptr(), ctx.code, n, h,
+                                        w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
+                                        1 if wrap else 0, _lib.ptr(in_mask),
+                                        1 if ctx.binary_masks else 0, _lib.ptr(row_scale),
+                                        None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
+                   'se3ds_conv2d_wgrad')
       if x.requires_grad:
         prev = x.grad
         shape = (n,) + tuple(xd.shape[1:])

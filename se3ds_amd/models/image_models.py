@@ -205,15 +205,22 @@ class ResNetDecoder:
     self.final_deconv = layers.Conv2DTranspose(store, name + '/final_deconv', d, output_dim, 2, 2,
                                                use_bias=True)
 
+  # deconv1 blocks per gradient segment.  One block per segment made the per-segment optimiser
+  # kernels tiny: 49 spectral-dot launches of 365 us each (two 9.4 M-parameter layers = 128
+  # workgroups, profiles/r03_*), 18 ms of GPU time per step where one batched launch took 1.3 ms.
+  # Four blocks (8 layers, 150 MB of gradient) fill the chip and still stream.
+  SEGMENT_BLOCKS = 4
+
   def segments(self):
     """{segment: parameter-name prefixes}, each contiguous in the arena.  deconv1 holds 0.96 of a
     decoder's parameters and its blocks finish one after the other during the last 3/4 of the
-    decoder's backward pass: one segment per block lets their gradients (and, on one replica,
-    their Adam updates) stream out under the rest of it."""
+    decoder's backward pass: a segment per SEGMENT_BLOCKS blocks lets their gradients (and, on one
+    replica, their Adam updates) stream out under the rest of it."""
     n = self.name
     segs = {n + '_head': (n + '/upc', n + '/agent4', n + '/agent4_bn', n + '/deconv1/upsample')}
-    for i in range(len(self.deconv1.block)):
-      segs[f'{n}/deconv1/block{i}'] = (f'{n}/deconv1/block{i}',)
+    nb, g = len(self.deconv1.block), self.SEGMENT_BLOCKS
+    for i in range(0, nb, g):
+      segs[f'{n}/deconv1/blocks{i}'] = tuple(f'{n}/deconv1/block{j}' for j in range(i, min(i + g, nb)))
     tail = [n + '/deconv2', n + '/deconv3', n + '/deconv4']
     for k in range(4):
       tail += [f'{n}/agent{k}', f'{n}/agent{k}_bn']
@@ -237,7 +244,7 @@ class ResNetDecoder:
     out = self.upc_bn(ctx, out, act=ACT_LRELU, alpha=0.2)
     out = nn.upsample2x(ctx, out)
     out = self._agent(ctx, self.agent4, self.agent4_bn, out, None)
-    out = self.deconv1(ctx, out, mark=self.name + '/deconv1')
+    out = self.deconv1(ctx, out, mark=self.name + '/deconv1', group=self.SEGMENT_BLOCKS)
     ctx.mark_segment(self.name + '_tail')
     out = nn.add(ctx, out, self._agent(ctx, self.agent3, self.agent3_bn, skip[3], masks[3]))
     out = self.deconv2(ctx, out)

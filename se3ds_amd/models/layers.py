@@ -232,12 +232,13 @@ class ResStackTranspose:
                                       upsample=upsample, circular_pad=circular_pad,
                                       conv_fn=conv_fn))
 
-  def __call__(self, ctx: Ctx, x: Var, mark: Optional[str] = None) -> Var:
-    """mark: segment-name prefix; a gradient-synchronisation marker `mark/block{i}` is placed in
-    front of every block (ResNetGenerator.SEGMENTS), so that a block's parameter gradients can be
-    clipped / reduced / applied as soon as the backward pass has left the block."""
+  def __call__(self, ctx: Ctx, x: Var, mark: Optional[str] = None, group: int = 1) -> Var:
+    """mark: segment-name prefix; a gradient-synchronisation marker `mark/blocks{i}` is placed in
+    front of every `group`-th block (ResNetGenerator.SEGMENTS), so that the parameter gradients of
+    blocks [i, i + group) can be clipped / reduced / applied as soon as the backward pass has left
+    them."""
     for i, b in enumerate(self.block):
-      if mark is not None:
-        ctx.mark_segment(f'{mark}/block{i}')
+      if mark is not None and i % group == 0:
+        ctx.mark_segment(f'{mark}/blocks{i}')
       x = b(ctx, x)
     return x

@@ -31,6 +31,10 @@ FUSED_SN_CLIP = os.environ.get('SE3DS_FUSED_SN_CLIP', '1') != '0'
 GRAD_CLIP_NORM = 5.0   # _clip_grad default, reference :27
 # one replica: per-module clip + Adam on a side stream under the backward pass (0: after it)
 SEGMENT_OPTIMIZER = os.environ.get('SE3DS_SEGMENT_OPTIMIZER', '1') != '0'
+# one replica: weight gradients on their own stream (Ctx.on_wgrad_stream).  Bit-identical, but
+# measured SLOWER (221.0 vs 213.5 ms per step, same box): two MFMA-bound kernels co-running cost
+# more than the dependency chain gains.  Off; kept for A/B runs.
+WGRAD_STREAM = os.environ.get('SE3DS_WGRAD_STREAM', '0') != '0'
 
 
 def _L():
@@ -133,6 +137,20 @@ class GAN(gan_manager.GANManager):
       assert sum(len(v) for v in self._seg_layers.values()) == len(layers), 'segments miss conv layers'
     return self._seg_layers
 
+  def _operand_group(self, model, segment, dtype):
+    """nn.OperandGroup of one generator segment (or of a whole model: segment None)."""
+    cache = self.__dict__.setdefault('_operand_groups', {})
+    key = (id(model), segment, dtype)
+    if key not in cache:
+      layers = self._all_conv_layers(model) if segment is None else self._segment_layers(model)[segment]
+      cache[key] = nn.OperandGroup(layers, dtype, model.store.theta.device)
+    return cache[key]
+
+  def _wgrad_stream(self, dev):
+    if getattr(self, '_wg_stream', None) is None:
+      self._wg_stream = torch.cuda.Stream(dev)
+    return self._wg_stream
+
   def _optimizer_stream(self, dev):
     if getattr(self, '_opt_stream', None) is None:
       self._opt_stream = torch.cuda.Stream(dev)
@@ -197,6 +215,10 @@ class GAN(gan_manager.GANManager):
 
     # ---- generator forward (both "tapes" of the reference share this forward)
     ctx_g = G.make_ctx(training=True, record=True, group=group, world=R)
+    if sync is not None:
+      # the per-module clip of the gradient-synchronisation path runs inside the backward
+      # closures and shares its scratch across modules: one stream (as with several replicas)
+      ctx_g.streams = None
     outs, (push_rgb, push_depth) = G.forward(ctx_g, inputs)
     depth_out, generated = outs[3], outs[6]
 
@@ -285,6 +307,9 @@ class GAN(gan_manager.GANManager):
                              d_depth.data_ptr(), _lib.stream()), 'se3ds_add')
     # ---- generator backward
     ctx_g.param_grads = True
+    if ctx_g.streams is not None and WGRAD_STREAM:
+      # one replica: the conv layers' weight gradients leave the dgrad -> norm -> dgrad chain
+      ctx_g.wgrad_stream = self._wgrad_stream(dev)
     push_rgb(d_rgb)
     push_depth(d_depth)
     # ---- clip per tensor (per replica), aggregate, apply (:238-257)
@@ -312,22 +337,23 @@ class GAN(gan_manager.GANManager):
         t0, t1, e0, e1 = segs[name]
         done = torch.cuda.Event()
         done.record()   # on the stream that ran the module's backward (main or a decoder branch)
+        wdone = ctx_g.wgrad_event()   # ... and behind its weight gradients
         with torch.cuda.stream(opt):
           opt.wait_event(done)
+          if wdone is not None:
+            opt.wait_event(wdone)
           G.spectral.backward_fixup(prefix=G.SEGMENTS[name], dots_only=FUSED_SN_CLIP)
           self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP)
           self.g_optimizer.apply_segment(e0, e1, ema_theta, ema_omd)
           # ... and the module's compute-dtype operand copies for the NEXT step (its backward is
           # over, nothing reads the old copies any more): 315 launches leave the critical path
-          for layer in self._segment_layers(G)[name]:
-            layer.prep(ctx_g.dtype, G.store.version + 1)
+          self._operand_group(G, name, ctx_g.dtype).prep(G.store.version + 1)
       ctx_g.on_segment = segment_done
       ctx_g.backward()
       ctx_g.on_segment = None
       with torch.cuda.stream(opt):   # (the discriminator's pass 2 read its old copies until now)
         opt.wait_stream(main)
-        for layer in self._all_conv_layers(D):
-          layer.prep(ctx_d.dtype, D.store.version)
+        self._operand_group(D, None, ctx_d.dtype).prep(D.store.version)
       main.wait_stream(opt)
       self.g_optimizer.end_step()
       g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()

@@ -301,13 +301,10 @@ def test_bilinear_and_resampling_paths():
 _OLD = dict(SE3DS_SPLAT_PACKED='0')   # the 20-byte-record paths behind the 8-byte packed default
 @pytest.mark.parametrize('env_extra', [
     dict(SE3DS_SPLAT_SLICE='48'),                          # packed records, every tile banded
-    dict(_OLD),                                            # three-pass, 20-byte records
-    dict(_OLD, SE3DS_SPLAT_SLICE='48'),                    # ... every tile banded
-    dict(_OLD, SE3DS_SPLAT_FUSED='8'),                     # single-pass binning kernel, 8 points / thread
-    dict(_OLD, SE3DS_SPLAT_FUSED='16', SE3DS_SPLAT_CAP='64'),    # ... 16 points, bins overflow into the list
+    dict(_OLD, SE3DS_SPLAT_SLICE='48'),                    # three-pass, 20-byte records, every tile banded
+    dict(_OLD, SE3DS_SPLAT_FUSED='16'),                    # single-pass binning kernel, 16 points / thread
     dict(_OLD, SE3DS_SPLAT_FUSED='8', SE3DS_SPLAT_CAP='64', SE3DS_SPLAT_SLICE='48'),   # overflow + bands
-], ids=['packed-banded', 'three-pass', 'three-pass-banded', 'single-pass', 'single-pass-overflow',
-        'single-pass-overflow-banded'])
+], ids=['packed-banded', 'three-pass-banded', 'single-pass', 'single-pass-overflow-banded'])
 def test_splat_banded_tiles_bit_exact(env_extra):
   """The splat parity tests re-run in a child process under switches that are read once per
   process: tiny slices (every tile of the small parity images is cut into bands of rows, in the

@@ -34,10 +34,12 @@ if len(sys.argv) > 1 and sys.argv[1] == '--worker':
   sys.exit(0)
 
 size, batch, steps = (sys.argv[1:] + ['128', '2', '4'])[:3]
-configs = [('0', '0', ''), ('0', '1', ''), ('1', '0', ''), ('1', '1', ''), ('1', '0', 'fwd'), ('1', '0', 'bwd')]
+configs = [('0', '0', ''), ('0', '1', ''), ('1', '0', ''), ('1', '1', ''), ('1', '0', 'fwd'), ('1', '0', 'bwd'),
+           ('1', '1', 'nowg'), ('1', '0', 'nowg')]   # 'nowg' rows: WITH the opt-in wgrad stream
 out = {}
 for ds, so, ph in configs:
-  env = dict(os.environ, SE3DS_DUAL_STREAM=ds, SE3DS_SEGMENT_OPTIMIZER=so, SE3DS_DUAL_PHASES=ph)
+  env = dict(os.environ, SE3DS_DUAL_STREAM=ds, SE3DS_SEGMENT_OPTIMIZER=so,
+             SE3DS_DUAL_PHASES='' if ph == 'nowg' else ph, SE3DS_WGRAD_STREAM='1' if ph == 'nowg' else '0')
   r = subprocess.run([sys.executable, os.path.abspath(__file__), '--worker', size, batch, steps],
                      env=env, capture_output=True, text=True)
   lines = [l for l in r.stdout.splitlines() if l.startswith('STEP')]
