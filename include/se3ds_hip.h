@@ -187,6 +187,16 @@ int se3ds_perspective_guidance(const float* pred_rgb, const float* pred_depth, i
                                float* proj_image, float* proj_depth, float* proj_mask,
                                void* stream);
 
+/* tf.image.resize with half-pixel centres on an NHWC tensor (F32 / I32 / U8): method 0 = nearest
+ * (output of the input dtype), 1 = bilinear (fp32 output, antialias off).  Callers:
+ * utils/pano_utils.py:203-208 (equirectangular_to_pointcloud with size_mult != 1) and :299-301
+ * (crop_pano(resize_to_original=True): an up-scaling, where TF's antialias=True changes nothing). */
+int se3ds_resize(const void* x, int dtype, int n, int h, int w, int c, int oh, int ow, int method,
+                 void* y, void* stream);
+/* *out = mean(x[0..n)) accumulated in binary64: the padding value of
+ * project_perspective_image(pad_mode='mean'), utils/pano_utils.py:403-407. */
+int se3ds_mean_f32(const float* x, int64_t n, float* out, void* stream);
+
 /* mask_pano -- utils/pano_utils.py:245-265: rows [mh, H-mh] kept, others := value. */
 int se3ds_mask_pano(const void* pano, int dtype, int n, int height, int width, int channels,
                     int masked_height, float value, void* out, void* stream);

@@ -297,18 +297,22 @@ def mask_pano(pano, proportion=0.125, masked_region_value=0):
   return m * pano + (1 - m) * np.asarray(masked_region_value).astype(pano.dtype)
 
 
-def crop_pano(pano, proportion=0.125):
-  """pano_utils.py:268-303 without the optional resize (rows mh .. H-mh-1)."""
+def crop_pano(pano, proportion=0.125, method='bilinear', resize_to_original=False):
+  """pano_utils.py:268-303 (rows mh .. H-mh-1).  resize_to_original: tf.image.resize(...,
+  antialias=True) back to (H, W) and tf.cast to the input dtype; the crop only removes rows, so
+  the resize scales UP, where TF's antialiasing (a kernel widened by max(1 / scale, 1)) changes
+  nothing -- PARITY UNPINNED (no reference test touches this branch)."""
   pano = np.asarray(pano)
-  if pano.ndim == 3:
-    h = pano.shape[0]
-    mh = int(h * proportion)
-    return pano[mh:h - mh]
-  if pano.ndim == 4:
-    h = pano.shape[1]
-    mh = int(h * proportion)
-    return pano[:, mh:h - mh]
-  raise ValueError(f'pano should be of shape (N, H, W, C), got {pano.shape} instead.')
+  if pano.ndim not in (3, 4):
+    raise ValueError(f'pano should be of shape (N, H, W, C), got {pano.shape} instead.')
+  x = pano[None] if pano.ndim == 3 else pano
+  h, w = x.shape[1], x.shape[2]
+  mh = int(h * proportion)
+  x = x[:, mh:h - mh]
+  if resize_to_original:
+    x = _resize_nearest(x, h, w) if method == 'nearest' else _resize_bilinear(x, h, w)
+    x = np.trunc(x).astype(pano.dtype) if np.issubdtype(pano.dtype, np.integer) else x.astype(pano.dtype)
+  return x[0] if pano.ndim == 3 else x
 
 
 def interpolate_bilinear(grid, query_points, indexing='ij'):

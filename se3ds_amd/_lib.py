@@ -46,6 +46,8 @@ _SIGS = {
     'se3ds_perspective_guidance': (c_int, [c_p, c_p, c_int, c_int, c_p, c_p, c_int, c_int, c_p, c_p, c_p,
                                            c_p]),
     'se3ds_mask_pano': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_f, c_p, c_p]),
+    'se3ds_resize': (c_int, [c_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_p, c_p]),
+    'se3ds_mean_f32': (c_int, [c_p, c_i64, c_p, c_p]),
     'se3ds_compact_workspace_bytes': (c_sz, [c_i64]),
     'se3ds_compact_valid': (c_int, [c_p, c_p, c_int, c_int, c_i64, c_int, c_f, c_p, c_p, c_p, c_p,
                                     c_sz, c_p]),

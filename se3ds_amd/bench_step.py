@@ -166,18 +166,21 @@ def batch_max(gan, h, dev, rank, candidates=(24, 16), steps=3):
   return {'per_gpu_batch': None, 'value': None, 'error': last}
 
 
-def cpu_baseline(args, gan, tflop_per_sample, budget_s=55.0):
+def cpu_baseline(args, gan, tflop_per_sample, budget_s=60.0):
   """The reference's CPU path beside the GPU number: TensorFlow cannot run here, so
   this is the PyTorch-CPU restatement of the SAME step -- oracle/nets_torch.train_g_d: generator
   and discriminator forward, both backward passes, losses, per-tensor clip -- on the bench's own
-  weights (copied off the device), all host cores, fp32.  `value` is what was MEASURED: the
-  median of up to three warmed runs at cfg1's shape (128x256, batch 2); one untimed warm-up run
-  first (oneDNN primitive creation and the allocator's first touch cost as much as a step).  The
-  figure for the benchmarked 512x1024 shape is an extrapolation and is labelled as one
-  (`extrapolated_512x1024`: the measured rate / 16, the pixel ratio -- all work of the step is
-  per pixel); when the time budget allows, one 256x512 run checks that ratio
-  (`measured_256x512`, expected value / 4).  A port, not TF; baseline only."""
-  import statistics
+  weights (copied off the device), all host cores, fp32.
+
+  `value` is what was MEASURED: one step at cfg1's shape (128x256, batch 2).  No warm-up run: a
+  warm-up changes nothing here (30.6 s against 30.7 s, BENCH notes in DESIGN.md section 5) and
+  a step costs half the budget.  The second measurement is the same step at batch 1: a CPU step
+  is dominated by work that does NOT scale with pixels -- W / sigma and its gradient over 1.1 B
+  parameters, several weight-sized fp32 passes per layer -- so t(batch) = a + batch * p separates
+  the weight-bound part `a` from the per-panorama part `p`, and the figure for the benchmarked
+  shape is the MODEL a + B * 16 * p (pixel ratio 16 on the per-panorama part only), labelled
+  `extrapolated_512x1024`.  The plain pixel-ratio figure (value / 16) is kept beside it; it is a
+  lower bound of the CPU rate.  A port, not TF; baseline only."""
   import torch as T
   from oracle import nets_torch as O
   try:
@@ -199,35 +202,40 @@ def cpu_baseline(args, gan, tflop_per_sample, budget_s=55.0):
              d_train=lambda k: not k.endswith('/u'))
   h_lo, n_lo = 128, 2
   g = T.Generator().manual_seed(1234)
-  batch = synth_batch_cpu(n_lo, h_lo, g)
-  def timed(b):
+  def timed(n):
+    b = synth_batch_cpu(n, h_lo, g)
     t0 = time.perf_counter()
     O.train_g_d(gp, dp, b, cfg)
     return time.perf_counter() - t0
-  warm = timed(batch)                      # untimed in the result
-  runs = []
-  while len(runs) < 3 and (not runs or
-                           time.perf_counter() - t_start + min(runs) < 0.6 * budget_s):
-    runs.append(timed(batch))
-  dt = statistics.median(runs)
-  rate = n_lo / dt
+  t2 = timed(n_lo)
+  rate = n_lo / t2
+  scale = (args.image_size / h_lo) ** 2
+  nb = args.batch if args.batch > 0 else 8
   out = {'value': rate, 'unit': 'panoramas/sec', 'cores': threads, 'kind': 'port',
-         'resolution': f'{h_lo}x{2 * h_lo}', 'batch': n_lo,
-         'warmup_run_s': warm, 'timed_runs_s': runs,
-         'extrapolated_512x1024': rate / (args.image_size / h_lo) ** 2,
-         'measured_256x512': None}
-  left = budget_s - (time.perf_counter() - t_start)
-  if left > 2.0 * 4.0 * dt / n_lo:    # one 256x512 panorama ~ 4x one 128x256 panorama (+ warm-up margin)
-    d_mid = timed(synth_batch_cpu(1, 256, g))
-    out['measured_256x512'] = 1.0 / d_mid
+         'resolution': f'{h_lo}x{2 * h_lo}', 'batch': n_lo, 'timed_runs_s': [t2],
+         'pixel_ratio_512x1024': rate / scale, 'extrapolated_512x1024': rate / scale,
+         'model': None}
+  note = 'no time left for the batch-1 run: extrapolated by the pixel ratio only.'
+  if budget_s - (time.perf_counter() - t_start) > 0.85 * t2:
+    t1 = timed(1)
+    out['timed_runs_s'].append(t1)
+    p_lo, a = t2 - t1, 2.0 * t1 - t2
+    if p_lo > 0.02 * t2 and a >= 0.0:
+      t_hi = a + nb * scale * p_lo
+      out['extrapolated_512x1024'] = nb / t_hi
+      out['model'] = {'weight_bound_s': a, 'per_panorama_128x256_s': p_lo,
+                      'step_s_512x1024_batch': t_hi, 'batch': nb}
+      note = (f'batch 1 took {t1:.1f} s: t(batch) = {a:.1f} s (weight-sized passes, batch- and '
+              f'resolution-independent) + batch x {p_lo:.1f} s; model for {args.image_size}x'
+              f'{2 * args.image_size} batch {nb}: {a:.1f} + {nb} x {scale:.0f} x {p_lo:.1f} = {t_hi:.0f} s '
+              f'per step = {nb / t_hi:.5f} panoramas/s (extrapolated_512x1024).')
+    else:
+      note = f'batch 1 took {t1:.1f} s: no usable split, extrapolated by the pixel ratio only.'
   out['sample'] = (f'oracle.nets_torch.train_g_d (PyTorch-CPU fp32 restatement of the full G+D step: '
                    f'forward, both backward passes, losses, clip; the bench weights) at cfg1 shape '
-                   f'{h_lo}x{2 * h_lo} batch {n_lo}: 1 warm-up run ({warm:.1f} s) + {len(runs)} timed, '
-                   f'median {dt:.1f} s = {rate:.4f} panoramas/s AT THAT SIZE (value).  512x1024 is '
-                   f'extrapolated by the pixel ratio: {out["extrapolated_512x1024"]:.5f} panoramas/s'
-                   + (f'; one 256x512 run measured {out["measured_256x512"]:.4f} panoramas/s '
-                      f'(pixel-ratio prediction {rate / 4:.4f}).' if out['measured_256x512'] else
-                      '; no time left for the 256x512 check.') + '  Not TF.')
+                   f'{h_lo}x{2 * h_lo} batch {n_lo}: {t2:.1f} s = {rate:.4f} panoramas/s AT THAT SIZE '
+                   f'(value, measured; pixel ratio alone would give {rate / scale:.5f} at '
+                   f'{args.image_size}x{2 * args.image_size}).  ' + note + '  Not TF.')
   return out
 
 

@@ -2317,8 +2317,8 @@ pad_channels8_kernel(const uint16_t* __restrict__ src, int cout, int64_t px,
 
 // sum the split partials: out[i] (+)= sum_s part[s][i]
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t n, int accumulate,
-                    const float* __restrict__ out_scale, float* __restrict__ out) {
+wgrad_reduce_scalar_kernel(const float* __restrict__ part, int splits, int64_t n, int accumulate,
+                           const float* __restrict__ out_scale, float* __restrict__ out) {
   const float sc = out_scale ? *out_scale : 1.0f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     // four independent partial sums keep the loads of a long split list in flight
@@ -2334,6 +2334,36 @@ wgrad_reduce_kernel(const float* __restrict__ part, int splits, int64_t n, int a
     float s = (s0 + s1) + (s2 + s3);
     s *= sc;
     out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+// The same with 16-byte accesses (n % 4 == 0, 16-byte aligned slabs and output): the reduce is
+// pure HBM traffic (108 MB for a 3x3 1024 -> 1024 layer with two slabs) and ran at a third of
+// the bandwidth with dword loads (295 launches, 8.3 ms per step in profiles/r03_*).  Per element
+// the summation order is the scalar kernel's, so the results are bit-identical.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_vec_kernel(const float* __restrict__ part, int splits, int64_t n4, int accumulate,
+                        const float* __restrict__ out_scale, float* __restrict__ out) {
+  const float sc = out_scale ? *out_scale : 1.0f;
+  const float4* __restrict__ P = reinterpret_cast<const float4*>(part);
+  float4* __restrict__ O = reinterpret_cast<float4*>(out);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    int k = 0;
+    auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+    for (; k + 3 < splits; k += 4) {
+      const float4 a = P[(int64_t)k * n4 + i], b = P[(int64_t)(k + 1) * n4 + i];
+      const float4 c = P[(int64_t)(k + 2) * n4 + i], d = P[(int64_t)(k + 3) * n4 + i];
+      add(s0, a); add(s1, b); add(s2, c); add(s3, d);
+    }
+    for (; k < splits; ++k) add(s0, P[(int64_t)k * n4 + i]);
+    float4 r = make_float4(((s0.x + s1.x) + (s2.x + s3.x)) * sc, ((s0.y + s1.y) + (s2.y + s3.y)) * sc,
+                           ((s0.z + s1.z) + (s2.z + s3.z)) * sc, ((s0.w + s1.w) + (s2.w + s3.w)) * sc);
+    if (accumulate) {
+      const float4 o = O[i];
+      r.x = o.x + r.x; r.y = o.y + r.y; r.z = o.z + r.z; r.w = o.w + r.w;
+    }
+    O[i] = r;
   }
 }
 
@@ -3252,6 +3282,17 @@ weight_prep_vec_kernel(const float* __restrict__ w, int64_t K, int Cout, uint16_
   }
 }
 
+static void launch_wgrad_reduce(const float* part, int splits, int64_t n, int accumulate,
+                                const float* out_scale, float* out, hipStream_t s) {
+  static const bool scalar_only = getenv("SE3DS_WGRAD_REDUCE_SCALAR") != nullptr;   // (A/B switch)
+  if (!scalar_only && (n % 4) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, part,
+                       splits, n / 4, accumulate, out_scale, out);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, part,
+                       splits, n, accumulate, out_scale, out);
+}
+
 int fill_classes(IgemmParams& p, int mode, int bm = BM) {
   int total = 0;
   if (mode == MODE_FWD) {
@@ -3576,6 +3617,20 @@ static int wgrad_splits(int64_t L, int64_t tiles, int64_t nel) {
   return best;
 }
 
+// CUs a weight-gradient launch may count on (SE3DS_WGRAD_SLOTS; default: all 256).  With the two
+// decoders on two streams a 128-item launch of one branch shares the chip with the other
+// branch's; 128 makes the cost model prefer unsplit launches (no partial slabs, no reduce).
+// Measured: 221.1 / 221.4 ms per step with 128 against 222.7 / 221.5 with 256 on one box -- the
+// launches of the two branches do not pair up reliably; the default stays 256.
+static int wgrad_slots() {
+  static const int v = [] {
+    const char* e = getenv("SE3DS_WGRAD_SLOTS");
+    const int x = e ? atoi(e) : 0;
+    return x >= 16 && x <= 256 ? x : 256;
+  }();
+  return v;
+}
+
 // tap-fused 3x3 kernel: steps of 64 pixels, work items = (Cin/64) x (Cout/128) x splits on 256
 // single-workgroup CUs.  Returns the split count (0: shape not eligible).
 static int wgrad_taps_splits(int n, int ho, int wo, int cin, int cout, int kh, int kw, int* steps) {
@@ -3594,7 +3649,7 @@ static int wgrad_taps_splits(int n, int ho, int wo, int cin, int cout, int kh, i
   for (int s = 1; s <= 512 && s <= total; ++s) {
     const double per = (double)ceil_div(total, (int64_t)s);
     if (s > 1 && per < 8) break;
-    const double rounds = (double)ceil_div(tiles * s, (int64_t)256);
+    const double rounds = (double)ceil_div(tiles * s, (int64_t)wgrad_slots());
     const double cost = rounds * (per * kStepUs + 4.0) +
                         (double)s * (double)nel * 8.0 / kBytesPerUs * (s > 1 ? 1.0 : 0.5);
     if (cost < best_cost) { best_cost = cost; best = s; }
@@ -3658,8 +3713,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
       else
         hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(512), 0, s, q);
       const int64_t tnel = (int64_t)9 * cin * cout;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(tnel, 256)), dim3(256), 0, s,
-                         (const float*)workspace, tsplits, tnel, accumulate, out_scale, dw);
+      launch_wgrad_reduce((const float*)workspace, tsplits, tnel, accumulate, out_scale, dw, s);
       return check_launch("conv2d_wgrad(taps)");
     }
   }
@@ -3681,8 +3735,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
     if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(thin_cin_wgrad_kernel, dim3((unsigned)blocks), dim3(kThinWThreads), lds, s, q);
     const int64_t tnel = (int64_t)kh * kw * cin * cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(tnel, 256)), dim3(256), 0, s,
-                       (const float*)workspace, (int)blocks, tnel, accumulate, out_scale, dw);
+    launch_wgrad_reduce((const float*)workspace, (int)blocks, tnel, accumulate, out_scale, dw, s);
     return check_launch("conv2d_wgrad(thin cin)");
   }
   WgradParams p;
@@ -3713,8 +3766,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
     hipLaunchKernelGGL(wgrad_kernel<uint16_t>, grid, dim3(kThreads), 0, s, p);
   }
   const int64_t nel = (int64_t)kh * kw * cin * cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nel, 256)), dim3(256), 0, s,
-                     (const float*)workspace, p.splits, nel, accumulate, out_scale, dw);
+  launch_wgrad_reduce((const float*)workspace, p.splits, nel, accumulate, out_scale, dw, s);
   return check_launch("conv2d_wgrad");
 }
 
@@ -3769,9 +3821,7 @@ int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dty
     if (blocks > kThinQSlabs) blocks = kThinQSlabs;
     hipLaunchKernelGGL(thin_cout_wgrad_kernel, dim3((unsigned)blocks), dim3(kThinWThreads), lds, s, q);
     const int64_t tnel = (int64_t)9 * cin * cout;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(tnel, 256)), dim3(256), 0, s,
-                       (const float*)workspace, (int)blocks, tnel, accumulate, (const float*)nullptr,
-                       dw);
+    launch_wgrad_reduce((const float*)workspace, (int)blocks, tnel, accumulate, nullptr, dw, s);
     return check_launch("conv2d_wgrad(thin cout)");
   }
   if (dtype == SE3DS_BF16 && !g_disable_glds) {
@@ -3796,8 +3846,7 @@ int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dty
       dim3 tgrid((unsigned)(cin / 64), 1, (unsigned)tsplits);
       hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(512), 0, s, q);
       const int64_t tnel = (int64_t)9 * cin * cout;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(tnel, 256)), dim3(256), 0, s,
-                         (const float*)part, tsplits, tnel, accumulate, (const float*)nullptr, dw);
+      launch_wgrad_reduce((const float*)part, tsplits, tnel, accumulate, nullptr, dw, s);
       return check_launch("conv2d_wgrad(taps, thin)");
     }
   }

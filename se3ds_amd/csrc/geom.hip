@@ -2588,6 +2588,77 @@ mask_pano_kernel(const T* __restrict__ pano, int height, int64_t row_elems, int 
 }
 
 // ------------------------------------------------------------------------- compaction
+// ------------------------------------------------------------------------------ tf.image.resize
+// Half-pixel centres (TF 2.x): nearest src = floor((i + 0.5) * in / out), bilinear src =
+// (i + 0.5) * in / out - 0.5 with the taps clamped to the image and the lerp written as
+// a + (b - a) * t; every fp32 op rounded on its own (-ffp-contract=off), as oracle/warp_np.py does.
+// Callers: equirectangular_to_pointcloud(size_mult != 1) (pano_utils.py:203-208) and
+// crop_pano(resize_to_original=True) (:299-301; its antialias=True only changes DOWN-scaling).
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+resize_nearest_kernel(const T* __restrict__ x, int n, int h, int w, int c, int oh, int ow,
+                      T* __restrict__ y) {
+  const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+  const int64_t total = (int64_t)n * oh * ow * c;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kBlock) {
+    const int k = (int)(i % c);
+    const int64_t p = i / c;
+    const int ox = (int)(p % ow);
+    const int64_t q = p / ow;
+    const int oy = (int)(q % oh), b = (int)(q / oh);
+    int iy = (int)floorf(((float)oy + 0.5f) * sy), ix = (int)floorf(((float)ox + 0.5f) * sx);
+    iy = iy < h - 1 ? iy : h - 1;
+    ix = ix < w - 1 ? ix : w - 1;
+    y[i] = x[(((int64_t)b * h + iy) * w + ix) * c + k];
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock)
+resize_bilinear_kernel(const T* __restrict__ x, int n, int h, int w, int c, int oh, int ow,
+                       float* __restrict__ y) {
+  const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+  const int64_t total = (int64_t)n * oh * ow * c;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kBlock) {
+    const int k = (int)(i % c);
+    const int64_t p = i / c;
+    const int ox = (int)(p % ow);
+    const int64_t q = p / ow;
+    const int oy = (int)(q % oh), b = (int)(q / oh);
+    const float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+    const float ly = floorf(fy), lx = floorf(fx);
+    const float ty = fy - ly, tx = fx - lx;
+    int y0 = (int)ly, x0 = (int)lx, y1 = y0 + 1, x1 = x0 + 1;
+    y0 = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 > h - 1 ? h - 1 : y1);
+    x0 = x0 < 0 ? 0 : (x0 > w - 1 ? w - 1 : x0);
+    x1 = x1 < 0 ? 0 : (x1 > w - 1 ? w - 1 : x1);
+    const T* base = x + (int64_t)b * h * w * c + k;
+    const float v00 = (float)base[((int64_t)y0 * w + x0) * c], v01 = (float)base[((int64_t)y0 * w + x1) * c];
+    const float v10 = (float)base[((int64_t)y1 * w + x0) * c], v11 = (float)base[((int64_t)y1 * w + x1) * c];
+    const float top = v00 + (v01 - v00) * tx, bot = v10 + (v11 - v10) * tx;
+    y[i] = top + (bot - top) * ty;
+  }
+}
+
+// mean of an fp32 array in binary64 (one workgroup; pad_mode='mean' of project_perspective_image,
+// pano_utils.py:403-407: a few hundred thousand elements)
+__global__ void __launch_bounds__(1024)
+mean_f32_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+  __shared__ double s_p[1024];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) acc += (double)x[i];
+  s_p[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s_p[threadIdx.x] += s_p[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(s_p[0] / (double)n);
+}
+
 // flags -> per-block counts -> exclusive scan of block counts (one block) -> scatter.
 constexpr int kCBlock = 256;
 constexpr int kCItems = 4;  // points per thread
@@ -2928,6 +2999,35 @@ int se3ds_perspective_guidance(const float* pred_rgb, const float* pred_depth, i
                      dim3(kBlock), 0, as_stream(stream), pred_rgb, pred_depth, eq_h, eq_w, kinv_t,
                      rot, height, width, proj_image, proj_depth, proj_mask);
   return check_launch("perspective_guidance");
+}
+
+int se3ds_resize(const void* x, int dtype, int n, int h, int w, int c, int oh, int ow, int method,
+                 void* y, void* stream) {
+  if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || oh <= 0 || ow <= 0) return SE3DS_E_BADSHAPE;
+  if (method != 0 && method != 1) return SE3DS_E_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const dim3 g((unsigned)grid_for((int64_t)n * oh * ow * c, kBlock));
+#define SE3DS_RS(T)                                                                               \
+  if (method == 0)                                                                                \
+    hipLaunchKernelGGL(resize_nearest_kernel<T>, g, dim3(kBlock), 0, s, (const T*)x, n, h, w, c,  \
+                       oh, ow, (T*)y);                                                            \
+  else                                                                                            \
+    hipLaunchKernelGGL(resize_bilinear_kernel<T>, g, dim3(kBlock), 0, s, (const T*)x, n, h, w, c, \
+                       oh, ow, (float*)y)
+  switch (dtype) {
+    case SE3DS_F32: SE3DS_RS(float); break;
+    case SE3DS_I32: SE3DS_RS(int32_t); break;
+    case SE3DS_U8: SE3DS_RS(uint8_t); break;
+    default: return SE3DS_E_BADDTYPE;
+  }
+#undef SE3DS_RS
+  return check_launch("resize");
+}
+
+int se3ds_mean_f32(const float* x, int64_t n, float* out, void* stream) {
+  if (n <= 0 || !out) return SE3DS_E_BADSHAPE;
+  hipLaunchKernelGGL(mean_f32_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n, out);
+  return check_launch("mean_f32");
 }
 
 int se3ds_mask_pano(const void* pano, int dtype, int n, int height, int width, int channels,

