@@ -31,6 +31,10 @@ FUSED_SN_CLIP = os.environ.get('SE3DS_FUSED_SN_CLIP', '1') != '0'
 GRAD_CLIP_NORM = 5.0   # _clip_grad default, reference :27
 # one replica: per-module clip + Adam on a side stream under the backward pass (0: after it)
 SEGMENT_OPTIMIZER = os.environ.get('SE3DS_SEGMENT_OPTIMIZER', '1') != '0'
+# one replica: the discriminator's parameter-gradient pass on a side stream under the generator's
+# backward pass (train_g_d).  Bit-identical; measured 213.8 / 214.1 ms against 214.1 / 214.6 ms per
+# step on one box (-0.2 %, inside the noise) for 0.7 GB more memory: off, kept for A/B runs.
+D_OVERLAP = os.environ.get('SE3DS_D_OVERLAP', '0') != '0'
 # one replica: weight gradients on their own stream (Ctx.on_wgrad_stream).  Bit-identical, but
 # measured SLOWER (221.0 vs 213.5 ms per step, same box): two MFMA-bound kernels co-running cost
 # more than the dependency chain gains.  Off; kept for A/B runs.
@@ -145,6 +149,11 @@ class GAN(gan_manager.GANManager):
       layers = self._all_conv_layers(model) if segment is None else self._segment_layers(model)[segment]
       cache[key] = nn.OperandGroup(layers, dtype, model.store.theta.device)
     return cache[key]
+
+  def _d_stream(self, dev):
+    if getattr(self, '_dis_stream', None) is None:
+      self._dis_stream = torch.cuda.Stream(dev)
+    return self._dis_stream
 
   def _wgrad_stream(self, dev):
     if getattr(self, '_wg_stream', None) is None:
@@ -279,25 +288,48 @@ class GAN(gan_manager.GANManager):
     tape_d = ctx_d.tape
     ctx_d.tape = None
 
-    # ---- pass 1: discriminator parameter gradients (disc_tape, :244)
-    ctx_d.param_grads = True
-    self._set_input_grad(x_all, False)
-    self._backward_tape(ctx_d, tape_d, seeds_d, logits)
-    D.spectral.backward_fixup()
-    if sync is not None:
-      d_norm = self._sync_discriminator(sync)
-    # ---- pass 2: gradient of the generator loss w.r.t. the fake images (gen_tape, :236)
-    # Only the fake half of [fake; real] carries generator loss, and nothing in the
-    # discriminator couples samples (instance norm, no batch statistics): the pass runs on the
-    # first n samples of every saved activation.
-    ctx_d.param_grads = False
-    ctx_d.batch_limit = n
-    self._set_input_grad(x_all, True)
-    self._backward_tape(ctx_d, tape_d, [g[:n] for g in seeds_g], logits)
-    ctx_d.batch_limit = None
-    gx = x_all.grad
-    x_all.grad = None
-    del tape_d
+    def pass1():
+      # discriminator parameter gradients (disc_tape, :244)
+      ctx_d.param_grads = True
+      ctx_d.batch_limit = None
+      self._set_input_grad(x_all, False)
+      self._backward_tape(ctx_d, tape_d, seeds_d, logits)
+      D.spectral.backward_fixup()
+
+    def pass2():
+      # gradient of the generator loss w.r.t. the fake images (gen_tape, :236).  Only the fake
+      # half of [fake; real] carries generator loss, and nothing in the discriminator couples
+      # samples (instance norm, no batch statistics): the pass runs on the first n samples of
+      # every saved activation.
+      ctx_d.param_grads = False
+      ctx_d.batch_limit = n
+      self._set_input_grad(x_all, True)
+      self._backward_tape(ctx_d, tape_d, [g[:n] for g in seeds_g], logits)
+      ctx_d.batch_limit = None
+      g = x_all.grad
+      x_all.grad = None
+      return g
+
+    side_opt = sync is None and SEGMENT_OPTIMIZER and nn.conv_profiler() is None
+    d_done = None
+    if side_opt and D_OVERLAP:
+      # One replica: the generator's backward pass only needs pass 2.  Pass 1 (the discriminator's
+      # own parameter gradients over [fake; real]) is issued behind it on a side stream and runs
+      # under the generator's backward pass; the discriminator's activations stay alive until the
+      # streams have joined (tape_d is released at the end of the step).
+      gx = pass2()
+      dstream = self._d_stream(dev)
+      dstream.wait_stream(torch.cuda.current_stream(dev))
+      with torch.cuda.stream(dstream):
+        pass1()
+        d_done = torch.cuda.Event()
+        d_done.record()
+    else:
+      pass1()
+      if sync is not None:
+        d_norm = self._sync_discriminator(sync)
+      gx = pass2()
+      del tape_d
     g_rgb = nn.slice_channels(gx[:n], 0, 3, torch.float32)
     _lib.check(L.se3ds_add(d_rgb.data_ptr(), g_rgb.data_ptr(), _lib.F32, d_rgb.numel(),
                            d_rgb.data_ptr(), _lib.stream()), 'se3ds_add')
@@ -314,7 +346,7 @@ class GAN(gan_manager.GANManager):
     push_depth(d_depth)
     # ---- clip per tensor (per replica), aggregate, apply (:238-257)
     ema_theta, ema_omd = self.ema_fused_args()   # EMA of the trainable variables rides on Adam
-    if sync is None and SEGMENT_OPTIMIZER and nn.conv_profiler() is None:
+    if side_opt:
       # (not while the bench times single convolution launches: see _Model.make_ctx)
       # One replica: a module's spectral fix-up, per-tensor clip and Adam (+ EMA) update run on a
       # SIDE STREAM as soon as the backward pass has left the module, under the rest of the
@@ -324,9 +356,11 @@ class GAN(gan_manager.GANManager):
       segs = self._segments()
       opt = self._optimizer_stream(dev)
       main = torch.cuda.current_stream(dev)
-      ev = torch.cuda.Event()
-      ev.record()
-      with torch.cuda.stream(opt):   # discriminator: its gradients are final since pass 1
+      ev = d_done
+      if ev is None:
+        ev = torch.cuda.Event()
+        ev.record()
+      with torch.cuda.stream(opt):   # discriminator: its gradients are final behind pass 1
         opt.wait_event(ev)
         d_norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
         self.d_optimizer.apply_gradients(group, 1)

@@ -27,7 +27,4 @@ for d in random room; do
   rm -rf gpurun_out/prof_warp_r3
 done
 rm -rf gpurun_out/prof_gan_r3 gpurun_out/pmc_r3_*
-SECONDS=0
-timeout 900 python -m pytest "tests/test_nets_gpu.py::test_segment_grad_sync_matches_serial_path" "tests/test_configs_gpu.py::test_cfg1_generator_gradients_vs_fp64_yardstick" "tests/test_nets_gpu.py::test_scheduling_switches_are_bit_identical" -m gpu -x -q --durations=5 > gpurun_out/r3_k_tests.log 2>&1
-echo "pytest rc=$? elapsed $SECONDS s"; tail -8 gpurun_out/r3_k_tests.log | cut -c1-200
 du -sh gpurun_out
