@@ -77,14 +77,16 @@ class SE3DSModel(object):
         resnet_version=config.resnet_version, gen_dims=config.gen_dims,
         use_blurred_mask=config.use_blurred_mask, device=self.device, dtype=dtype)
     if config.ckpt_path is not None:
-      # reference :100-104 restores tf.train.Checkpoint(ema_generator=model).  TensorFlow bundles
-      # cannot be read here; the same variables are accepted as an .npz with keys
-      # 'ema_generator/<variable path>' (GANManager.save_checkpoint, or the TF-side exporter of
-      # INTEGRATION.md section 5).
+      # reference :100-104 restores tf.train.Checkpoint(ema_generator=model): a TensorFlow tensor
+      # bundle prefix ('<dir>/ckpt-N', files .index + .data-*) is read by utils/tf_bundle.py
+      # through the object-graph key table; the same variables are also accepted as an .npz with
+      # keys 'ema_generator/<variable path>' (GANManager.save_checkpoint).
       if not str(config.ckpt_path).endswith('.npz'):
-        raise NotImplementedError(
-            'tf.train.Checkpoint bundles cannot be read without TensorFlow: export the '
-            'ema_generator variables to .npz (INTEGRATION.md section 5)')
+        from se3ds_amd.utils import tf_bundle
+        tf_bundle.load_generator(self.model, str(config.ckpt_path), root='ema_generator')
+        print(f'Restored SE3DS generator from {config.ckpt_path}.')
+        self._restored = True
+    if config.ckpt_path is not None and not getattr(self, '_restored', False):
       import numpy as _np
       with _np.load(config.ckpt_path) as f:
         for prefix in ('ema_generator/', 'generator/'):

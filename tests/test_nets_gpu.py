@@ -744,8 +744,16 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
   with np.load(path) as f:
     k = next(k for k in f.files if k.startswith('ema_generator/') and k.endswith('/kernel'))
     np.testing.assert_array_equal(m.model.store[k[len('ema_generator/'):]].cpu().numpy(), f[k])
+  # the reference's own format: a tf.train.Checkpoint(ema_generator=...) bundle prefix
+  from se3ds_amd.utils import tf_bundle
+  prefix = path[:-4] + '_tf/ckpt-1'
+  os.makedirs(os.path.dirname(prefix), exist_ok=True)
+  tf_bundle.save_generator(m.model, prefix)
+  cfg.ckpt_path = prefix
+  m2 = models.SE3DSModel(cfg, device=DEV, dtype=torch.float32)
+  assert torch.equal(m2.model.store.theta, m.model.store.theta)
   cfg.ckpt_path = '/nonexistent/model.ckpt-1'
-  with pytest.raises(NotImplementedError):
+  with pytest.raises(FileNotFoundError):
     models.SE3DSModel(cfg, device=DEV, dtype=torch.float32)
 
 
