@@ -185,7 +185,7 @@ def bench_warp(args, rank, world, dev):
 
   traffic, traffic_detail = (None, None)
   if (h, views, args.warp_depth) == (1024, 2, 'random'):
-    traffic, traffic_detail = _pmc_traffic('r02_warp_pmc.json', ('splat_bin', 'splat_tile', 'splat_sink'))
+    traffic, traffic_detail = _pmc_traffic('r03_warp_pmc.json', ('splat_pack',))
   out = {
       'metric': 'panoramas/sec (2-view unproject + 1 target render, 1024x2048 equirect)',
       'value': world * args.steps / dt, 'unit': 'panoramas/sec', 'n_gpus': world,
@@ -194,7 +194,7 @@ def bench_warp(args, rank, world, dev):
       'data': 'synthetic',
       'config': {'workload': f'warp cfg5 {h}x{w} V={views} (replicas only)' +
                              ('' if args.warp_depth == 'random' else f', {args.warp_depth} depth')},
-      'roofline': {'bound': 'hbm', 'kernel': 'project+splat (chunk count, column scan, scatter, per-tile resolve)',
+      'roofline': {'bound': 'hbm', 'kernel': 'project+splat (splat_pack_*: count, column scan, permute, per-tile resolve, sink)',
                    'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                    'traffic_detail': traffic_detail,

@@ -80,9 +80,32 @@ def _same_pads(size, k, s):
   return total // 2, total - total // 2
 
 
+def _conv2d_patches(x, kernel, stride):
+  """'VALID' convolution of an (already padded) NHWC tensor as ONE matrix product in the operands'
+  natural layouts: patches[n, y, x, (ky, kx, ci)] @ kernel.reshape(kh*kw*ci, co).  Used for the
+  binary64 yardstick runs only: PyTorch's fp64 conv2d is a per-image im2col loop behind a strided
+  transposition of every kernel (HWIO -> OIHW), which at 1.1 B parameters was most of those runs'
+  time (aten::copy_ 30 %, slow_conv2d 14 %); the products and sums are the same up to
+  reassociation (1e-16 relative in binary64)."""
+  kh, kw, ci, co = kernel.shape
+  n, hp, wp, _ = x.shape
+  ho, wo = (hp - kh) // stride + 1, (wp - kw) // stride + 1
+  cols = [x[:, ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (wo - 1) + 1:stride, :]
+          for ky in range(kh) for kx in range(kw)]
+  patches = torch.cat(cols, dim=-1) if len(cols) > 1 else cols[0]
+  y = patches.reshape(-1, kh * kw * ci) @ kernel.reshape(kh * kw * ci, co)
+  return y.reshape(n, ho, wo, co)
+
+
 def tf_conv2d(x, kernel, stride, padding):
   """tf.nn.conv2d: NHWC input, HWIO kernel, 'VALID' | 'SAME'."""
   k = kernel.shape[0]
+  if x.dtype == torch.float64:
+    if padding.upper() == 'SAME':
+      pt, pb = _same_pads(x.shape[1], k, stride)
+      pl, pr = _same_pads(x.shape[2], kernel.shape[1], stride)
+      x = F.pad(x, (0, 0, pl, pr, pt, pb))
+    return _conv2d_patches(x, kernel, stride)
   xn = _nchw(x)
   if padding.upper() == 'SAME':
     pt, pb = _same_pads(x.shape[1], k, stride)
@@ -116,6 +139,30 @@ def power_iteration(kernel, u, eps=1e-10):
   u_hat, v_hat = u_hat.detach(), v_hat.detach()
   sigma = (v_hat @ w) @ u_hat.t()
   return sigma, u_hat
+
+
+class _DivBySigma(torch.autograd.Function):
+  """kernel / denom (denom a one-element tensor) with a backward pass that makes two sweeps over
+  the kernel-sized operands instead of autograd's five (g / d, and one dot product for the
+  denominator's gradient -sum(g * kernel) / d^2).  Binary64 yardstick runs only; same arithmetic
+  up to the summation order of that dot product."""
+
+  @staticmethod
+  def forward(ctx, kernel, denom):
+    ctx.save_for_backward(kernel, denom)
+    return kernel / denom
+
+  @staticmethod
+  def backward(ctx, g):
+    kernel, denom = ctx.saved_tensors
+    gd = -(torch.dot(g.reshape(-1), kernel.reshape(-1)) / (denom * denom))
+    return g / denom, gd.reshape(denom.shape)
+
+
+def div_by_sigma(kernel, denom):
+  if kernel.dtype == torch.float64 and denom.numel() == 1:
+    return _DivBySigma.apply(kernel, denom)
+  return kernel / denom
 
 
 def leaky_relu(x, alpha):
@@ -221,7 +268,7 @@ class Net:
     sigma, u_hat = power_iteration(kernel, self.get(name + '/u'))
     if self.training:
       self.updates[name + '/u'] = u_hat
-    w_norm = kernel / (sigma + 1e-10)
+    w_norm = div_by_sigma(kernel, sigma + 1e-10)
     y = tf_conv2d(x, w_norm, stride, padding)
     if self.has(name + '/bias'):
       y = y + self.get(name + '/bias')

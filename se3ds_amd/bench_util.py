@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def pmc_traffic(json_name, kernels):
   """HBM bytes per launch from the TRACKED rocprofv3 PMC summaries under profiles/ (separate
-  FETCH_SIZE / WRITE_SIZE passes, tools/gpu_r2_prof.sh; raw counter values, the guide's x2 gfx950
+  FETCH_SIZE / WRITE_SIZE passes, tools/gpu_r3_prof.sh; raw counter values, the guide's x2 gfx950
   correction for wide coalesced reads is listed beside them).  None when the file is missing."""
   path = os.path.join(ROOT, 'profiles', json_name)
   if not os.path.exists(path):

@@ -125,3 +125,38 @@ def test_avg_and_max_pool_same_semantics():
   m = O.max_pool_same(x)
   assert m.shape == (2, 3, 4, 1)
   assert float(m[0, 2, 3, 0]) == float(x[0, 4, 6, 0])
+
+
+def test_fp64_yardstick_fast_paths_equal_the_plain_formulation():
+  """The binary64 runs of the oracle (yardstick of the GPU gradient tests) take a patch-matrix
+  convolution and a two-sweep spectral division; both must be the plain F.conv2d / autograd
+  division up to binary64 rounding, values and gradients."""
+  import torch.nn.functional as F
+  g = torch.Generator().manual_seed(0)
+  for (k, stride, padding, h, w) in ((3, 1, 'SAME', 6, 9), (4, 2, 'SAME', 9, 12), (1, 1, 'VALID', 5, 4),
+                                     (7, 2, 'VALID', 15, 17), (3, 2, 'SAME', 8, 8), (2, 1, 'VALID', 4, 6)):
+    x = torch.randn((2, h, w, 5), generator=g, dtype=torch.float64, requires_grad=True)
+    kern = torch.randn((k, k, 5, 7), generator=g, dtype=torch.float64, requires_grad=True)
+    y = O.tf_conv2d(x, kern, stride, padding)
+    xn = x.permute(0, 3, 1, 2)
+    if padding == 'SAME':
+      pt, pb = O._same_pads(h, k, stride)
+      pl, pr = O._same_pads(w, k, stride)
+      xn = F.pad(xn, (pl, pr, pt, pb))
+    want = F.conv2d(xn, kern.permute(3, 2, 0, 1), stride=stride).permute(0, 2, 3, 1)
+    assert y.shape == want.shape
+    cot = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    gx, gk = torch.autograd.grad((y * cot).sum(), (x, kern))
+    wx, wk = torch.autograd.grad((want * cot).sum(), (x, kern))
+    for a, b in ((y, want), (gx, wx), (gk, wk)):
+      assert float((a - b).abs().max()) <= 1e-13 * float(b.abs().max()), (k, stride, padding)
+  kern = torch.randn((3, 3, 4, 6), generator=g, dtype=torch.float64, requires_grad=True)
+  sig = torch.tensor([[1.7]], dtype=torch.float64, requires_grad=True)
+  cot = torch.randn(kern.shape, generator=g, dtype=torch.float64)
+  a = torch.autograd.grad((O.div_by_sigma(kern, sig + 1e-10) * cot).sum(), (kern, sig))
+  b = torch.autograd.grad(((kern / (sig + 1e-10)) * cot).sum(), (kern, sig))
+  for u, v in zip(a, b):
+    assert u.shape == v.shape and float((u - v).abs().max()) <= 1e-14 * float(v.abs().max())
+  # fp32 keeps the plain path (its rounding order is what the GPU results are compared with)
+  k32 = kern.detach().float().requires_grad_(True)
+  assert O.div_by_sigma(k32, sig.detach().float()).grad_fn.name().startswith('DivBackward')
