@@ -280,6 +280,25 @@ int se3ds_conv2d_dgrad_acc(const void* dy, const void* wn, void* dx, int dtype, 
                        const float* bias, const float* row_a, int act, float act_alpha,
                        const void* addend, void* stream);
 
+/* Data gradient with FUSED batch-norm backward statistics (round 3).  dx (+ addend when given)
+ * is the gradient of y = act(norm(bn_x) [+ res]), the output of a SyncBatchNormalization
+ * (tf.keras.layers.experimental.SyncBatchNormalization behind models/layers.py:241-251,
+ * 424-444); besides dx the epilogue emits stats[rows][2][cin] = per 64-pixel tile
+ * (sum dz, sum dz * xhat) with dz = dx_stored * act'(y) (bn_mask: one "y > 0" bit per element,
+ * or NULL without activation; bn_act 0 / 1 relu / 2 leaky relu with slope bn_alpha) and
+ * xhat = (bn_x - bn_mean) * bn_rstd -- the sums se3ds_norm_bwd_stats takes from a second pass over
+ * dx and bn_x.  se3ds_norm_reduce_rows_dst reduces the rows (and writes the beta / gamma
+ * gradients).  _rows returns 0 when this shape cannot (strided, fp32, thin / ragged channels,
+ * a dy row scale): call se3ds_conv2d_dgrad[_acc] and se3ds_norm_bwd_stats then. */
+int64_t se3ds_conv2d_dgrad_bnstats_rows(int dtype, int n, int h, int w, int cin, int cout, int kh,
+                                        int kw, int stride, int has_row_scale);
+int se3ds_conv2d_dgrad_bnstats(const void* dy, const void* wn, void* dx, int dtype, int n, int h,
+                               int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride,
+                               int pad_t, int pad_l, int wrap_w, const float* scale,
+                               const float* row_a, const void* addend, const void* bn_x,
+                               const uint8_t* bn_mask, const float* bn_mean, const float* bn_rstd,
+                               int bn_act, float bn_alpha, float* stats, void* stream);
+
 /* dW[kh,kw,cin,cout] (fp32) (+)= (*out_scale) * sum_pixels (x*in_mask)^T (dy*row_scale).
  * The reduction over n*ho*wo is split across workgroups and reduced deterministically. */
 size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int cout, int kh,
@@ -342,6 +361,10 @@ int se3ds_norm_stats(const void* x, int dtype, int g, int64_t r, int c, const fl
  * se3ds_norm_workspace_bytes(ceil(rows/512), c) bytes for rows > 2048). */
 int se3ds_norm_reduce_rows(const float* partial, int64_t rows, int c, float* sums, void* workspace,
                            size_t workspace_bytes, void* stream);
+/* The same; dst0 / dst1 (c floats each, may be NULL) additionally receive sums[0][:] / sums[1][:]
+ * (the beta / gamma gradients when the rows are fused batch-norm backward statistics). */
+int se3ds_norm_reduce_rows_dst(const float* partial, int64_t rows, int c, float* sums, float* dst0,
+                               float* dst1, void* workspace, size_t workspace_bytes, void* stream);
 /* mean = S0/count, var = S1/count - mean^2 (biased); scale = gamma*rsqrt(var+eps),
  * shift = beta - mean*scale; moving stats (c) updated in place unless NULL;
  * use_moving != 0: inference (statistics from moving_mean / moving_var). */

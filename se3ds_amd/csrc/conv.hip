@@ -81,6 +81,14 @@ struct IgemmParams {
   // dx = conv result + addend (same layout and dtype as out; may alias out): the second
   // contribution to a tensor with two consumers (ResNet block input) without a separate pass
   const void* addend;
+  // DGRAD with fused batch-norm backward statistics (se3ds_conv2d_dgrad_bnstats): `out` is the
+  // gradient of y = act(norm(bn_x)) + ..., and the epilogue also emits, per 64-pixel wave tile,
+  // stats[row][2][oC] = (sum dz, sum dz * xhat) with dz = out * act'(y) (activation bit mask
+  // bn_mask, one bit per element, or null without activation) and xhat = (bn_x - mean) * rstd,
+  // taken from the STORED (rounded, addend included) gradient -- what norm_partial_kernel<MODE 1>
+  // would read back.  bn_x == nullptr: off.
+  const uint16_t* bn_x; const uint8_t* bn_mask; const float* bn_mean; const float* bn_rstd;
+  int bn_act; float bn_alpha;
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
@@ -218,7 +226,7 @@ template <int NI, int PXC = 32> constexpr int kEpiScratch = PXC * (NI * 64 + 16)
 
 // PXC: pixels parked per pass (32, or 16 to halve the scratch).  bias4(cl) returns the bias of
 // channels co_base + cl .. + 3 (zeros without bias); `scale` is the spectral 1/(sigma+eps).
-template <int NI, int PXC, typename BiasFn>
+template <int NI, int PXC, bool BNB = false, typename BiasFn>
 __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16_t (&acc)[NI][2],
                                                     const int64_t (&opix)[2], int co_base, int lane,
                                                     unsigned char* scratch, float scale,
@@ -240,6 +248,22 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
   // epilogue form (wave-uniform): 0 plain, 1 + bias, 2 * ratio, 3 partial conv with bias
   const int form = p.row_a ? (p.bias ? 3 : 2) : (p.bias ? 1 : 0);
   float cs1 = 0.f, cs2 = 0.f;   // column sums of channel co_base + lane (NI == 2 only)
+  // fused batch-norm backward statistics (wave-uniform switch): in the write-back a lane owns
+  // channels co_base + (lane % 8) * 8 .. + 7 of pixel lane / 8
+  const bool bnb = BNB && NI == 2 && NPASS == 1 && stats_row != nullptr && p.bn_x != nullptr;
+  // (sum dz * (x - mean) is accumulated and scaled by rstd once at the end: 24 live registers
+  // instead of 32 in an epilogue that is already at the register limit)
+  float bs1[8], bs2[8], bmu[8];
+  if (BNB && NI == 2 && bnb) {
+    const int c0 = co_base + (lane % LPP) * 8;
+#pragma unroll
+    for (int h4 = 0; h4 < 2; ++h4) {
+      const float4 m4 = *reinterpret_cast<const float4*>(p.bn_mean + c0 + h4 * 4);
+      bmu[h4 * 4] = m4.x; bmu[h4 * 4 + 1] = m4.y; bmu[h4 * 4 + 2] = m4.z; bmu[h4 * 4 + 3] = m4.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; }
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int64_t o = opix[j];
@@ -281,7 +305,7 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
       else if (form == 2) emit(std::integral_constant<int, 2>());
       else emit(std::integral_constant<int, 3>());
       __builtin_amdgcn_wave_barrier();
-      if (NI == 2 && NPASS == 1 && stats_row != nullptr) {
+      if (NI == 2 && NPASS == 1 && stats_row != nullptr && !bnb) {
         // batch-norm statistics of the stored (rounded) outputs: lane = channel
 #pragma unroll 8
         for (int px = 0; px < PXC; ++px) {
@@ -297,6 +321,9 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
         const int64_t po = offs[px];
         if (po >= 0) {
           if (p.addend) {
+            // (requesting the four pieces of a fragment before the parking phase instead of one
+            // exposed round trip per store was measured 0.8 % slower per step: 16 more live
+            // registers in an epilogue at the limit)
             const uint4 a = *reinterpret_cast<const uint4*>((const uint16_t*)p.addend + po * p.oC +
                                                             co_base + c16 * 8);
             uint32_t* vw = reinterpret_cast<uint32_t*>(&v);
@@ -309,18 +336,61 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
             }
           }
           *reinterpret_cast<uint4*>(out + po * p.oC + co_base + c16 * 8) = v;
+          if (BNB && NI == 2 && bnb) {
+            // (fetching these before the parking phase instead -- 40 more live registers, spills
+            // in the 256-channel kernel -- was measured slower still)
+            const int64_t e0 = po * p.oC + co_base + c16 * 8;
+            const uint4 xr = *reinterpret_cast<const uint4*>(p.bn_x + e0);
+            const unsigned mb = p.bn_mask ? p.bn_mask[e0 >> 3] : 0xffu;
+            const uint32_t* vw = reinterpret_cast<const uint32_t*>(&v);
+            const uint32_t* xw = reinterpret_cast<const uint32_t*>(&xr);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float d0 = __uint_as_float(vw[q] << 16) *
+                               act_grad_from_bit((mb >> (2 * q)) & 1u, p.bn_act, p.bn_alpha);
+              const float d1 = __uint_as_float(vw[q] & 0xffff0000u) *
+                               act_grad_from_bit((mb >> (2 * q + 1)) & 1u, p.bn_act, p.bn_alpha);
+              const float x0 = __uint_as_float(xw[q] << 16), x1 = __uint_as_float(xw[q] & 0xffff0000u);
+              bs1[2 * q] += d0;
+              bs2[2 * q] += d0 * (x0 - bmu[2 * q]);
+              bs1[2 * q + 1] += d1;
+              bs2[2 * q + 1] += d1 * (x1 - bmu[2 * q + 1]);
+            }
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
   }
-  if (NI == 2 && stats_row != nullptr) {
+  if (BNB && NI == 2 && bnb) {
+    // the eight lanes with the same lane % 8 hold the same channels: butterfly over lane bits 3-5
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int m = 8; m < 64; m <<= 1) {
+        bs1[e] += __shfl_xor(bs1[e], m, 64);
+        bs2[e] += __shfl_xor(bs2[e], m, 64);
+      }
+    }
+    if (lane < 8) {
+      float* r1 = stats_row + co_base + lane * 8;
+      float* r2 = stats_row + p.oC + co_base + lane * 8;
+      const float4 ra4 = *reinterpret_cast<const float4*>(p.bn_rstd + co_base + lane * 8);
+      const float4 rb4 = *reinterpret_cast<const float4*>(p.bn_rstd + co_base + lane * 8 + 4);
+      bs2[0] *= ra4.x; bs2[1] *= ra4.y; bs2[2] *= ra4.z; bs2[3] *= ra4.w;
+      bs2[4] *= rb4.x; bs2[5] *= rb4.y; bs2[6] *= rb4.z; bs2[7] *= rb4.w;
+      *reinterpret_cast<float4*>(r1) = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]);
+      *reinterpret_cast<float4*>(r1 + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
+      *reinterpret_cast<float4*>(r2) = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]);
+      *reinterpret_cast<float4*>(r2 + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
+    }
+  } else if (NI == 2 && stats_row != nullptr) {
     stats_row[co_base + lane] = cs1;
     stats_row[p.oC + co_base + lane] = cs2;
   }
 }
 
-template <int NI>
+template <int NI, bool BNB = false>
 __device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&acc)[NI][2],
                                                const int64_t (&opix)[2], int co_base, int lane,
                                                unsigned char* scratch, float* stats_row = nullptr) {
@@ -331,12 +401,12 @@ __device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&
     return p.bias ? *reinterpret_cast<const float4*>(p.bias + co_base + cl)
                   : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  store_wave_lds_impl<NI, 32>(p, acc, opix, co_base, lane, scratch, scale, bias4, stats_row);
+  store_wave_lds_impl<NI, 32, BNB>(p, acc, opix, co_base, lane, scratch, scale, bias4, stats_row);
 }
 
 // m_base / co_base: first pixel row / output channel of this wave's sub-tile.
 // scratch: this wave's kEpiScratch<NI> bytes of LDS (no longer read by anyone) or null.
-template <typename T, int MODE, int NI = 2>
+template <typename T, int MODE, int NI = 2, bool BNB = false>
 __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)[NI][2],
                                            int64_t m_base, int co_base, int64_t Mc, int cH, int cW,
                                            int py, int px, int half, int l32,
@@ -359,12 +429,12 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)
   if (sizeof(T) == 2 && scratch != nullptr && (p.oC & 7) == 0 && co_base + NI * 32 <= p.oC) {
     if (NI == 4 && stats_row != nullptr) {
       // column sums are kept per 64-channel half (lane = channel)
-      store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base,
-                        half * 32 + l32, scratch, stats_row);
-      store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64,
-                        half * 32 + l32, scratch, stats_row);
+      store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base,
+                             half * 32 + l32, scratch, stats_row);
+      store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix,
+                             co_base + 64, half * 32 + l32, scratch, stats_row);
     } else {
-      store_wave_lds<NI>(p, acc, opix, co_base, half * 32 + l32, scratch, stats_row);
+      store_wave_lds<NI, BNB>(p, acc, opix, co_base, half * 32 + l32, scratch, stats_row);
     }
     return;
   }
@@ -611,7 +681,7 @@ __device__ __attribute__((aligned(128))) unsigned char g_zero_page[128];
 typedef __attribute__((address_space(1))) const void* gas_ptr;
 typedef __attribute__((address_space(3))) void* las_ptr;
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool BNB = false>
 __global__ void __launch_bounds__(kThreads, 2)
 igemm_glds_kernel(const IgemmParams p) {
   using tt = TT<T>;
@@ -794,10 +864,11 @@ igemm_glds_kernel(const IgemmParams p) {
     flush_acc<T>(acc, tot);
   }
   // (the loop's closing __syncthreads leaves both stages idle: stage0 is the epilogue scratch)
-  float* stats_row = (MODE == MODE_FWD && p.stats)
+  // (DGRAD: only in the instantiation with fused batch-norm backward statistics)
+  float* stats_row = ((MODE == MODE_FWD || BNB) && p.stats)
                          ? p.stats + ((int64_t)(tile_m * (BM / 64) + wn) * 2) * p.oC : nullptr;
-  store_tile<T, MODE>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py, px,
-                      half, l32, stage0 + wave * kEpiScratch<2>, stats_row);
+  store_tile<T, MODE, 2, BNB>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py,
+                              px, half, l32, stage0 + wave * kEpiScratch<2>, stats_row);
 }
 
 // ------------------------------------------------------------------ 256-pixel macro tiles
@@ -808,7 +879,7 @@ igemm_glds_kernel(const IgemmParams p) {
 // fill-bound; this tile doubles (CO = 128: x1.33) the FLOPs per byte filled and, with a
 // 128 x 64 wave tile, needs 0.75 fragment reads per MFMA instead of 1.  Requires oC % CO == 0
 // and reduction channels % 64 == 0, and the same gather restrictions as igemm_glds_kernel.
-template <int MODE, int CO>
+template <int MODE, int CO, bool BNB = false>
 __global__ void __launch_bounds__(512)
 igemm_big_kernel(const IgemmParams p) {
   typedef uint16_t T;
@@ -1026,9 +1097,9 @@ igemm_big_kernel(const IgemmParams p) {
   if (wm == 0) __builtin_amdgcn_s_barrier();   // balance the late start of channel half 1
   // every wave is past its last fragment read: the stages become the epilogue scratch
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-  float* stats_row = (MODE == MODE_FWD && p.stats)
+  float* stats_row = ((MODE == MODE_FWD || BNB) && p.stats)
                          ? p.stats + ((int64_t)(tile_m * (PIX / 64) + wn) * 2) * p.oC : nullptr;
-  store_tile<T, MODE, NI>(p, acc, (int64_t)tile_m * PIX + wn * 64, n0 + wm * (CO / 2), Mc, cH, cW,
+  store_tile<T, MODE, NI, BNB>(p, acc, (int64_t)tile_m * PIX + wn * 64, n0 + wm * (CO / 2), Mc, cH, cW,
                           py, px, half, l32,
                           (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>, stats_row);
 }
@@ -1047,7 +1118,7 @@ igemm_big_kernel(const IgemmParams p) {
 //   pixel (y0 + a, x0 + b) is patch pixel (a + dy, b + dx) with (dy, dx) = (ky, kx) forward and
 //   (2 - ky, 2 - kx) for the data gradient.  16-byte chunks are XOR-swizzled with (r >> 1) & 7;
 //   the 32 consecutive rows of a fragment read stay conflict-free for any start row.
-template <int MODE, int CO, int WST>
+template <int MODE, int CO, int WST, bool BNB = false>
 __global__ void __launch_bounds__(512)
 igemm_halo_kernel(const IgemmParams p) {
   typedef uint16_t T;
@@ -1299,7 +1370,7 @@ igemm_halo_kernel(const IgemmParams p) {
   // Every wave is past its last fragment read.  xb1 is the epilogue scratch (the last K steps'
   // idle copies only touch `sink`); xb0 and the first weight stages hold / take the next item's
   // first slab and weight tiles.
-  float* stats_row = (MODE == MODE_FWD && p.stats)
+  float* stats_row = ((MODE == MODE_FWD || BNB) && p.stats)
                          ? p.stats + ((int64_t)(cur.tile * 4 + wn) * 2) * p.oC : nullptr;
   item += gridDim.x;
   const bool have = item < nitems;
@@ -1311,11 +1382,11 @@ igemm_halo_kernel(const IgemmParams p) {
   // so that the epilogue issues no global load, was measured slower: 1.62 vs 1.44 ms on the
   // 3x3 128->128 @512x1024 layer)
   unsigned char* scratch = xb1 + wave * kEpiScratch<2>;
-  store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane, scratch,
-                    stats_row);
+  store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane,
+                         scratch, stats_row);
   if (NI == 4)
-    store_wave_lds<2>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64,
-                      lane, scratch, stats_row);
+    store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64,
+                           lane, scratch, stats_row);
   if (!have) break;
   }
 }
@@ -3383,12 +3454,15 @@ static int big_tile_channels(const IgemmParams& p, int mode) {
 // (one row per 64-pixel wave tile), or 0 when that kernel cannot (fp32, scalar gather, ragged
 // channel tiles).  Must follow conv_common's routing order: halo, 256-pixel macro tile, 128 x 128.
 static int64_t fwd_stats_rows(const IgemmParams& p, int dtype, int stride, int kh, int kw,
-                              bool glds) {
+                              bool glds, int mode = MODE_FWD) {
   if (!glds || dtype != SE3DS_BF16) return 0;
+  // data gradient (fused batch-norm backward statistics): stride 1 only -- one parity class,
+  // the same tile geometry as a forward pass over the gradient's pixels
+  if (mode == MODE_DGRAD && stride != 1) return 0;
   const int64_t M = (int64_t)p.N * p.oH * p.oW;
   if (stride == 1 && kh == 3 && kw == 3 && halo_tile_channels(p))
     return (int64_t)p.N * ceil_div(p.oH, 8) * ceil_div(p.oW, 32) * 4;
-  if (big_tile_channels(p, MODE_FWD)) return ceil_div(M, (int64_t)256) * 4;
+  if (big_tile_channels(p, mode)) return ceil_div(M, (int64_t)256) * 4;
   if ((p.oC % BN) == 0) return ceil_div(M, (int64_t)BM) * (BM / 64);
   return 0;
 }
@@ -3400,7 +3474,10 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
                        int stride, int pad_t, int pad_l, int wrap_w, const float* src_mask,
                        int mask_binary, const float* scale, const float* bias, const float* row_a,
                        const float* row_b, int act, float act_alpha, void* stream,
-                       float* stats = nullptr, const void* addend = nullptr) {
+                       float* stats = nullptr, const void* addend = nullptr,
+                       const void* bn_x = nullptr, const uint8_t* bn_mask = nullptr,
+                       const float* bn_mean = nullptr, const float* bn_rstd = nullptr,
+                       int bn_act = 0, float bn_alpha = 0.f) {
   if (n <= 0 || h <= 0 || wdt <= 0 || cin <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || kh <= 0 ||
       kw <= 0 || stride <= 0 || stride > 2)
     return SE3DS_E_BADSHAPE;
@@ -3429,10 +3506,15 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   hipStream_t s = as_stream(stream);
   const bool glds = (p.sC % (2 * bk)) == 0 && (src_mask == nullptr || mask_binary) &&
                     !g_disable_glds;
-  if (stats != nullptr &&
-      !(mode == MODE_FWD && fwd_stats_rows(p, dtype, stride, kh, kw, glds) > 0))
-    return SE3DS_E_UNSUPPORTED;   // callers ask se3ds_conv2d_fwd_stats_rows first
-  p.stats = mode == MODE_FWD ? stats : nullptr;
+  if (stats != nullptr && !(fwd_stats_rows(p, dtype, stride, kh, kw, glds, mode) > 0))
+    return SE3DS_E_UNSUPPORTED;   // callers ask se3ds_conv2d_{fwd_stats,dgrad_bnstats}_rows first
+  if (stats != nullptr && mode == MODE_DGRAD &&
+      (bn_x == nullptr || bn_mean == nullptr || bn_rstd == nullptr || (p.oC & 7) != 0))
+    return SE3DS_E_UNSUPPORTED;
+  p.stats = stats;
+  p.bn_x = (mode == MODE_DGRAD && stats != nullptr) ? (const uint16_t*)bn_x : nullptr;
+  p.bn_mask = bn_mask; p.bn_mean = bn_mean; p.bn_rstd = bn_rstd;
+  p.bn_act = bn_act; p.bn_alpha = bn_alpha;
   if (mode == MODE_DGRAD && dtype == SE3DS_BF16 && kh == 4 && kw == 4 && stride == 2 && cin <= 4 &&
       cout == 128 && src_mask == nullptr && row_a == nullptr && bias == nullptr && act == 0 &&
       !wrap_w && (pad_t == 0 || pad_t == 2) && (pad_l == 0 || pad_l == 2) &&
@@ -3487,16 +3569,17 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   if (glds && dtype == SE3DS_BF16 && stride == 1 && kh == 3 && kw == 3) {
     const int co = halo_tile_channels(p);
     if (co) {
-      p.stats = mode == MODE_FWD ? stats : nullptr;
       p.halo_ty = ceil_div(p.oH, 8);
       p.halo_tx = ceil_div(p.oW, 32);
       const int64_t items = (int64_t)p.N * p.halo_ty * p.halo_tx * (p.oC / co);
       dim3 grid((unsigned)(items < 256 ? items : 256));   // persistent: one workgroup per CU
       if (co == 256) {
         if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256, 2>), grid, dim3(512), 0, s, p);
+        else if (p.bn_x) hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2>), grid, dim3(512), 0, s, p);
       } else {
         if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3>), grid, dim3(512), 0, s, p);
+        else if (p.bn_x) hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3>), grid, dim3(512), 0, s, p);
       }
       return check_launch(mode == MODE_FWD ? "conv2d_fwd(halo)" : "conv2d_dgrad(halo)");
@@ -3510,9 +3593,11 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       dim3 grid((unsigned)tiles, (unsigned)(p.oC / co));
       if (co == 256) {
         if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_big_kernel<MODE_FWD, 256>), grid, dim3(512), 0, s, p);
+        else if (p.bn_x) hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 256, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 256>), grid, dim3(512), 0, s, p);
       } else {
         if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_big_kernel<MODE_FWD, 128>), grid, dim3(512), 0, s, p);
+        else if (p.bn_x) hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 128, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 128>), grid, dim3(512), 0, s, p);
       }
       return check_launch(mode == MODE_FWD ? "conv2d_fwd(big)" : "conv2d_dgrad(big)");
@@ -3527,6 +3612,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       else hipLaunchKernelGGL((igemm_glds_kernel<float, MODE_DGRAD>), grid, dim3(kThreads), 0, s, p);
     } else {
       if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
+      else if (p.bn_x) hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_DGRAD, true>), grid, dim3(kThreads), 0, s, p);
       else hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_DGRAD>), grid, dim3(kThreads), 0, s, p);
     }
     return check_launch(mode == MODE_FWD ? "conv2d_fwd(glds)" : "conv2d_dgrad(glds)");
@@ -3596,6 +3682,36 @@ int se3ds_conv2d_dgrad_acc(const void* dy, const void* wn, void* dx, int dtype, 
   return conv_common(MODE_DGRAD, dy, wn, dx, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride,
                      pad_t, pad_l, wrap_w, dy_row_scale, 0, scale, bias, row_a, nullptr, act,
                      act_alpha, stream, nullptr, addend);
+}
+
+// Data gradient with FUSED batch-norm backward statistics: dx (+ addend, may be null) is the
+// gradient of y = act(norm(bn_x) [+ res]); besides dx the epilogue emits stats[rows][2][cin] =
+// per-64-pixel-tile (sum dz, sum dz * xhat), dz = dx * act'(y) (bn_mask: one "y > 0" bit per
+// element or null), xhat = (bn_x - bn_mean) * bn_rstd, which se3ds_norm_reduce_rows turns into
+// the sums se3ds_norm_bwd_stats would have produced from a second pass over dx and bn_x.
+// rows == 0: this shape / routing cannot (strided, fp32, thin or ragged channel tiles).
+int64_t se3ds_conv2d_dgrad_bnstats_rows(int dtype, int n, int h, int w, int cin, int cout, int kh,
+                                        int kw, int stride, int has_row_scale) {
+  if (dtype != SE3DS_BF16 || stride != 1 || (cout % 64) != 0 || (cin % 8) != 0 || has_row_scale ||
+      g_disable_glds)
+    return 0;
+  const char* e = getenv("SE3DS_FUSED_BN_BWD_STATS");
+  if (e && atoi(e) == 0) return 0;
+  IgemmParams p;
+  p.N = n; p.oH = h; p.oW = w; p.oC = cin; p.stride = stride;
+  return fwd_stats_rows(p, dtype, stride, kh, kw, true, MODE_DGRAD);
+}
+
+int se3ds_conv2d_dgrad_bnstats(const void* dy, const void* wn, void* dx, int dtype, int n, int h,
+                               int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride,
+                               int pad_t, int pad_l, int wrap_w, const float* scale,
+                               const float* row_a, const void* addend, const void* bn_x,
+                               const uint8_t* bn_mask, const float* bn_mean, const float* bn_rstd,
+                               int bn_act, float bn_alpha, float* stats, void* stream) {
+  if (stats == nullptr) return SE3DS_E_UNSUPPORTED;
+  return conv_common(MODE_DGRAD, dy, wn, dx, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride,
+                     pad_t, pad_l, wrap_w, nullptr, 0, scale, nullptr, row_a, nullptr, 0, 0.f,
+                     stream, stats, addend, bn_x, bn_mask, bn_mean, bn_rstd, bn_act, bn_alpha);
 }
 
 static int wgrad_splits(int64_t L, int64_t tiles, int64_t nel) {

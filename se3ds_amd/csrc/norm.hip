@@ -774,12 +774,23 @@ int se3ds_colsum_row_scale(const void* x, int dtype, int64_t r, int c, const flo
                                      (uint16_t*)scaled_out, out_row_scale);
 }
 
+int se3ds_norm_reduce_rows_dst(const float* partial, int64_t rows, int c, float* sums, float* dst0,
+                               float* dst1, void* workspace, size_t workspace_bytes, void* stream);
+
 int se3ds_norm_reduce_rows(const float* partial, int64_t rows, int c, float* sums, void* workspace,
                            size_t workspace_bytes, void* stream) {
+  return se3ds_norm_reduce_rows_dst(partial, rows, c, sums, nullptr, nullptr, workspace,
+                                    workspace_bytes, stream);
+}
+
+// ... and optionally the two column sums also to dst0 / dst1 (c floats each): the beta / gamma
+// gradients of a batch norm whose backward statistics came out of a conv epilogue
+int se3ds_norm_reduce_rows_dst(const float* partial, int64_t rows, int c, float* sums, float* dst0,
+                               float* dst1, void* workspace, size_t workspace_bytes, void* stream) {
   if (rows <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
   hipStream_t s = as_stream(stream);
   if (rows <= 2048) {
-    launch_final_reduce(s, partial, (int)rows, c, 1, sums, nullptr, nullptr);
+    launch_final_reduce(s, partial, (int)rows, c, 1, sums, dst0, dst1);
     return check_launch("norm_reduce_rows");
   }
   // two levels: groups of kChunk rows -> workspace[groups][2][c] -> sums
@@ -794,7 +805,7 @@ int se3ds_norm_reduce_rows(const float* partial, int64_t rows, int c, float* sum
   if (tail)
     launch_final_reduce(s, partial + full * kChunk * 2 * c, (int)tail, c, 1, mid + full * 2 * c,
                         nullptr, nullptr);
-  launch_final_reduce(s, mid, (int)groups, c, 1, sums, nullptr, nullptr);
+  launch_final_reduce(s, mid, (int)groups, c, 1, sums, dst0, dst1);
   return check_launch("norm_reduce_rows");
 }
 

@@ -188,11 +188,16 @@ def truncated_normal_init(shape, gen, std=0.05):
 # --------------------------------------------------------------------------------- context
 class Var:
   """Activation handle: NHWC tensor in the compute dtype plus its (lazy) gradient."""
-  __slots__ = ('data', 'grad', 'requires_grad', 'col_stats', 'grad_pre_act', 'shared', 'grad_ev')
+  __slots__ = ('data', '_grad', 'gver', 'requires_grad', 'col_stats', 'grad_pre_act', 'shared',
+               'grad_ev', 'bn_src', 'bn_stats')
 
   def __init__(self, data, requires_grad=True):
     self.data = data
-    self.grad = None
+    self._grad = None
+    self.gver = 0           # bumped by every write to .grad (assignment or in-place accumulation)
+    self.bn_src = None      # batch-norm outputs: (x, act mask, mean, rstd, act, alpha) of the norm
+    self.bn_stats = None    # ... (stats rows, gver): backward statistics a data-gradient epilogue
+                            # took from the gradient it stored (valid while gver is unchanged)
     self.requires_grad = requires_grad
     self.col_stats = None   # conv outputs: partial column sums for a following batch norm
     self.grad_pre_act = False   # the consumer already applied this tensor's activation derivative
@@ -202,6 +207,15 @@ class Var:
   @property
   def shape(self):
     return self.data.shape
+
+  @property
+  def grad(self):
+    return self._grad
+
+  @grad.setter
+  def grad(self, g):
+    self._grad = g
+    self.gver += 1
 
 
 class Ctx:
@@ -663,6 +677,7 @@ def accumulate(var: Var, g: torch.Tensor):
     _grad_wait(var)
     _chk(_L().se3ds_add(var.grad.data_ptr(), g.data_ptr(), _lib.dtype_code(g), g.numel(),
                         var.grad.data_ptr(), _lib.stream()), 'se3ds_add')
+    var.gver += 1
   _grad_mark(var)
 
 
@@ -1053,7 +1068,37 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
       if x.requires_grad:
         prev = x.grad
         shape = (n,) + tuple(xd.shape[1:])
-        if prev is not None and tuple(prev.shape) == shape and prev.dtype == xd.dtype:
+        have_prev = prev is not None and tuple(prev.shape) == shape and prev.dtype == xd.dtype
+        bn_rows = 0
+        if (x.bn_src is not None and row_scale is None and lim is None and _FUSED_BN_BWD and
+            (prev is None or have_prev)):
+          bn_rows = int(L.se3ds_conv2d_dgrad_bnstats_rows(ctx.code, n, h, w, cin, layer.cout, k, k,
+                                                          s, 0))
+        if bn_rows > 0:
+          # x is a batch norm's output: this data gradient also takes the norm's backward
+          # statistics from the gradient it stores (speculatively: they are used only if no later
+          # contribution changes x.grad -- the first consumer in forward order is the last here)
+          bx, bmask, bmean, brstd, bact, balpha = x.bn_src
+          stats = torch.empty((bn_rows, 2, cin), dtype=torch.float32, device=ctx.device)
+          if have_prev:
+            _grad_wait(x)
+            dx = prev
+          else:
+            dx = ctx.empty(shape)
+          with _Timed('dgrad', flops, tag):
+            _chk(L.se3ds_conv2d_dgrad_bnstats(
+                dys.data_ptr(), wn.data_ptr(), dx.data_ptr(), ctx.code, n, h, w, cin, ho, wo,
+                layer.cout, k, k, s, pt, pl, 1 if wrap else 0, _lib.ptr(scale), _lib.ptr(in_mask),
+                prev.data_ptr() if have_prev else None, bx.data_ptr(), _lib.ptr(bmask),
+                bmean.data_ptr(), brstd.data_ptr(), bact, float(balpha), stats.data_ptr(),
+                _lib.stream()), 'se3ds_conv2d_dgrad_bnstats')
+          if have_prev:
+            x.gver += 1
+            _grad_mark(x)
+          else:
+            accumulate(x, dx)
+          x.bn_stats = (stats, x.gver)
+        elif have_prev:
           # second contribution (e.g. a ResNet block's input: residual branch first, then this
           # conv): the epilogue adds the existing gradient in place instead of a separate pass
           _grad_wait(x)
@@ -1063,6 +1108,7 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
                                           1 if wrap else 0, _lib.ptr(row_scale), _lib.ptr(scale),
                                           None, _lib.ptr(in_mask), ACT_NONE, 0.0, prev.data_ptr(),
                                           _lib.stream()), 'se3ds_conv2d_dgrad_acc')
+          x.gver += 1
           _grad_mark(x)
         else:
           dx = ctx.empty(shape)
@@ -1145,6 +1191,15 @@ class NormLayer:
 _MERGED_BN_STATS = os.environ.get('SE3DS_NORM_MERGED', '1') != '0'
 
 
+_NORM_DEBUG = {} if os.environ.get('SE3DS_NORM_DEBUG') else None
+# SE3DS_FUSED_BN_BWD=1: batch-norm backward statistics from the epilogue of the data gradient that
+# produces dy (se3ds_conv2d_dgrad_bnstats) instead of their own pass over dy and x.  OFF by
+# default: measured 2.8-4.4 ms per step SLOWER at batch 8 (the x tile is then read at the tail of
+# every workgroup's epilogue -- data gradient 887 -> 768 TFLOP/s, +8.5 ms -- to save a streaming
+# pass that costs 5.7 ms).  Kept, tested, for larger batches / tensors.
+_FUSED_BN_BWD = os.environ.get('SE3DS_FUSED_BN_BWD', '0') == '1'
+
+
 def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: Var = None,
              post: Var = None, in_act=None) -> Var:
   """y = act(norm(x) [+ res]) [+ post].  Batch norm uses cross-replica batch statistics when
@@ -1196,6 +1251,9 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
            'se3ds_norm_reduce_rows')
       x.col_stats = None
     else:
+      if _NORM_DEBUG is not None:   # SE3DS_NORM_DEBUG: which norms take their own statistics pass
+        key = (layer.name, tuple(xd.shape), layer.kind)
+        _NORM_DEBUG[key] = _NORM_DEBUG.get(key, 0) + 1
       sums = _colsum(ctx, xd.data_ptr(), ctx.code, r, c, groups=g)
     if not finalized:
       if not inst and ctx.world > 1:
@@ -1220,10 +1278,17 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
   out = Var(y)
   if act != ACT_NONE and ctx.act_taps is not None:
     ctx.act_taps[layer.name] = y
+  if (ctx.tape is not None and not inst and not use_moving and post is None and c % 8 == 0 and
+      xd.dtype == torch.bfloat16 and (act == ACT_NONE or amask is not None)):
+    out.bn_src = (xd, amask, mean, rstd, act, alpha)   # a consuming conv's data gradient may fuse
   sync_bwd = (not inst) and ctx.world > 1 and not use_moving   # the backward all-reduces too
   if ctx.tape is not None:
     def bwd(g=g):
       dy = out.grad
+      fused = out.bn_stats
+      if fused is not None and fused[1] != out.gver:
+        fused = None   # the gradient changed after the epilogue that took the statistics
+      out.bn_stats = None
       out.grad = None
       if dy is None:
         return
@@ -1259,12 +1324,25 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
         direct = ctx.param_grads and g == 1
         # parameter gradients are the LOCAL sums (aggregated later with every other gradient);
         # for batch norm the reduction writes them straight into the gradient arena
-        _chk(L.se3ds_norm_bwd_stats(
-            dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c, mean.data_ptr(),
-            rstd.data_ptr(), act, float(alpha), bs.data_ptr(),
-            st.grad_views[layer.name + '/beta'].data_ptr() if direct else None,
-            st.grad_views[layer.name + '/gamma'].data_ptr() if direct else None,
-            _lib.ptr(amask), ws.data_ptr(), ws.numel(), _lib.stream()), 'se3ds_norm_bwd_stats')
+        if fused is not None and g == 1 and fused[0].shape[2] == c:
+          # the statistics came out of the data-gradient epilogue that produced dy
+          rows = fused[0].shape[0]
+          rws = ctx.ws('norm', L.se3ds_norm_workspace_bytes(max(1, (rows + 511) // 512), c))
+          _chk(L.se3ds_norm_reduce_rows_dst(
+              fused[0].data_ptr(), rows, c, bs.data_ptr(),
+              st.grad_views[layer.name + '/beta'].data_ptr() if direct else None,
+              st.grad_views[layer.name + '/gamma'].data_ptr() if direct else None,
+              rws.data_ptr(), rws.numel(), _lib.stream()), 'se3ds_norm_reduce_rows_dst')
+          if _NORM_DEBUG is not None:
+            _NORM_DEBUG[('fused-bwd', tuple(xd.shape), layer.kind)] = \
+                _NORM_DEBUG.get(('fused-bwd', tuple(xd.shape), layer.kind), 0) + 1
+        else:
+          _chk(L.se3ds_norm_bwd_stats(
+              dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c, mean.data_ptr(),
+              rstd.data_ptr(), act, float(alpha), bs.data_ptr(),
+              st.grad_views[layer.name + '/beta'].data_ptr() if direct else None,
+              st.grad_views[layer.name + '/gamma'].data_ptr() if direct else None,
+              _lib.ptr(amask), ws.data_ptr(), ws.numel(), _lib.stream()), 'se3ds_norm_bwd_stats')
         if not ctx.param_grads or direct:
           pass
         else:

@@ -259,3 +259,62 @@ def test_block_fwd_bwd_at_production_width(case, dtype):
   vec_tol = tol if dtype == torch.float32 else 5e-2
   bad = {k: v for k, v in e.items() if not v <= (vec_tol if is_vec.get(k, False) else tol)}
   assert not bad, bad
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c.name for c in CASES])
+def test_fused_bn_backward_statistics_match_separate_pass(case):
+  """SE3DS_FUSED_BN_BWD (opt-in: measured slower at batch 8): where a batch norm's
+  output feeds a stride-1 convolution, that convolution's data gradient takes the norm's backward
+  statistics (sum dz, sum dz * xhat) from the gradient it stores (se3ds_conv2d_dgrad_bnstats)
+  instead of a second pass over dy and x.  Same block, same inputs, switch on / off: every
+  gradient agrees to the rounding of a re-ordered fp32 sum (parameter gradients 2e-3 of their
+  class scale; input gradients one bf16 ulp of the tensor's maximum), and the fused path is
+  really taken."""
+  dtype = torch.bfloat16
+  res = {}
+  for fused in (False, True):
+    gen = torch.Generator().manual_seed(11)
+    store = nn.ParamStore()
+    mod = case.build(store)
+    store.finalize(DEV, torch.Generator().manual_seed(7))
+    _randomise(store, gen)
+    sg = nn.SpectralGroup(image_models._conv_layers_of(mod), torch.device(DEV))
+    xs = [_bf(torch.relu(torch.randn(s, generator=gen) * 0.7 + torch.randn(s[-1], generator=gen) * 0.5))
+          for s in case.shapes]
+    mask = _mask(*case.mask_shape, gen) if case.mask_shape else None
+    old = nn._FUSED_BN_BWD, nn._NORM_DEBUG
+    nn._FUSED_BN_BWD, nn._NORM_DEBUG = fused, {}
+    try:
+      ctx = nn.Ctx(DEV, dtype, training=True, record=True)
+      xv = [nn.Var(x.to(DEV).to(dtype)) for x in xs]
+      sg.power_iteration(True)
+      out, _ = case.hip(ctx, mod, xv, mask.to(DEV) if mask is not None else None)
+      if case.name.startswith('head'):
+        y_h, push = nn.head(ctx, out, 0)
+        push(_bf(torch.randn(y_h.shape, generator=gen)).to(DEV))
+      else:
+        out.grad = _bf(torch.randn(out.data.shape, generator=gen)).to(DEV).to(dtype)
+      ctx.backward()
+      sg.backward_fixup()
+      n_fused = sum(v for k, v in nn._NORM_DEBUG.items() if k[0] == 'fused-bwd')
+    finally:
+      nn._FUSED_BN_BWD, nn._NORM_DEBUG = old
+    g = {k: store.grad_views[k].float().cpu().clone() for k in store.trainable_names}
+    for i, v in enumerate(xv):
+      g[f'dx{i}'] = v.grad.float().cpu()
+    res[fused] = (g, n_fused)
+  # (the norms of the upsampling block / the decoder entry feed transposed, masked-1x1 or no convs)
+  want = 0 if case.name.startswith(('upsampling', 'upc')) else 1
+  assert res[False][1] == 0 and res[True][1] >= want, (res[True][1], res[False][1])
+  base = res[False][0]
+  vec_scale = max([float(v.abs().max()) for k, v in base.items() if v.dim() <= 1] or [1.0])
+  worst = []
+  for k, a in res[True][0].items():
+    b = base[k]
+    den = max(float(b.abs().max()), 1e-30)
+    if b.dim() <= 1:
+      den = max(den, 1e-2 * vec_scale)   # (biases in front of a norm: rounding residue, see above)
+    e = float((a - b).abs().max() / den)
+    worst.append((e, k))
+    assert e <= (8e-3 if k.startswith('dx') else 2e-3), (k, e)
+  print(f'{case.name}: {res[True][1]} norms with fused backward statistics; worst', sorted(worst)[-2:])

@@ -1,4 +1,5 @@
-# round 3: device idle time between kernels (serial schedule and default schedule)
+# round 3: device idle time between kernels (serial schedule and default schedule), then the
+# configs tests with the faster fp64 oracle
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 ulimit -c 0
@@ -11,4 +12,8 @@ for mode in serial default; do
   echo "== $mode"
   python tools/gap_analysis.py gpurun_out/prof_gap/gap_results.db 0.6 | tee gpurun_out/r3_q_gaps_$mode.log
 done
+unset SE3DS_DUAL_STREAM SE3DS_SEGMENT_OPTIMIZER
 rm -rf gpurun_out/prof_gap
+SECONDS=0
+timeout 1500 python -m pytest tests/test_configs_gpu.py tests/test_nets_gpu.py -m gpu -x -q -s --durations=8 2>&1 | grep -v "^$" | tail -40 | cut -c1-200
+echo "configs+nets elapsed $SECONDS s"

@@ -17,3 +17,14 @@ for i in range(14):
 print('wall', ' '.join(f'{t*1e3:.0f}' for t in ts))
 print('host', ' '.join(f'{t*1e3:.0f}' for t in hs))
 print('gc counts', gc.get_count(), 'peak GiB', torch.cuda.max_memory_allocated() / 2**30)
+from se3ds_amd.hipops import nn as _nn
+if _nn._NORM_DEBUG is not None:
+  import collections
+  per = collections.Counter()
+  for (name, shape, kind), cnt in _nn._NORM_DEBUG.items():
+    per[(shape, kind)] += cnt
+  print('norms with their own statistics pass, launches over 14 steps by shape:')
+  for k, v in sorted(per.items(), key=lambda kv: -kv[1])[:20]:
+    print(' ', v, k)
+  for (name, shape, kind), cnt in sorted(_nn._NORM_DEBUG.items(), key=lambda kv: -kv[1])[:40]:
+    print('   ', cnt, name, shape, kind)
