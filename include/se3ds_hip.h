@@ -393,6 +393,19 @@ int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype
                          const float* sums, float count, int act, float alpha, void* dx,
                          void* dres, const void* act_mask, int in_act, float in_alpha,
                          void* stream);
+/* se3ds_norm_bwd_apply for a SyncBatchNormalization (one group, bf16, c % 8 == 0) whose input x
+ * is the output of a PartialConv with a bias (models/layers.py:100-209) and this norm its only
+ * consumer: dx is stored pre-scaled by out_row[row] (mask_ratio * update_mask, the multiplier of
+ * layers.py:199-204 the conv's weight / data gradients need) and colsum_dst[c] = sum over rows of
+ * the rounded dx * sum_row[row] (update_mask: the bias gradient) -- what se3ds_colsum_row_scale
+ * takes from a pass of its own over dx.  workspace: se3ds_norm_workspace_bytes(3, c).
+ * SE3DS_E_UNSUPPORTED where the fast kernel does not apply. */
+int se3ds_norm_bwd_apply_rows(const void* dy, const void* x, int dtype, int64_t r, int c,
+                              const float* mean, const float* rstd, const float* gamma,
+                              const float* sums, float count, int act, float alpha, void* dx,
+                              void* dres, const void* act_mask, const float* sum_row,
+                              const float* out_row, float* colsum_dst, void* workspace,
+                              size_t workspace_bytes, void* stream);
 /* inference-mode backward: dx = dpre*scale; dres = dpre. */
 int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r, int c,
                      const float* scale, int act, float alpha, void* dx, void* dres,

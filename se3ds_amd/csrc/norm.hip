@@ -545,22 +545,36 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
 // every load separately -- 41 us for a 17 MB tensor where the forward apply takes 10 us (ISA:
 // tools/isa_scan.py; measured with tools/norm_bwd_apply_probe.py).  Here the row loop is
 // branch-free and two rows are in flight.  ACT != 0 requires the activation bit mask.
-template <int ACT, int IN_ACT>
+// ROWS (batch norm, one group; x is the output of a PARTIAL convolution with a bias and this norm
+// its only consumer): the kernel hands that convolution's backward pass what it would otherwise
+// take from a pass of its own over dx (se3ds_colsum_row_scale, ~144 launches per step):
+//   dx is stored PRE-SCALED by out_row[row] (ratio * update_mask: the operand of the partial
+//   conv's weight / data gradients), computed from the bf16-rounded dx as that pass would;
+//   colpart[blockIdx.x][2][C] (second row zero: the layout of the statistics partials, so the
+//   same final reduction applies) = column sums of rounded dx * sum_row[row] -- the bias gradient.
+template <int ACT, int IN_ACT, bool ROWS = false>
 __global__ void __launch_bounds__(256)
 norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                            const float* __restrict__ mean, const float* __restrict__ rstd,
                            const float* __restrict__ gamma, const float* __restrict__ sums,
                            float count, int64_t R, int C, int cx, int ry, float alpha,
                            uint16_t* __restrict__ dx, uint16_t* __restrict__ dres,
-                           const uint8_t* __restrict__ amask, float in_alpha) {
+                           const uint8_t* __restrict__ amask, float in_alpha,
+                           const float* __restrict__ sum_row = nullptr,
+                           const float* __restrict__ out_row = nullptr,
+                           float* __restrict__ colpart = nullptr) {
   typedef uint16_t T;
   constexpr int VEC = 8;
   const int g = blockIdx.z;
   const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
   const int c0 = (blockIdx.y * cx + tx) * VEC;
-  if (c0 >= C) return;
+  if (!ROWS && c0 >= C) return;
+  const bool live = c0 < C;
+  float bsum[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) bsum[e] = 0.f;
   float gr[VEC], k1[VEC], c0k[VEC];
-  {
+  if (live) {
     const int64_t gc = (int64_t)g * C + c0;
     float mu[VEC], rs[VEC], gm[VEC], s0[VEC], s1[VEC];
     VT<float>::load(mean + gc, reinterpret_cast<float(&)[4]>(mu[0]));
@@ -582,7 +596,7 @@ norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __re
     }
   }
   const int64_t stride = (int64_t)gridDim.x * ry;
-  for (int64_t r = (int64_t)blockIdx.x * ry + ty; r < R; r += 2 * stride) {
+  for (int64_t r = (int64_t)blockIdx.x * ry + ty; live && r < R; r += 2 * stride) {
     const bool two = r + stride < R;
     const int64_t off0 = ((int64_t)g * R + r) * C + c0;
     const int64_t off1 = two ? off0 + stride * C : off0;
@@ -592,6 +606,11 @@ norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __re
     const uint4 qd1 = ld16(dy + off1), qx1 = ld16(x + off1);
     if (ACT != 0) m0 = amask[off0 >> 3];
     if (ACT != 0) m1 = amask[off1 >> 3];
+    float sr0 = 1.f, or0 = 1.f, sr1 = 1.f, or1 = 1.f;
+    if (ROWS) {
+      const int64_t r1 = two ? r + stride : r;
+      sr0 = sum_row[r]; or0 = out_row[r]; sr1 = sum_row[r1]; or1 = out_row[r1];
+    }
     __builtin_amdgcn_sched_barrier(0);   // all six loads are issued before the first use
     unpack8(qd0, d0); unpack8(qx0, x0); unpack8(qd1, d1); unpack8(qx1, x1);
 #pragma unroll
@@ -601,6 +620,11 @@ norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __re
       float v = fmaf(gr[e], d0[e], fmaf(-k1[e], x0[e], c0k[e]));
       if (IN_ACT == 1) v = x0[e] > 0.0f ? v : 0.0f;
       if (IN_ACT == 2) v = x0[e] > 0.0f ? v : v * in_alpha;
+      if (ROWS) {
+        const float vr = bf16_to_f32(f32_to_bf16(v));   // what a pass over the stored dx reads
+        bsum[e] += vr * sr0;
+        v = vr * or0;
+      }
       o[e] = v;
     }
     VT<T>::store(dx + off0, o);
@@ -613,10 +637,32 @@ norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __re
         float v = fmaf(gr[e], d1[e], fmaf(-k1[e], x1[e], c0k[e]));
         if (IN_ACT == 1) v = x1[e] > 0.0f ? v : 0.0f;
         if (IN_ACT == 2) v = x1[e] > 0.0f ? v : v * in_alpha;
+        if (ROWS) {
+          const float vr = bf16_to_f32(f32_to_bf16(v));
+          bsum[e] += vr * sr1;
+          v = vr * or1;
+        }
         o[e] = v;
       }
       VT<T>::store(dx + off1, o);
       if (dres) VT<T>::store(dres + off1, d1);
+    }
+  }
+  if (ROWS) {
+    __shared__ float red[256 * VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = bsum[e];
+    __syncthreads();
+    if (ty == 0 && live) {
+      const int ny = 256 / cx;
+      float* row = colpart + (int64_t)blockIdx.x * 2 * C + c0;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float t = 0.f;
+        for (int q = 0; q < ny; ++q) t += red[(q * cx + tx) * VEC + e];
+        row[e] = t;
+        row[C + e] = 0.f;
+      }
     }
   }
 }
@@ -927,6 +973,42 @@ int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype
   }
 #undef LAUNCH_BWD
   return check_launch("norm_bwd_apply");
+}
+
+// se3ds_norm_bwd_apply for a batch norm (one group, bf16, c % 8 == 0) whose input x is the output
+// of a partial convolution with a bias (and this norm its only consumer): dx is stored pre-scaled
+// by out_row[row] and colsum_dst[c] = sum over rows of rounded dx * sum_row[row] (the bias
+// gradient) -- what se3ds_colsum_row_scale would take from its own pass over dx.
+// workspace: se3ds_norm_workspace_bytes(3, c).  SE3DS_E_UNSUPPORTED where the fast kernel does not
+// apply (the caller then takes se3ds_norm_bwd_apply and leaves the rest to the convolution).
+int se3ds_norm_bwd_apply_rows(const void* dy, const void* x, int dtype, int64_t r, int c,
+                              const float* mean, const float* rstd, const float* gamma,
+                              const float* sums, float count, int act, float alpha, void* dx,
+                              void* dres, const void* act_mask, const float* sum_row,
+                              const float* out_row, float* colsum_dst, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (r <= 0 || c <= 0) return SE3DS_E_BADSHAPE;
+  if (dtype != SE3DS_BF16 || colsum_dst == nullptr || gamma == nullptr || sum_row == nullptr ||
+      out_row == nullptr)
+    return SE3DS_E_UNSUPPORTED;
+  Layout2D l = make_layout(c, 8);
+  if (!(l.vec > 1 && (act == 0 || act_mask != nullptr) && act >= 0 && act <= 2))
+    return SE3DS_E_UNSUPPORTED;
+  hipStream_t s = as_stream(stream);
+  const dim3 grid = ew_grid(l, r, 1);
+  if (workspace_bytes < sizeof(float) * ((size_t)grid.x * 2 * c + 2 * (size_t)c))
+    return SE3DS_E_WORKSPACE;
+  float* part = (float*)workspace;
+  float* scratch_sums = part + (size_t)grid.x * 2 * c;   // [2][c], discarded
+#define LAUNCH_ROWS(A)                                                                           \
+  hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<A, 0, true>), grid, dim3(256), 0, s,            \
+                     (const uint16_t*)dy, (const uint16_t*)x, mean, rstd, gamma, sums, count, r, \
+                     c, l.cx, l.ry, alpha, (uint16_t*)dx, (uint16_t*)dres,                        \
+                     (const uint8_t*)act_mask, 0.0f, sum_row, out_row, part)
+  if (act == 0) LAUNCH_ROWS(0); else if (act == 1) LAUNCH_ROWS(1); else LAUNCH_ROWS(2);
+#undef LAUNCH_ROWS
+  launch_final_reduce(s, part, (int)grid.x, c, 1, scratch_sums, colsum_dst, nullptr);
+  return check_launch("norm_bwd_apply_rows");
 }
 
 int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r, int c,

@@ -189,7 +189,7 @@ def truncated_normal_init(shape, gen, std=0.05):
 class Var:
   """Activation handle: NHWC tensor in the compute dtype plus its (lazy) gradient."""
   __slots__ = ('data', '_grad', 'gver', 'requires_grad', 'col_stats', 'grad_pre_act', 'shared',
-               'grad_ev', 'bn_src', 'bn_stats')
+               'grad_ev', 'bn_src', 'bn_stats', 'row_sink', 'grad_scaled')
 
   def __init__(self, data, requires_grad=True):
     self.data = data
@@ -198,6 +198,10 @@ class Var:
     self.bn_src = None      # batch-norm outputs: (x, act mask, mean, rstd, act, alpha) of the norm
     self.bn_stats = None    # ... (stats rows, gver): backward statistics a data-gradient epilogue
                             # took from the gradient it stored (valid while gver is unchanged)
+    self.row_sink = None    # outputs of biased partial convs: (out row scale, bias row scale,
+                            # store, bias name) -- a batch norm that is the only consumer stores
+                            # its dx pre-scaled and writes the bias gradient (norm_bwd_apply_rows)
+    self.grad_scaled = None   # ... gver at which it did
     self.requires_grad = requires_grad
     self.col_stats = None   # conv outputs: partial column sums for a following batch norm
     self.grad_pre_act = False   # the consumer already applied this tensor's activation derivative
@@ -997,9 +1001,14 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
     ctx.act_taps[layer.name] = y
   if stats is not None:
     out.col_stats = stats   # [rows][2][cout] partial (sum, sum of squares) of y
+  if (recording and partial and bias is not None and ctx.binary_masks and act == ACT_NONE and
+      layer.cout % 8 == 0 and xd.dtype == torch.bfloat16):
+    out.row_sink = (ru, bu, layer.store, layer.name + '/bias')
   if recording:
     def bwd(n=n):
       dy = out.grad
+      pre_scaled = out.grad_scaled is not None and out.grad_scaled == out.gver
+      out.grad_scaled = None
       out.grad = None
       if dy is None:
         return
@@ -1018,7 +1027,11 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
       dys = dy
       st = layer.store
       bias_done = False
-      if partial:
+      if partial and pre_scaled:
+        # the batch norm behind this conv stored its dx already multiplied by ratio * update_mask
+        # and wrote the bias gradient (se3ds_norm_bwd_apply_rows): no pass over dy here
+        bias_done = True
+      elif partial:
         row_scale = ru if bias is not None else ratio
         if ctx.binary_masks:
           # pre-scale dy once so that wgrad / dgrad can take the LDS-DMA kernels
@@ -1198,6 +1211,11 @@ _NORM_DEBUG = {} if os.environ.get('SE3DS_NORM_DEBUG') else None
 # every workgroup's epilogue -- data gradient 887 -> 768 TFLOP/s, +8.5 ms -- to save a streaming
 # pass that costs 5.7 ms).  Kept, tested, for larger batches / tensors.
 _FUSED_BN_BWD = os.environ.get('SE3DS_FUSED_BN_BWD', '0') == '1'
+# SE3DS_FUSED_ROW_SCALE=0: the backward pass of a biased partial conv always takes dy * (ratio *
+# update_mask) and its bias gradient from a pass of its own over dy (se3ds_colsum_row_scale);
+# default: the batch norm in front of it (in backward order) stores its dx pre-scaled and writes
+# the bias gradient from the same kernel (se3ds_norm_bwd_apply_rows)
+_FUSED_ROW_SCALE = os.environ.get('SE3DS_FUSED_ROW_SCALE', '1') != '0'
 
 
 def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: Var = None,
@@ -1351,15 +1369,38 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
           st.grad_views[layer.name + '/gamma'].copy_(tot[0, 0, c:])
 
         def finish():
-          _chk(L.se3ds_norm_bwd_apply(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r, c,
-                                      mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                                      bs.data_ptr(), count, act, float(alpha), dx.data_ptr(),
-                                      _lib.ptr(dres), _lib.ptr(amask),
-                                      in_act[0] if in_act else 0, float(in_act[1]) if in_act else 0.0,
-                                      _lib.stream()), 'se3ds_norm_bwd_apply')
+          sink = x.row_sink
+          rows_done = False
+          if (sink is not None and _FUSED_ROW_SCALE and ctx.param_grads and g == 1 and not in_act and
+              x.grad is None and lim is None and xd.dtype == torch.bfloat16):
+            # x is the output of a biased partial conv and this norm (so far) its only consumer:
+            # store dx pre-scaled for that conv's backward pass and write its bias gradient here
+            cws = ctx.ws('norm_rows', L.se3ds_norm_workspace_bytes(3, c))
+            rc = L.se3ds_norm_bwd_apply_rows(
+                dy.data_ptr(), xd.data_ptr(), ctx.code, r, c, mean.data_ptr(), rstd.data_ptr(),
+                gamma.data_ptr(), bs.data_ptr(), count, act, float(alpha), dx.data_ptr(),
+                _lib.ptr(dres), _lib.ptr(amask), sink[1].data_ptr(), sink[0].data_ptr(),
+                sink[2].grad_views[sink[3]].data_ptr(), cws.data_ptr(), cws.numel(), _lib.stream())
+            if rc == 0:
+              rows_done = True
+              if _NORM_DEBUG is not None:
+                _NORM_DEBUG[('fused-rows', tuple(xd.shape), layer.kind)] = \
+                    _NORM_DEBUG.get(('fused-rows', tuple(xd.shape), layer.kind), 0) + 1
+            elif rc not in (-5, -3):   # SE3DS_E_UNSUPPORTED / SE3DS_E_WORKSPACE: separate passes
+              _chk(rc, 'se3ds_norm_bwd_apply_rows')
+          if not rows_done:
+            _chk(L.se3ds_norm_bwd_apply(dy.data_ptr(), y.data_ptr(), xd.data_ptr(), ctx.code, g, r,
+                                        c, mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                        bs.data_ptr(), count, act, float(alpha), dx.data_ptr(),
+                                        _lib.ptr(dres), _lib.ptr(amask),
+                                        in_act[0] if in_act else 0,
+                                        float(in_act[1]) if in_act else 0.0,
+                                        _lib.stream()), 'se3ds_norm_bwd_apply')
           if in_act:
             x.grad_pre_act = True
           accumulate(x, dx)
+          if rows_done:
+            x.grad_scaled = x.gver
           if want_res:
             accumulate(res, dres)
         if sync_bwd:

@@ -262,17 +262,23 @@ def test_block_fwd_bwd_at_production_width(case, dtype):
 
 
 @pytest.mark.parametrize('case', CASES, ids=[c.name for c in CASES])
-def test_fused_bn_backward_statistics_match_separate_pass(case):
-  """SE3DS_FUSED_BN_BWD (opt-in: measured slower at batch 8): where a batch norm's
-  output feeds a stride-1 convolution, that convolution's data gradient takes the norm's backward
-  statistics (sum dz, sum dz * xhat) from the gradient it stores (se3ds_conv2d_dgrad_bnstats)
-  instead of a second pass over dy and x.  Same block, same inputs, switch on / off: every
-  gradient agrees to the rounding of a re-ordered fp32 sum (parameter gradients 2e-3 of their
-  class scale; input gradients one bf16 ulp of the tensor's maximum), and the fused path is
-  really taken."""
+def test_fused_backward_passes_match_separate_passes(case):
+  """Round 3, two fusions of per-row / per-channel work into kernels that stream the data anyway:
+  (a) SE3DS_FUSED_ROW_SCALE (default on): the batch norm behind a biased PARTIAL conv stores its dx
+      already multiplied by ratio * update_mask and writes that conv's bias gradient
+      (se3ds_norm_bwd_apply_rows) -- instead of the conv's own pass over dx
+      (se3ds_colsum_row_scale, ~144 launches per step);
+  (b) SE3DS_FUSED_BN_BWD (opt-in: measured slower at batch 8): where a batch norm's
+      output feeds a stride-1 convolution, that convolution's data gradient takes the norm's
+      backward statistics (sum dz, sum dz * xhat) from the gradient it stores
+      (se3ds_conv2d_dgrad_bnstats) instead of a second pass over dy and x.
+  Same block, same inputs, each switch against both off: (a) is bit-identical except for the bias
+  gradient (a re-ordered fp32 sum); (b) agrees to the rounding of re-ordered fp32 sums (parameter
+  gradients 2e-3 of their class scale, input gradients one bf16 ulp of the tensor's maximum); and
+  the fused paths are really taken."""
   dtype = torch.bfloat16
   res = {}
-  for fused in (False, True):
+  for cfg in ('plain', 'rows', 'bn_bwd'):
     gen = torch.Generator().manual_seed(11)
     store = nn.ParamStore()
     mod = case.build(store)
@@ -282,8 +288,8 @@ def test_fused_bn_backward_statistics_match_separate_pass(case):
     xs = [_bf(torch.relu(torch.randn(s, generator=gen) * 0.7 + torch.randn(s[-1], generator=gen) * 0.5))
           for s in case.shapes]
     mask = _mask(*case.mask_shape, gen) if case.mask_shape else None
-    old = nn._FUSED_BN_BWD, nn._NORM_DEBUG
-    nn._FUSED_BN_BWD, nn._NORM_DEBUG = fused, {}
+    old = nn._FUSED_BN_BWD, nn._FUSED_ROW_SCALE, nn._NORM_DEBUG
+    nn._FUSED_BN_BWD, nn._FUSED_ROW_SCALE, nn._NORM_DEBUG = cfg == 'bn_bwd', cfg == 'rows', {}
     try:
       ctx = nn.Ctx(DEV, dtype, training=True, record=True)
       xv = [nn.Var(x.to(DEV).to(dtype)) for x in xs]
@@ -296,25 +302,33 @@ def test_fused_bn_backward_statistics_match_separate_pass(case):
         out.grad = _bf(torch.randn(out.data.shape, generator=gen)).to(DEV).to(dtype)
       ctx.backward()
       sg.backward_fixup()
-      n_fused = sum(v for k, v in nn._NORM_DEBUG.items() if k[0] == 'fused-bwd')
+      counts = {t: sum(v for k, v in nn._NORM_DEBUG.items() if k[0] == t)
+                for t in ('fused-bwd', 'fused-rows')}
     finally:
-      nn._FUSED_BN_BWD, nn._NORM_DEBUG = old
+      nn._FUSED_BN_BWD, nn._FUSED_ROW_SCALE, nn._NORM_DEBUG = old
     g = {k: store.grad_views[k].float().cpu().clone() for k in store.trainable_names}
     for i, v in enumerate(xv):
       g[f'dx{i}'] = v.grad.float().cpu()
-    res[fused] = (g, n_fused)
-  # (the norms of the upsampling block / the decoder entry feed transposed, masked-1x1 or no convs)
-  want = 0 if case.name.startswith(('upsampling', 'upc')) else 1
-  assert res[False][1] == 0 and res[True][1] >= want, (res[True][1], res[False][1])
-  base = res[False][0]
+    res[cfg] = (g, counts)
+  assert res['plain'][1] == {'fused-bwd': 0, 'fused-rows': 0}, res['plain'][1]
+  # by construction: the bottleneck has biased partial convs in front of norms and norms in front
+  # of stride-1 convs; the norms of the upsampling block / decoder entry feed transposed or no convs
+  assert res['rows'][1]['fused-rows'] >= (1 if case.name.startswith('bottleneck') else 0), res['rows'][1]
+  assert res['bn_bwd'][1]['fused-bwd'] >= (0 if case.name.startswith(('upsampling', 'upc')) else 1), \
+      res['bn_bwd'][1]
+  base = res['plain'][0]
   vec_scale = max([float(v.abs().max()) for k, v in base.items() if v.dim() <= 1] or [1.0])
-  worst = []
-  for k, a in res[True][0].items():
-    b = base[k]
-    den = max(float(b.abs().max()), 1e-30)
-    if b.dim() <= 1:
-      den = max(den, 1e-2 * vec_scale)   # (biases in front of a norm: rounding residue, see above)
-    e = float((a - b).abs().max() / den)
-    worst.append((e, k))
-    assert e <= (8e-3 if k.startswith('dx') else 2e-3), (k, e)
-  print(f'{case.name}: {res[True][1]} norms with fused backward statistics; worst', sorted(worst)[-2:])
+  for cfg in ('rows', 'bn_bwd'):
+    worst = []
+    for k, a in res[cfg][0].items():
+      b = base[k]
+      if cfg == 'rows' and not k.endswith('/bias'):
+        assert torch.equal(a, b), (cfg, k)   # same values through a different kernel
+        continue
+      den = max(float(b.abs().max()), 1e-30)
+      if b.dim() <= 1:
+        den = max(den, 1e-2 * vec_scale)   # (biases in front of a norm: rounding residue, see above)
+      e = float((a - b).abs().max() / den)
+      worst.append((e, k))
+      assert e <= (8e-3 if k.startswith('dx') else 2e-3), (cfg, k, e)
+    print(f'{case.name} [{cfg}]: {res[cfg][1]}; worst', sorted(worst)[-2:])
