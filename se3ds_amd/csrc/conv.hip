@@ -54,10 +54,6 @@ template <> struct TT<uint16_t> {  // bf16 raw bits
   static __device__ __forceinline__ uint16_t from_f(float v) { return f32_to_bf16(v); }
 };
 
-#ifndef SE3DS_HALO128_QP4
-#define SE3DS_HALO128_QP4 0
-#endif
-
 struct IgemmParams {
   // source tensor of the gather (x for FWD, dy for DGRAD) and its dims
   const void* src; int sH, sW, sC;
@@ -1132,10 +1128,14 @@ igemm_halo_kernel(const IgemmParams p) {
   constexpr int XBUF = XPIECES * 8 * ROW2;
   constexpr int WT = CO * ROW2;
   constexpr int NI = CO / 64, WS = CO / 64;
-  // phases per K step: NP read / MFMA slot pairs of QP 16-channel fragments each.  256 channels:
-  // 4 x 1 (16 MFMAs per slot); 128 channels: 2 x 2 (8 MFMAs per slot), or with
-  // SE3DS_HALO128_QP4 one slot pair of 16 MFMAs -- half the barriers per K step
-  constexpr int QP = (NI == 2 && SE3DS_HALO128_QP4) ? 4 : 8 / (2 * NI), NP = 4 / QP;
+  // phases per K step: NP read / MFMA slot pairs of QP 16-channel fragments each (8 MFMAs per
+  // slot and wave).  One 16-MFMA slot pair per K step for the 128-channel tile (half the
+  // barriers) was measured and changed nothing: 761 / 799 vs 769 / 782 TFLOP/s forward / data
+  // gradient on 3x3 128 -> 128 @512x1024 -- barriers are not what holds that tile at 0.36-0.40
+  // MFMA-busy (its fragment reads book ~50 % of the 256 B/clk LDS pipe, one 1 KiB read per MFMA
+  // against 0.75 for the 256-channel tile; the tap-fused weight gradient of the same layer,
+  // with 1.2 half-size reads per MFMA and no activation-sized output, runs at 1 190 TFLOP/s).
+  constexpr int QP = 8 / (2 * NI), NP = 4 / QP;
   constexpr int DIST = WST - 1;   // weight tiles are fetched DIST K steps ahead
   static_assert(WST == 2 || WST == 3, "weight stages");
   __shared__ __attribute__((aligned(16))) unsigned char wst0[WT];
@@ -1307,11 +1307,11 @@ igemm_halo_kernel(const IgemmParams p) {
         issue_w(wnxt, 2 * ph, wfar, ntap, nslab, has_next);
         issue_w(wnxt, 2 * ph + 1, wfar, ntap, nslab, has_next);
       }
-      if (NP <= 2 && ph == 0) {
+      if (NP == 2 && ph == 0) {
         issue_w(wnxt, 0, wfar, ntap, nslab, has_next);
         issue_w(wnxt, 1, wfar, ntap, nslab, has_next);
       }
-      if (ph == (NP == 4 ? 2 : NP - 1)) issue_x(xnxt, xsl, xfar, xfm, xslab, x_piece);
+      if (ph == NP - 2 + (NP == 2)) issue_x(xnxt, xsl, xfar, xfm, xslab, x_piece);
       if (ph == NP - 1) {
         // the weight tile of the NEXT K step must have landed; younger DMA stays in flight:
         // this K step's patch piece and, with three weight stages, this K step's weight pieces
