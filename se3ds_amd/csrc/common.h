@@ -37,11 +37,19 @@ inline int grid_for(int64_t work_items, int block) {
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round to nearest even, NaN -> quiet NaN); the
+// integer formulation it replaces cost ~9 VALU instructions per element, which made the conv
+// epilogues VALU-bound (3x3 128 -> 128 @512x1024: epilogue 27 % of the kernel, its global stores
+// 2 % -- measured with the stores / the epilogue / the MFMAs compiled out).
+typedef float se3ds_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 se3ds_bf16x2 __attribute__((ext_vector_type(2)));
+// (a, b) -> a in the low half, b in the high half
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b) {
+  const se3ds_f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, se3ds_bf16x2));
+}
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+  return (uint16_t)(pack2_bf16(f, f) & 0xffffu);
 }
 
 // 64-lane wave reductions (DPP/shuffle based)
@@ -96,7 +104,7 @@ template <> struct VT<uint16_t> {
     uint32_t q[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      q[e] = (uint32_t)f32_to_bf16(o[2 * e]) | ((uint32_t)f32_to_bf16(o[2 * e + 1]) << 16);
+      q[e] = pack2_bf16(o[2 * e], o[2 * e + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(q[0], q[1], q[2], q[3]);
   }
   static __device__ __forceinline__ float ld1(const uint16_t* p) { return bf16_to_f32(*p); }

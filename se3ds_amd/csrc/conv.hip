@@ -202,8 +202,8 @@ __device__ __forceinline__ void store_pixel(const IgemmParams& p, f32x16_t (&acc
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           uint2 pk;
-          pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-          pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+          pk.x = pack2_bf16(v[0], v[1]);
+          pk.y = pack2_bf16(v[2], v[3]);
           *reinterpret_cast<uint2*>(o) = pk;
         }
       } else {
@@ -293,8 +293,8 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
               v[e] = t > 0.f ? t : t * slope;
             }
             uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            pk.x = pack2_bf16(v[0], v[1]);
+            pk.y = pack2_bf16(v[2], v[3]);
             if (o < 0) pk = make_uint2(0u, 0u);   // (keeps the column sums clean)
             if (mine)
               *reinterpret_cast<uint2*>(scratch + lp * RB + (i * 32 + g * 8 + half * 4) * 2) = pk;
@@ -332,7 +332,7 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
             for (int q = 0; q < 4; ++q) {
               const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
               const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
-              vw[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+              vw[q] = pack2_bf16(lo, hi);
             }
           }
           *reinterpret_cast<uint4*>(out + po * p.oC + co_base + c16 * 8) = v;
@@ -570,7 +570,7 @@ igemm_kernel(const IgemmParams p) {
               for (int e = 0; e < 4; ++e) {
                 float lo = __uint_as_float(q[e] << 16) * mk;
                 float hi = __uint_as_float(q[e] & 0xffff0000u) * mk;
-                q[e] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+                q[e] = pack2_bf16(lo, hi);
               }
             }
           }
@@ -2778,7 +2778,7 @@ thin_cin_wgrad_kernel(const ThinCinWgradParams p) {
             for (int q = 0; q < 4; ++q) {
               const float lo = __uint_as_float(w[q] << 16) * rs;
               const float hi = __uint_as_float(w[q] & 0xffff0000u) * rs;
-              w[q] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+              w[q] = pack2_bf16(lo, hi);
             }
           }
         }

@@ -1105,3 +1105,26 @@ def test_scheduling_switches_are_bit_identical():
                      env=env, cwd=root, capture_output=True, text=True, timeout=900)
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
   assert r.stdout.count('IDENTICAL to serial') == 8, r.stdout[-2000:]
+
+
+def test_bf16_conversion_is_round_to_nearest_even():
+  """fp32 -> bf16 goes through gfx950's v_cvt_pk_bf16_f32 (csrc/common.h pack2_bf16; the integer
+  formulation it replaced made the conv epilogues VALU-bound): bit-identical to round-to-nearest-
+  even on ties, denormals, infinities and a million random values; NaN stays NaN."""
+  g = torch.Generator().manual_seed(1)
+  one = torch.tensor([1.0]).view(torch.int32)
+  ties = (one + torch.tensor([0x8000, 0x18000, 0x7fff, 0x8001, 0x17fff, 0x18001], dtype=torch.int32)).view(torch.float32)
+  special = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.38e38, -3.38e38, 3.4028235e38, float('inf'), -float('inf'),
+                          1e-40, -1e-40, 1.1754944e-38, 1.1754942e-38, 9.2e-41, 65504.0, 1e-45])
+  rnd = torch.randn(1 << 20, generator=g) * torch.exp(torch.randn(1 << 20, generator=g) * 8)
+  bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (1 << 18,), generator=g, dtype=torch.int32).view(torch.float32)
+  x = torch.cat([ties, -ties, special, rnd, bits, torch.tensor([float('nan')])])
+  x = torch.cat([x, torch.zeros((-x.numel()) % 8)]).reshape(1, 1, -1, 8)
+  ctx = nn.Ctx(DEV, torch.bfloat16)
+  got = nn.to_var(ctx, x.to(DEV)).data.cpu()
+  want = x.to(torch.bfloat16)
+  nan = torch.isnan(x)
+  assert bool(torch.isnan(got.float())[nan].all())
+  a, b = got.view(torch.int16)[~nan], want.view(torch.int16)[~nan]
+  bad = (a != b).nonzero()
+  assert bad.numel() == 0, (bad.numel(), x[~nan][bad[:5, 0]], a[bad[:5, 0]], b[bad[:5, 0]])
