@@ -735,7 +735,13 @@ inline dim3 ew_grid(const Layout2D& l, int64_t R, int G) {
 int pick_rblocks(int64_t R, int ry, int ctiles, int G) {
   // ~2048 blocks in total (8 per CU) so the streaming reads have enough waves in flight, at
   // least 4 row-iterations per thread, at most 1024 partials per column.
-  int64_t want = 2048 / ((int64_t)ctiles * G);
+  // (SE3DS_NORM_STAT_BLOCKS: A/B override of the total)
+  static const int total = [] {
+    const char* e = getenv("SE3DS_NORM_STAT_BLOCKS");
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? x : 2048;
+  }();
+  int64_t want = total / ((int64_t)ctiles * G);
   if (want < 1) want = 1;
   int64_t max_rb = ceil_div(R, (int64_t)ry * 4);
   if (max_rb < 1) max_rb = 1;
