@@ -141,30 +141,6 @@ def power_iteration(kernel, u, eps=1e-10):
   return sigma, u_hat
 
 
-class _DivBySigma(torch.autograd.Function):
-  """kernel / denom (denom a one-element tensor) with a backward pass that makes two sweeps over
-  the kernel-sized operands instead of autograd's five (g / d, and one dot product for the
-  denominator's gradient -sum(g * kernel) / d^2).  Binary64 yardstick runs only; same arithmetic
-  up to the summation order of that dot product."""
-
-  @staticmethod
-  def forward(ctx, kernel, denom):
-    ctx.save_for_backward(kernel, denom)
-    return kernel / denom
-
-  @staticmethod
-  def backward(ctx, g):
-    kernel, denom = ctx.saved_tensors
-    gd = -(torch.dot(g.reshape(-1), kernel.reshape(-1)) / (denom * denom))
-    return g / denom, gd.reshape(denom.shape)
-
-
-def div_by_sigma(kernel, denom):
-  if kernel.dtype == torch.float64 and denom.numel() == 1:
-    return _DivBySigma.apply(kernel, denom)
-  return kernel / denom
-
-
 def leaky_relu(x, alpha):
   return torch.where(x > 0, x, x * alpha)
 
@@ -268,8 +244,14 @@ class Net:
     sigma, u_hat = power_iteration(kernel, self.get(name + '/u'))
     if self.training:
       self.updates[name + '/u'] = u_hat
-    w_norm = div_by_sigma(kernel, sigma + 1e-10)
-    y = tf_conv2d(x, w_norm, stride, padding)
+    if kernel.dtype == torch.float64:
+      # binary64 yardstick runs: conv(x, W / s) = conv(x, W) / s -- the division runs over the
+      # activation instead of materialising (and keeping for the backward pass) a normalised copy
+      # of every kernel, 9 GB at the real dimensions; same value up to binary64 rounding
+      y = tf_conv2d(x, kernel, stride, padding) / (sigma + 1e-10)
+    else:
+      w_norm = kernel / (sigma + 1e-10)
+      y = tf_conv2d(x, w_norm, stride, padding)
     if self.has(name + '/bias'):
       y = y + self.get(name + '/bias')
     return y

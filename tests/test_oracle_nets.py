@@ -129,8 +129,8 @@ def test_avg_and_max_pool_same_semantics():
 
 def test_fp64_yardstick_fast_paths_equal_the_plain_formulation():
   """The binary64 runs of the oracle (yardstick of the GPU gradient tests) take a patch-matrix
-  convolution and a two-sweep spectral division; both must be the plain F.conv2d / autograd
-  division up to binary64 rounding, values and gradients."""
+  convolution and divide the spectral conv's OUTPUT by sigma instead of its kernel; both must be
+  the plain F.conv2d with the normalised kernel up to binary64 rounding, values and gradients."""
   import torch.nn.functional as F
   g = torch.Generator().manual_seed(0)
   for (k, stride, padding, h, w) in ((3, 1, 'SAME', 6, 9), (4, 2, 'SAME', 9, 12), (1, 1, 'VALID', 5, 4),
@@ -150,13 +150,25 @@ def test_fp64_yardstick_fast_paths_equal_the_plain_formulation():
     wx, wk = torch.autograd.grad((want * cot).sum(), (x, kern))
     for a, b in ((y, want), (gx, wx), (gk, wk)):
       assert float((a - b).abs().max()) <= 1e-13 * float(b.abs().max()), (k, stride, padding)
-  kern = torch.randn((3, 3, 4, 6), generator=g, dtype=torch.float64, requires_grad=True)
-  sig = torch.tensor([[1.7]], dtype=torch.float64, requires_grad=True)
-  cot = torch.randn(kern.shape, generator=g, dtype=torch.float64)
-  a = torch.autograd.grad((O.div_by_sigma(kern, sig + 1e-10) * cot).sum(), (kern, sig))
-  b = torch.autograd.grad(((kern / (sig + 1e-10)) * cot).sum(), (kern, sig))
-  for u, v in zip(a, b):
-    assert u.shape == v.shape and float((u - v).abs().max()) <= 1e-14 * float(v.abs().max())
-  # fp32 keeps the plain path (its rounding order is what the GPU results are compared with)
-  k32 = kern.detach().float().requires_grad_(True)
-  assert O.div_by_sigma(k32, sig.detach().float()).grad_fn.name().startswith('DivBackward')
+  # spectral conv: conv(x, W / sigma) (fp32 path, plain) == conv(x, W) / sigma (binary64 path)
+  p64 = {'c/kernel': torch.randn((3, 3, 4, 6), generator=g, dtype=torch.float64),
+         'c/u': torch.randn((1, 6), generator=g, dtype=torch.float64),
+         'c/bias': torch.randn((6,), generator=g, dtype=torch.float64)}
+  x0 = torch.randn((2, 7, 5, 4), generator=g, dtype=torch.float64)
+  cot = torch.randn((2, 7, 5, 6), generator=g, dtype=torch.float64)
+  outs = []
+  for plain in (False, True):
+    p = {k: v.clone().requires_grad_(k != 'c/u') for k, v in p64.items()}
+    x = x0.clone().requires_grad_(True)
+    net = O.Net(p, training=True)
+    if plain:
+      sigma, _ = O.power_iteration(p['c/kernel'], p['c/u'])
+      w_n = p['c/kernel'] / (sigma + 1e-10)
+      xn = F.pad(x.permute(0, 3, 1, 2), (1, 1, 1, 1))
+      y = F.conv2d(xn, w_n.permute(3, 2, 0, 1)).permute(0, 2, 3, 1) + p['c/bias']
+    else:
+      y = net.spectral_conv(x, 'c', 1, 'SAME')
+    gx, gk, gb = torch.autograd.grad((y * cot).sum(), (x, p['c/kernel'], p['c/bias']))
+    outs.append((y.detach(), gx, gk, gb))
+  for a_, b_ in zip(*outs):
+    assert float((a_ - b_).abs().max()) <= 1e-13 * float(b_.abs().max())
