@@ -27,6 +27,10 @@ import torch
 import torch.nn.functional as F
 
 BN_EPS, BN_MOMENTUM, IN_EPS = 1e-3, 0.99, 1e-3
+# binary64 runs only: divide a spectral conv's output (True) or its kernel (False) by sigma; an
+# A/B switch for timing the yardstick runs (tools/oracle_f64_time.py)
+import os as _os
+_F64_DIV_OUTPUT = _os.environ.get('SE3DS_ORACLE_F64_DIV', 'output') == 'output'
 
 
 # ----------------------------------------------------------------------------- primitives
@@ -244,7 +248,7 @@ class Net:
     sigma, u_hat = power_iteration(kernel, self.get(name + '/u'))
     if self.training:
       self.updates[name + '/u'] = u_hat
-    if kernel.dtype == torch.float64:
+    if kernel.dtype == torch.float64 and _F64_DIV_OUTPUT:
       # binary64 yardstick runs: conv(x, W / s) = conv(x, W) / s -- the division runs over the
       # activation instead of materialising (and keeping for the backward pass) a normalised copy
       # of every kernel, 9 GB at the real dimensions; same value up to binary64 rounding
