@@ -187,7 +187,11 @@ def cpu_baseline(args, gan, tflop_per_sample, budget_s=60.0):
     cores = len(os.sched_getaffinity(0))
   except AttributeError:
     cores = os.cpu_count() or 1
-  threads = max(1, min(cores, 64))
+  # 16 threads: measured FASTEST on the GPU boxes' 2 x 64-core hosts (tools/oracle_f64_time.py:
+  # the same oracle pass takes 9.9 s on 16 threads, 26 s on 64, 75 s on 128 -- weight-sized passes
+  # and small-M products that more threads only oversubscribe); the baseline gets the setting
+  # that is best for it, `cores` reports it
+  threads = max(1, min(cores, 16))
   T.set_num_threads(threads)
   t_start = time.perf_counter()
   cpu = lambda m: {k: v.detach().cpu() for k, v in m.store.views.items()}
