@@ -1107,6 +1107,21 @@ def test_scheduling_switches_are_bit_identical():
   assert r.stdout.count('IDENTICAL to serial') == 8, r.stdout[-2000:]
 
 
+def test_default_schedule_is_bit_identical_to_serial_at_production_size():
+  """The same at the bench's own dimensions (highres.gin, 512x1024, batch 8, ResNet-101 at width
+  128): three steps of the default schedule -- two decoder streams, per-module optimiser on the
+  side stream -- against the serial order, losses and G / D / EMA / state checksums bit for bit."""
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, PYTHONPATH=root, SE3DS_CMP_CONFIGS='0:0:,1:1:')
+  env.pop('SE3DS_CMP_GIN', None)
+  r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'step_compare.py'), '512', '8', '3'],
+                     env=env, cwd=root, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+  assert r.stdout.count('IDENTICAL to serial') == 2, r.stdout[-2000:]
+
+
 def test_bf16_conversion_is_round_to_nearest_even():
   """fp32 -> bf16 goes through gfx950's v_cvt_pk_bf16_f32 (csrc/common.h pack2_bf16; the integer
   formulation it replaced made the conv epilogues VALU-bound): bit-identical to round-to-nearest-

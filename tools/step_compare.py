@@ -36,6 +36,8 @@ if len(sys.argv) > 1 and sys.argv[1] == '--worker':
 size, batch, steps = (sys.argv[1:] + ['128', '2', '4'])[:3]
 configs = [('0', '0', ''), ('0', '1', ''), ('1', '0', ''), ('1', '1', ''), ('1', '0', 'fwd'), ('1', '0', 'bwd'),
            ('1', '1', 'nowg'), ('1', '0', 'nowg')]   # 'nowg' rows: WITH the opt-in wgrad stream
+if os.environ.get('SE3DS_CMP_CONFIGS'):   # e.g. '0:0:,1:1:' -- a subset (the serial order must be in it)
+  configs = [tuple(c.split(':')) for c in os.environ['SE3DS_CMP_CONFIGS'].split(',')]
 out = {}
 for ds, so, ph in configs:
   env = dict(os.environ, SE3DS_DUAL_STREAM=ds, SE3DS_SEGMENT_OPTIMIZER=so,
