@@ -465,12 +465,12 @@ def patch_discriminator(net, x, name, n_layers, kernel_size=4):
   k = kernel_size
   results = []
   out = net.conv2d(pad_layer(x, k // 2), name + '/g0/conv', 2, 'VALID')
-  out = leaky_relu(out, 0.2)
+  out = net.act(out, name + '/g0/conv', 0.2)   # (LeakyReLU 0.2; tags: see Net.decisions)
   results.append(out)
   for i in range(1, n_layers):
     out = net.spectral_conv(pad_layer(out, k // 2), name + f'/g{i}/conv',
                             2 if i != n_layers - 1 else 1, 'VALID')
-    out = leaky_relu(net.instance_norm(out, name + f'/g{i}/in'), 0.2)
+    out = net.act(net.instance_norm(out, name + f'/g{i}/in'), name + f'/g{i}/in', 0.2)
     results.append(out)
   out = net.conv2d(out, name + '/final', 1, 'SAME')
   results.append(out)

@@ -17,6 +17,8 @@ Blocks (reference lines; widths and map sizes are those of highres.gin at 512 x 
                                       ConvT k2 s2 residual (32x64 -> 64x128)
   upc + agent4, agent3 + add   image_models.py:351-441,455-462
   head             image_models.py:79-104  128 -> 128 -> 128 -> 3 at 128x256, then (tanh+1)/2
+  patch discriminator  image_models.py:492-561  one scale of the discriminator, dis_dims 128 x 6
+                                      layers, on a 256x512 RGB-D input (input gradient included)
 
 ReLU / LeakyReLU derivatives are sign DECISIONS: two correct evaluations of a pre-activation
 differ by ~1e-6 relative (fp32), so on a 4 M-element tensor one or two elements straddle zero and
@@ -155,8 +157,21 @@ def _head_case():
   return _Case('head_rgb_128', [(2, 128, 256, 128)], None, build, hip, ref, 2)
 
 
+def _patch_discriminator_case():
+  # one scale of the multi-scale PatchGAN discriminator at highres.gin's width and depth
+  # (dis_dims 128, 6 layers: 4x4 stride-2 convs 4 -> 128 -> 256 -> 512 -> 512, a stride-1 512, the
+  # 1-channel logits; spectral norm, InstanceNorm, LeakyReLU 0.2) on the second scale's input
+  def build(store):
+    return image_models.SNPatchDiscriminator(store, 'dis0', 4, 4, 128, 6, False)
+  def hip(ctx, mod, xs, mask):
+    return mod(ctx, xs[0])[-1], None
+  def ref(net, xs, mask):
+    return O.patch_discriminator(net, xs[0], 'dis0', 6)[-1], None
+  return _Case('patch_discriminator_128x6', [(2, 256, 512, 4)], None, build, hip, ref, 6)
+
+
 CASES = [_bottleneck_case(), _trans_block_case(), _upsampling_block_case(), _upc_agents_case(),
-         _head_case()]
+         _head_case(), _patch_discriminator_case()]
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
@@ -312,9 +327,10 @@ def test_fused_backward_passes_match_separate_passes(case):
     res[cfg] = (g, counts)
   assert res['plain'][1] == {'fused-bwd': 0, 'fused-rows': 0}, res['plain'][1]
   # by construction: the bottleneck has biased partial convs in front of norms and norms in front
-  # of stride-1 convs; the norms of the upsampling block / decoder entry feed transposed or no convs
+  # of stride-1 convs; the norms of the upsampling block / decoder entry feed transposed or no convs,
+  # the discriminator has instance norms only
   assert res['rows'][1]['fused-rows'] >= (1 if case.name.startswith('bottleneck') else 0), res['rows'][1]
-  assert res['bn_bwd'][1]['fused-bwd'] >= (0 if case.name.startswith(('upsampling', 'upc')) else 1), \
+  assert res['bn_bwd'][1]['fused-bwd'] >= (0 if case.name.startswith(('upsampling', 'upc', 'patch')) else 1), \
       res['bn_bwd'][1]
   base = res['plain'][0]
   vec_scale = max([float(v.abs().max()) for k, v in base.items() if v.dim() <= 1] or [1.0])
