@@ -1008,6 +1008,11 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
     def bwd(n=n):
       dy = out.grad
       pre_scaled = out.grad_scaled is not None and out.grad_scaled == out.gver
+      if out.grad_scaled is not None and not pre_scaled:
+        # a norm stored its dx already multiplied by this conv's row scale and something else
+        # wrote to the gradient afterwards: the sum can no longer be un-mixed -- fail loudly
+        raise RuntimeError(f'{layer.name}: pre-scaled output gradient was modified by a second '
+                           'consumer (set SE3DS_FUSED_ROW_SCALE=0)')
       out.grad_scaled = None
       out.grad = None
       if dy is None:
