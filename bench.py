@@ -44,7 +44,9 @@ def _dist_setup(ngpus):
   if backend != 'nccl':
     local = 0
   if backend == 'nccl' and torch.cuda.device_count() < max(world, ngpus):
-    # (device_count() does not initialise the GPU) fail fast, before any rendezvous can hang
+    # fail fast, before any rendezvous can hang.  (device_count() may initialise the HIP runtime
+    # on builds without amdsmi: harmless here, this process is a rank already -- but the launcher
+    # below must stay spawn-only, never re-exec, for exactly that reason)
     raise SystemExit(f'bench.py: --gpus {ngpus} (WORLD_SIZE {world}) needs one GPU per rank, this '
                      f'node has {torch.cuda.device_count()}')
   torch.cuda.set_device(local)
@@ -247,6 +249,8 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-batch-max', action='store_true',
                   help='gan_step: skip the extra large-batch measurement (batch_max) on the default line')
+  ap.add_argument('--no-shipped', action='store_true',
+                  help='gan_step: skip the extra d_step_per_g_step = 2 cluster-step measurement')
   ap.add_argument('--no-warp', action='store_true',
                   help='gan_step: skip the extra cfg5 warp measurement on the default line')
   args = ap.parse_args()

@@ -308,6 +308,21 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
                        int pad_l, int wrap_w, const float* in_mask, int in_mask_binary,
                        const float* row_scale, const float* out_scale, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* The same without its final split reduction (round 4): the partial slabs stay in `workspace`
+ * (which the caller therefore keeps per layer until the reduction has run) and reduce_row (HOST
+ * memory, 5 x int64) receives [slabs, splits, n / 4, dw, 1]; rows of many layers go to ONE
+ * se3ds_wgrad_reduce_multi launch (device table of such rows with the 5th field replaced by the
+ * row's first workgroup: running sum of ceil(n4 / se3ds_wgrad_reduce_tile())).  When the 16-byte
+ * reduction does not apply (ragged sizes), the reduction is launched as usual and reduce_row[4]
+ * stays 0.  Bit-identical to se3ds_conv2d_wgrad.  Same reference semantics: the kernel gradient of
+ * tf.nn.conv2d (models/layers.py:153,193,334). */
+int se3ds_conv2d_wgrad_partial(const void* x, const void* dy, float* dw, int dtype, int n, int h,
+                               int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride,
+                               int pad_t, int pad_l, int wrap_w, const float* in_mask,
+                               int in_mask_binary, const float* row_scale, void* workspace,
+                               size_t workspace_bytes, int64_t* reduce_row, void* stream);
+int se3ds_wgrad_reduce_multi(const int64_t* table, int rows, int64_t workgroups, void* stream);
+int se3ds_wgrad_reduce_tile(void);
 
 /* Weight gradient of a THIN-Cout (cout <= 16), stride-1, same-size conv (the generator's
  * 128->3 / 128->1 output convs, image_models.py:93-104) computed with the operand roles
@@ -505,6 +520,18 @@ int se3ds_multi_adam_keras(float* params, const float* grads, float* m, float* v
 int se3ds_multi_adam_keras_ema(float* params, const float* grads, float* m, float* v, int64_t n,
                                float lr, float beta1, float beta2, float eps, int64_t step,
                                float* ema, float one_minus_decay, void* stream);
+/* One replica: se3ds_multi_clip_by_norm_sn + se3ds_multi_adam_keras_ema in ONE pass over the chunk
+ * rows [tensor id, first element, length] -- the clipped (and, for spectral kernels, fixed-up)
+ * gradient is formed in registers and consumed by the Adam (+ EMA) update; the gradient arena is
+ * read once and NOT rewritten (trainers/se3ds_trainer.py:27-32,238-257 with a single replica:
+ * clip_by_norm feeds apply_gradients directly).  Bit-identical to the two separate passes.
+ * sqnorm from se3ds_multi_sqnorm_sn; chunk rows carry absolute tensor ids and arena offsets; all
+ * arenas 16-byte aligned (SE3DS_E_UNSUPPORTED otherwise).  ema may be NULL. */
+int se3ds_multi_clip_adam_keras_ema(float* params, const float* grads, float* m, float* v,
+                                    const int64_t* chunks, int64_t nchunks, const float* sqnorm,
+                                    float clip_norm, const int64_t* tensor_sn, float lr, float beta1,
+                                    float beta2, float eps, int64_t step, float* ema,
+                                    float one_minus_decay, void* stream);
 /* ema -= (ema - vars) * one_minus_decay */
 int se3ds_multi_ema(float* ema, const float* vars, int64_t n, float one_minus_decay, void* stream);
 

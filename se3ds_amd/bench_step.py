@@ -118,7 +118,12 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
       'roofline': {'bound': 'mfma', 'kernel': 'implicit-GEMM convolutions: igemm_halo / igemm_big / '
                    'igemm_glds + wgrad_taps / wgrad_glds (every conv fwd, dgrad and wgrad call of '
                    'one step)', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                   'frac': achieved / peak, 'traffic': traffic, 'traffic_detail': traffic_detail,
+                   'frac': achieved / peak,
+                   # `frac`: every conv launch timed ALONE (serial instrumented step, HIP events);
+                   # `frac_in_step`: the same FLOPs over the WHOLE timed step (norms, optimiser,
+                   # launch gaps and stream sharing included) -- the effective MFMA fraction
+                   'frac_in_step': summ['flops'] / (ms * 1e-3) / 1e12 / peak,
+                   'traffic': traffic, 'traffic_detail': traffic_detail,
                    'launches': summ['launches'],
                    'avg_launch_ms': summ['ms'] / max(summ['launches'], 1),
                    'conv_ms_per_step': summ['ms'], 'conv_tflop_per_step': summ['flops'] / 1e12,
@@ -127,6 +132,8 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
           'gen/gen_gan_loss', 'dis/disc_loss', 'gen/depth_loss', 'gen/wc_loss')},
       'hbm_gib_peak': torch.cuda.max_memory_allocated(dev) / 2**30,
   }
+  if world == 1 and not getattr(args, 'no_shipped', False):
+    out['shipped_schedule'] = shipped_schedule(gan, n, h, dev, rank)
   if world == 1 and args.batch <= 0 and h == 512 and not getattr(args, 'no_batch_max', False):
     # "N = B (largest that fits; report B)".  The headline stays at the named
     # per-GPU batch 8 (= cfg4's share of global batch 64); the large-batch rate rides along.
@@ -137,11 +144,41 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
   return out
 
 
+def shipped_schedule(gan, n, h, dev, rank, steps=3):
+  """SURVEY 8d's secondary figure: the SHIPPED schedule, `d_step_per_g_step = 2`
+  (configs/highres/highres.gin:13).  One cluster step (gan_manager.py:376-385) splits the cluster
+  batch into two chunks: `train_d` on the first, `train_g_d` on the second; panoramas/s = samples
+  consumed by the cluster step (2 x per-GPU batch) / its wall time."""
+  import itertools
+  keep = gan.d_step_per_g_step, gan.train_ds
+  a, b = synth_batch(n, h, 1234 + rank, dev), synth_batch(n, h, 9876 + rank, dev)
+  cluster = {k: torch.cat([b[k], a[k]]) for k in a}   # train_d sees chunk 0, train_g_d chunk 1
+  del a, b
+  try:
+    gan.d_step_per_g_step = 2
+    gan.train_ds = itertools.repeat(cluster)
+    gan.train_cluster(1)
+    gan.global_step += gan.num_batched_steps
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      gan.train_cluster(1)
+      gan.global_step += gan.num_batched_steps
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+  finally:
+    gan.d_step_per_g_step, gan.train_ds = keep
+  return {'d_step_per_g_step': 2, 'value': 2 * n * steps / dt, 'unit': 'panoramas/sec',
+          'ms_per_cluster_step': 1e3 * dt / steps, 'cluster_batch': 2 * n, 'steps': steps,
+          'warmup': 1, 'what': 'train_d (chunk 0) + train_g_d (chunk 1) per cluster step'}
+
+
 def batch_max(gan, h, dev, rank, candidates=(24, 16), steps=3):
   """Throughput of the same step at the largest per-GPU batch that fits (the batch-independent
   part -- optimiser, operand staging, launch ramps -- is amortised): one warm-up + `steps` timed
   steps.  Falls back to the next candidate when the allocation fails."""
   import gc
+  degraded = False   # a candidate failed mid-step: later figures come from a half-stepped model
   for nb in candidates:
     gc.collect()
     torch.cuda.empty_cache()
@@ -159,28 +196,30 @@ def batch_max(gan, h, dev, rank, candidates=(24, 16), steps=3):
       dt = time.perf_counter() - t0
       return {'per_gpu_batch': nb, 'value': nb * steps / dt, 'unit': 'panoramas/sec',
               'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': 1,
-              'hbm_gib_peak': torch.cuda.max_memory_allocated(dev) / 2**30}
+              'hbm_gib_peak': torch.cuda.max_memory_allocated(dev) / 2**30,
+              'degraded': degraded}
     except (torch.OutOfMemoryError, RuntimeError) as e:   # does not fit: next candidate
       last = repr(e)[:200]
       big = None
-  return {'per_gpu_batch': None, 'value': None, 'error': last}
+      degraded = True
+      torch.cuda.synchronize()
+  return {'per_gpu_batch': None, 'value': None, 'error': last, 'degraded': True}
 
 
-def cpu_baseline(args, gan, tflop_per_sample, budget_s=60.0):
+def cpu_baseline(args, gan, tflop_per_sample, budget_s=46.0):
   """The reference's CPU path beside the GPU number: TensorFlow cannot run here, so
   this is the PyTorch-CPU restatement of the SAME step -- oracle/nets_torch.train_g_d: generator
   and discriminator forward, both backward passes, losses, per-tensor clip -- on the bench's own
-  weights (copied off the device), all host cores, fp32.
+  weights (copied off the device), fp32.
 
-  `value` is what was MEASURED: one step at cfg1's shape (128x256, batch 2).  No warm-up run: a
-  warm-up changes nothing here (30.6 s against 30.7 s, BENCH notes in DESIGN.md section 5) and
-  a step costs half the budget.  The second measurement is the same step at batch 1: a CPU step
-  is dominated by work that does NOT scale with pixels -- W / sigma and its gradient over 1.1 B
-  parameters, several weight-sized fp32 passes per layer -- so t(batch) = a + batch * p separates
-  the weight-bound part `a` from the per-panorama part `p`, and the figure for the benchmarked
-  shape is the MODEL a + B * 16 * p (pixel ratio 16 on the per-panorama part only), labelled
-  `extrapolated_512x1024`.  The plain pixel-ratio figure (value / 16) is kept beside it; it is a
-  lower bound of the CPU rate.  A port, not TF; baseline only."""
+  `value` is MEASURED AT THE METRIC'S SHAPE: one batch-1 `train_g_d` at the benchmarked resolution
+  (512x1024; SURVEY 8d: "time cfg3 for 1-2 steps").  No warm-up run: a warm-up changes nothing here
+  (30.6 s against 30.7 s) and a step costs half the budget.  A CPU step is
+  dominated by work that does NOT scale with pixels (W / sigma and its gradient over 1.1 B
+  parameters, several weight-sized fp32 passes per layer), so batch 1 is the cheapest sample that
+  still is the workload; the rate at batch 8 would be higher by the amortised weight-bound part,
+  and the secondary run at cfg1's resolution (128x256, `cfg1`) keeps the earlier rounds' figure
+  comparable.  A port, not TF; baseline only."""
   import torch as T
   from oracle import nets_torch as O
   try:
@@ -204,42 +243,31 @@ def cpu_baseline(args, gan, tflop_per_sample, budget_s=60.0):
              lambda_depth=gan.lambda_depth, mask_blurred=gan.mask_blurred,
              g_train=lambda k: not k.endswith(('/u', '/moving_mean', '/moving_variance')),
              d_train=lambda k: not k.endswith('/u'))
-  h_lo, n_lo = 128, 2
   g = T.Generator().manual_seed(1234)
-  def timed(n):
-    b = synth_batch_cpu(n, h_lo, g)
+  def timed(n, h):
+    b = synth_batch_cpu(n, h, g)
     t0 = time.perf_counter()
     O.train_g_d(gp, dp, b, cfg)
     return time.perf_counter() - t0
-  t2 = timed(n_lo)
-  rate = n_lo / t2
-  scale = (args.image_size / h_lo) ** 2
-  nb = args.batch if args.batch > 0 else 8
-  out = {'value': rate, 'unit': 'panoramas/sec', 'cores': threads, 'kind': 'port',
-         'resolution': f'{h_lo}x{2 * h_lo}', 'batch': n_lo, 'timed_runs_s': [t2],
-         'pixel_ratio_512x1024': rate / scale, 'extrapolated_512x1024': rate / scale,
-         'model': None}
-  note = 'no time left for the batch-1 run: extrapolated by the pixel ratio only.'
-  if budget_s - (time.perf_counter() - t_start) > 0.85 * t2:
-    t1 = timed(1)
-    out['timed_runs_s'].append(t1)
-    p_lo, a = t2 - t1, 2.0 * t1 - t2
-    if p_lo > 0.02 * t2 and a >= 0.0:
-      t_hi = a + nb * scale * p_lo
-      out['extrapolated_512x1024'] = nb / t_hi
-      out['model'] = {'weight_bound_s': a, 'per_panorama_128x256_s': p_lo,
-                      'step_s_512x1024_batch': t_hi, 'batch': nb}
-      note = (f'batch 1 took {t1:.1f} s: t(batch) = {a:.1f} s (weight-sized passes, batch- and '
-              f'resolution-independent) + batch x {p_lo:.1f} s; model for {args.image_size}x'
-              f'{2 * args.image_size} batch {nb}: {a:.1f} + {nb} x {scale:.0f} x {p_lo:.1f} = {t_hi:.0f} s '
-              f'per step = {nb / t_hi:.5f} panoramas/s (extrapolated_512x1024).')
-    else:
-      note = f'batch 1 took {t1:.1f} s: no usable split, extrapolated by the pixel ratio only.'
-  out['sample'] = (f'oracle.nets_torch.train_g_d (PyTorch-CPU fp32 restatement of the full G+D step: '
-                   f'forward, both backward passes, losses, clip; the bench weights) at cfg1 shape '
-                   f'{h_lo}x{2 * h_lo} batch {n_lo}: {t2:.1f} s = {rate:.4f} panoramas/s AT THAT SIZE '
-                   f'(value, measured; pixel ratio alone would give {rate / scale:.5f} at '
-                   f'{args.image_size}x{2 * args.image_size}).  ' + note + '  Not TF.')
+  h_hi = args.image_size
+  t_hi = timed(1, h_hi)
+  out = {'value': 1.0 / t_hi, 'unit': 'panoramas/sec', 'cores': threads, 'kind': 'port',
+         'resolution': f'{h_hi}x{2 * h_hi}', 'batch': 1, 'timed_runs_s': [t_hi], 'cfg1': None}
+  note = ''
+  # secondary: the cfg1 resolution (BASELINE.json configs[0]) at batch 1, if the budget allows (a
+  # step there costs ~10 s -- the weight-bound part -- against ~34 s at 512x1024)
+  h_lo, n_lo = 128, 1
+  if h_hi != h_lo and budget_s - (time.perf_counter() - t_start) > 10.5:
+    t_lo = timed(n_lo, h_lo)
+    out['cfg1'] = {'value': n_lo / t_lo, 'unit': 'panoramas/sec', 'resolution': f'{h_lo}x{2 * h_lo}',
+                   'batch': n_lo, 'timed_runs_s': [t_lo]}
+    note = (f'  Secondary (cfg1 shape {h_lo}x{2 * h_lo} batch {n_lo}): {t_lo:.1f} s = '
+            f'{n_lo / t_lo:.4f} panoramas/s at that size.')
+  out['leg_s'] = time.perf_counter() - t_start
+  out['sample'] = (f'ONE measured oracle.nets_torch.train_g_d step (PyTorch-CPU fp32 restatement of '
+                   f'the full G+D step: forward, both backward passes, losses, clip; the bench '
+                   f'weights) at the benchmarked resolution {h_hi}x{2 * h_hi}, batch 1: {t_hi:.1f} s '
+                   f'= {1.0 / t_hi:.4f} panoramas/s on {threads} host threads.' + note + '  Not TF.')
   return out
 
 

@@ -2445,6 +2445,66 @@ wgrad_reduce_vec_kernel(const float* __restrict__ part, int splits, int64_t n4, 
   }
 }
 
+// Round 4: the split reductions of MANY layers in one launch (se3ds_wgrad_reduce_multi): the
+// weight-gradient kernels of a module leave their partial slabs in per-layer scratch and the module's
+// reductions run as one table-driven launch when the backward pass has left the module (on the
+// optimiser's side stream in the one-replica trainer) -- 295 bandwidth-sized launches per step leave
+// the backward pass's critical path.  Table rows (device, int64 x 5): partial slabs, splits, n / 4,
+// destination, first workgroup of the row; a workgroup owns 1024 float4 (four per thread, independent
+// load chains).  Per element the summation order is wgrad_reduce_vec_kernel's: bit-identical.
+constexpr int kRedTile = 1024;
+__global__ void __launch_bounds__(256)
+wgrad_reduce_multi_kernel(const int64_t* __restrict__ tab, int rows) {
+  int lo = 0, hi = rows - 1;
+  while (lo < hi) {   // last row whose first workgroup is <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid * 5 + 4] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* R = tab + lo * 5;
+  const float4* __restrict__ P = reinterpret_cast<const float4*>(R[0]);
+  const int splits = (int)R[1];
+  const int64_t n4 = R[2];
+  float4* __restrict__ O = reinterpret_cast<float4*>(R[3]);
+  const int64_t base = ((int64_t)blockIdx.x - R[4]) * kRedTile + threadIdx.x;
+  auto add = [](float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+  if (splits == 2) {   // (the common case: all four elements' loads in flight together)
+    float4 a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = base + j * 256;
+      const int64_t q = i < n4 ? i : 0;
+      a[j] = P[q];
+      b[j] = P[n4 + q];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = base + j * 256;
+      if (i >= n4) continue;
+      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+      add(s0, a[j]);
+      add(s0, b[j]);
+      O[i] = make_float4(((s0.x + s1.x) + (s2.x + s3.x)) * 1.0f, ((s0.y + s1.y) + (s2.y + s3.y)) * 1.0f,
+                         ((s0.z + s1.z) + (s2.z + s3.z)) * 1.0f, ((s0.w + s1.w) + (s2.w + s3.w)) * 1.0f);
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = base + j * 256;
+    if (i >= n4) continue;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      const float4 a = P[(int64_t)k * n4 + i], b = P[(int64_t)(k + 1) * n4 + i];
+      const float4 c = P[(int64_t)(k + 2) * n4 + i], d = P[(int64_t)(k + 3) * n4 + i];
+      add(s0, a); add(s1, b); add(s2, c); add(s3, d);
+    }
+    for (; k < splits; ++k) add(s0, P[(int64_t)k * n4 + i]);
+    O[i] = make_float4(((s0.x + s1.x) + (s2.x + s3.x)) * 1.0f, ((s0.y + s1.y) + (s2.y + s3.y)) * 1.0f,
+                       ((s0.z + s1.z) + (s2.z + s3.z)) * 1.0f, ((s0.w + s1.w) + (s2.w + s3.w)) * 1.0f);
+  }
+}
+
 // dW[(ky,kx),ci,co] = tmp[(k-1-ky, k-1-kx), co, ci]: finishes the role-swapped weight gradient
 // of thin-Cout stride-1 'same' convs (see se3ds_conv2d_wgrad_swapped in the header).
 __global__ void __launch_bounds__(256)
@@ -3360,8 +3420,22 @@ weight_prep_vec_kernel(const float* __restrict__ w, int64_t K, int Cout, uint16_
   }
 }
 
+// se3ds_conv2d_wgrad_partial: the calling host thread's next split reduction is not launched but
+// described in this row [slabs, splits, n / 4, destination, 1] (when the 16-byte kernel applies)
+static thread_local int64_t* t_defer_row = nullptr;
+
 static void launch_wgrad_reduce(const float* part, int splits, int64_t n, int accumulate,
                                 const float* out_scale, float* out, hipStream_t s) {
+  if (t_defer_row != nullptr && !accumulate && out_scale == nullptr && (n % 4) == 0 &&
+      (((uintptr_t)part | (uintptr_t)out) & 15) == 0) {
+    t_defer_row[0] = (int64_t)(uintptr_t)part;
+    t_defer_row[1] = splits;
+    t_defer_row[2] = n / 4;
+    t_defer_row[3] = (int64_t)(uintptr_t)out;
+    t_defer_row[4] = 1;
+    t_defer_row = nullptr;
+    return;
+  }
   static const bool scalar_only = getenv("SE3DS_WGRAD_REDUCE_SCALAR") != nullptr;   // (A/B switch)
   if (!scalar_only && (n % 4) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0)
     hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, part,
@@ -3892,6 +3966,31 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   launch_wgrad_reduce((const float*)workspace, p.splits, nel, accumulate, out_scale, dw, s);
   return check_launch("conv2d_wgrad");
 }
+
+int se3ds_conv2d_wgrad_partial(const void* x, const void* dy, float* dw, int dtype, int n, int h,
+                               int w, int cin, int ho, int wo, int cout, int kh, int kw, int stride,
+                               int pad_t, int pad_l, int wrap_w, const float* in_mask,
+                               int in_mask_binary, const float* row_scale, void* workspace,
+                               size_t workspace_bytes, int64_t* reduce_row, void* stream) {
+  if (reduce_row == nullptr) return SE3DS_E_BADSHAPE;
+  reduce_row[4] = 0;
+  t_defer_row = reduce_row;
+  const int rc = se3ds_conv2d_wgrad(x, dy, dw, dtype, n, h, w, cin, ho, wo, cout, kh, kw, stride,
+                                    pad_t, pad_l, wrap_w, in_mask, in_mask_binary, row_scale,
+                                    nullptr, 0, workspace, workspace_bytes, stream);
+  t_defer_row = nullptr;
+  return rc;
+}
+
+int se3ds_wgrad_reduce_multi(const int64_t* table, int rows, int64_t workgroups, void* stream) {
+  if (rows <= 0 || workgroups <= 0) return SE3DS_OK;
+  if (workgroups >= ((int64_t)1 << 31)) return SE3DS_E_BADSHAPE;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)workgroups), dim3(256), 0,
+                     as_stream(stream), table, rows);
+  return check_launch("wgrad_reduce_multi");
+}
+
+int se3ds_wgrad_reduce_tile(void) { return kRedTile; }
 
 // thin-Cout layers through the tap-fused kernel (padded dy copy): split count, 0 = not eligible
 static int wgrad_taps_thin_splits(int n, int h, int w, int cin, int cout, int k, int* steps) {

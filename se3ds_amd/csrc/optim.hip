@@ -63,6 +63,32 @@ __device__ inline float sn_dot_gw(const float* __restrict__ vpart) {
   return dot;
 }
 
+// Per-element arithmetic shared by the separate passes (clip_kernel, adam_kernel, adam_ema_kernel)
+// and the fused one (clip_adam_kernel): one expression each, so that both compile to the same
+// operation sequence (contractions included) and the fused update is bit-identical.
+// (Every operation is pinned with the non-contractable intrinsics: left to -ffp-contract=fast the
+// compiler fused `inv * g - coef * v * u` one way in clip_kernel and the other way in the fused
+// kernel, where coef * v is shared by four elements -- a 1-ulp difference in the update.)
+__device__ __forceinline__ float clip_plain(float g, float clip, float den) {
+  return __fdiv_rn(__fmul_rn(g, clip), den);
+}
+__device__ __forceinline__ float clip_sn(float g, float inv, float coef, float vk, float uc,
+                                         float clip, float den) {
+  const float f = __fmaf_rn(inv, g, -__fmul_rn(__fmul_rn(coef, vk), uc));
+  return __fdiv_rn(__fmul_rn(f, clip), den);
+}
+__device__ __forceinline__ void adam_elem(float gi, float& p, float& m, float& v, float alpha,
+                                          float b1, float b2, float eps) {
+  const float mi = __fmaf_rn(__fsub_rn(gi, m), __fsub_rn(1.0f, b1), m);
+  const float vi = __fmaf_rn(__fmaf_rn(gi, gi, -v), __fsub_rn(1.0f, b2), v);
+  m = mi;
+  v = vi;
+  p = __fsub_rn(p, __fdiv_rn(__fmul_rn(mi, alpha), __fadd_rn(__fsqrt_rn(vi), eps)));
+}
+__device__ __forceinline__ float ema_elem(float e, float pn, float omd) {
+  return __fmaf_rn(-__fsub_rn(e, pn), omd, e);
+}
+
 __global__ void __launch_bounds__(kB)
 clip_kernel(float* __restrict__ g, const int64_t* __restrict__ chunks,
             const float* __restrict__ sqnorm, float clip, const int64_t* __restrict__ tensor_sn) {
@@ -73,7 +99,7 @@ clip_kernel(float* __restrict__ g, const int64_t* __restrict__ chunks,
   const float den = fmaxf(norm, clip);
   const int64_t* L = tensor_sn ? (const int64_t*)tensor_sn[t] : nullptr;
   if (L == nullptr) {
-    for (int64_t i = threadIdx.x; i < len; i += kB) g[start + i] = (g[start + i] * clip) / den;
+    for (int64_t i = threadIdx.x; i < len; i += kB) g[start + i] = clip_plain(g[start + i], clip, den);
     return;
   }
   // spectral layer whose gradient still is dL/d(W/sigma): the fix-up of sn_fix_kernel
@@ -92,8 +118,7 @@ clip_kernel(float* __restrict__ g, const int64_t* __restrict__ chunks,
   int c = (int)(e0 - k * C);
   const int dq = kB / C, dr = kB - dq * C;
   for (int64_t i = threadIdx.x; i < len; i += kB) {
-    const float f = inv * g[start + i] - coef * v[k] * uhat[c];
-    g[start + i] = (f * clip) / den;
+    g[start + i] = clip_sn(g[start + i], inv, coef, v[k], uhat[c], clip, den);
     k += dq;
     c += dr;
     if (c >= C) { c -= C; ++k; }
@@ -127,12 +152,11 @@ __global__ void __launch_bounds__(kB)
 adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
             float* __restrict__ v, int64_t n, float alpha, float b1, float b2, float eps) {
   for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)gridDim.x * kB) {
-    float gi = g[i];
-    float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-    float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_elem(g[i], pi, mi, vi, alpha, b1, b2, eps);
     m[i] = mi;
     v[i] = vi;
-    p[i] = p[i] - (mi * alpha) / (sqrtf(vi) + eps);
+    p[i] = pi;
   }
 }
 
@@ -143,14 +167,102 @@ adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __res
                 float* __restrict__ v, int64_t n, float alpha, float b1, float b2, float eps,
                 float* __restrict__ ema, float omd) {
   for (int64_t i = (int64_t)blockIdx.x * kB + threadIdx.x; i < n; i += (int64_t)gridDim.x * kB) {
-    float gi = g[i];
-    float mi = m[i] + (gi - m[i]) * (1.0f - b1);
-    float vi = v[i] + (gi * gi - v[i]) * (1.0f - b2);
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_elem(g[i], pi, mi, vi, alpha, b1, b2, eps);
     m[i] = mi;
     v[i] = vi;
-    const float pn = p[i] - (mi * alpha) / (sqrtf(vi) + eps);
-    p[i] = pn;
-    ema[i] = ema[i] - (ema[i] - pn) * omd;
+    p[i] = pi;
+    ema[i] = ema_elem(ema[i], pi, omd);
+  }
+}
+
+// Round 4: per-tensor clip (+ the spectral fix-up) applied INSIDE the Adam (+ EMA) pass -- one
+// replica only, where nobody else needs the clipped arena: the gradient is read once and never
+// rewritten (clip_kernel's read-modify-write of the arena, 8.9 GB per generator step, is gone).
+// One workgroup per chunk row (tensor id, start, length) as clip_kernel; 16-byte accesses where a
+// chunk allows them (chunks start 16-byte aligned: tensors are, and the chunk length is a multiple
+// of 4 except at a tensor's end).  Same arithmetic per element as clip_kernel followed by
+// adam_ema_kernel (shared inline functions above): bit-identical update.
+template <bool EMA>
+__global__ void __launch_bounds__(kB)
+clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                 float* __restrict__ v, const int64_t* __restrict__ chunks,
+                 const float* __restrict__ sqnorm, float clip,
+                 const int64_t* __restrict__ tensor_sn, float alpha, float b1, float b2, float eps,
+                 float* __restrict__ ema, float omd) {
+  const int64_t t = chunks[blockIdx.x * 3], start = chunks[blockIdx.x * 3 + 1],
+                len = chunks[blockIdx.x * 3 + 2];
+  const float sq = sqnorm[t];
+  const float norm = sq > 0.f ? sqrtf(sq) : sq;
+  const float den = fmaxf(norm, clip);
+  const int64_t* L = tensor_sn ? (const int64_t*)tensor_sn[t] : nullptr;
+  const float* sv = nullptr;
+  const float* su = nullptr;
+  float inv = 0.f, coef = 0.f;
+  int C = 4;
+  int64_t e_base = 0;
+  if (L != nullptr) {
+    sv = (const float*)L[2];
+    su = (const float*)L[3];
+    const float* sig = (const float*)L[4];
+    const float* vpart = (const float*)L[6];
+    C = (int)L[8];
+    const float dot = sn_dot_gw(vpart);
+    inv = sig[1];
+    coef = inv * inv * dot;
+    e_base = (g + start) - (const float*)L[9];   // element of the tensor this chunk starts at
+  }
+  auto one = [&](int64_t i, float gi) {   // clipped gradient of element start + i
+    if (L == nullptr) return clip_plain(gi, clip, den);
+    const int64_t e = e_base + i;
+    const int64_t k = e / C;
+    const int c = (int)(e - k * C);
+    return clip_sn(gi, inv, coef, sv[k], su[c], clip, den);
+  };
+  const int64_t len4 = ((C & 3) == 0) ? (len & ~(int64_t)3) : 0;   // (rows of C: a float4 stays in one)
+  for (int64_t i = (int64_t)threadIdx.x * 4; i < len4; i += (int64_t)kB * 4) {
+    const int64_t o = start + i;
+    const float4 g4 = *reinterpret_cast<const float4*>(g + o);
+    float4 p4 = *reinterpret_cast<const float4*>(p + o);
+    float4 m4 = *reinterpret_cast<const float4*>(m + o);
+    float4 v4 = *reinterpret_cast<const float4*>(v + o);
+    float gc[4];
+    if (L == nullptr) {
+      gc[0] = clip_plain(g4.x, clip, den); gc[1] = clip_plain(g4.y, clip, den);
+      gc[2] = clip_plain(g4.z, clip, den); gc[3] = clip_plain(g4.w, clip, den);
+    } else {
+      const int64_t e = e_base + i;
+      const int64_t k = e / C;
+      const int c = (int)(e - k * C);
+      const float vk = sv[k];
+      const float4 u4 = *reinterpret_cast<const float4*>(su + c);
+      gc[0] = clip_sn(g4.x, inv, coef, vk, u4.x, clip, den);
+      gc[1] = clip_sn(g4.y, inv, coef, vk, u4.y, clip, den);
+      gc[2] = clip_sn(g4.z, inv, coef, vk, u4.z, clip, den);
+      gc[3] = clip_sn(g4.w, inv, coef, vk, u4.w, clip, den);
+    }
+    adam_elem(gc[0], p4.x, m4.x, v4.x, alpha, b1, b2, eps);
+    adam_elem(gc[1], p4.y, m4.y, v4.y, alpha, b1, b2, eps);
+    adam_elem(gc[2], p4.z, m4.z, v4.z, alpha, b1, b2, eps);
+    adam_elem(gc[3], p4.w, m4.w, v4.w, alpha, b1, b2, eps);
+    *reinterpret_cast<float4*>(m + o) = m4;
+    *reinterpret_cast<float4*>(v + o) = v4;
+    *reinterpret_cast<float4*>(p + o) = p4;
+    if (EMA) {
+      float4 e4 = *reinterpret_cast<const float4*>(ema + o);
+      e4.x = ema_elem(e4.x, p4.x, omd); e4.y = ema_elem(e4.y, p4.y, omd);
+      e4.z = ema_elem(e4.z, p4.z, omd); e4.w = ema_elem(e4.w, p4.w, omd);
+      *reinterpret_cast<float4*>(ema + o) = e4;
+    }
+  }
+  for (int64_t i = len4 + threadIdx.x; i < len; i += kB) {
+    const int64_t o = start + i;
+    float pi = p[o], mi = m[o], vi = v[o];
+    adam_elem(one(i, g[o]), pi, mi, vi, alpha, b1, b2, eps);
+    m[o] = mi;
+    v[o] = vi;
+    p[o] = pi;
+    if (EMA) ema[o] = ema_elem(ema[o], pi, omd);
   }
 }
 
@@ -471,6 +583,26 @@ int se3ds_multi_adam_keras_ema(float* params, const float* grads, float* m, floa
   hipLaunchKernelGGL(adam_ema_kernel, dim3(grid_for(n, kB)), dim3(kB), 0, as_stream(stream), params,
                      grads, m, v, n, alpha, beta1, beta2, eps, ema, one_minus_decay);
   return check_launch("multi_adam_keras_ema");
+}
+
+int se3ds_multi_clip_adam_keras_ema(float* params, const float* grads, float* m, float* v,
+                                    const int64_t* chunks, int64_t nchunks, const float* sqnorm,
+                                    float clip_norm, const int64_t* tensor_sn, float lr, float beta1,
+                                    float beta2, float eps, int64_t step, float* ema,
+                                    float one_minus_decay, void* stream) {
+  if (nchunks <= 0) return SE3DS_OK;
+  if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) != 0)
+    return SE3DS_E_UNSUPPORTED;
+  const float alpha = adam_alpha(lr, beta1, beta2, step);
+  if (ema)
+    hipLaunchKernelGGL(clip_adam_kernel<true>, dim3((unsigned)nchunks), dim3(kB), 0, as_stream(stream),
+                       params, grads, m, v, chunks, sqnorm, clip_norm, tensor_sn, alpha, beta1, beta2,
+                       eps, ema, one_minus_decay);
+  else
+    hipLaunchKernelGGL(clip_adam_kernel<false>, dim3((unsigned)nchunks), dim3(kB), 0, as_stream(stream),
+                       params, grads, m, v, chunks, sqnorm, clip_norm, tensor_sn, alpha, beta1, beta2,
+                       eps, ema, one_minus_decay);
+  return check_launch("multi_clip_adam_keras_ema");
 }
 
 int se3ds_multi_ema(float* ema, const float* vars, int64_t n, float one_minus_decay,

@@ -248,6 +248,10 @@ class Ctx:
     # dgrad ...): with a stream here, every conv layer's wgrad goes to it behind an event on dy,
     # and MFMA-bound wgrads run under the HBM-bound normalisation kernels of the chain.
     self.wgrad_stream = None
+    # Deferred split reductions of the weight gradients (round 4): a list collects one row per conv
+    # layer [slabs, splits, n / 4, destination]; flush_wgrad_reduces() runs them as ONE launch (the
+    # trainer: per module, on the optimiser's side stream).  None: every layer reduces right away.
+    self.wgrad_defer = None
     self._tl = threading.local()   # branch_tag is per host thread (paired branches run in two)
     self._forked = set()
     # Several replicas: two structurally identical branches run in lockstep so that their k-th
@@ -370,25 +374,34 @@ class Ctx:
 
   def _replay(self, tape):
     cur, scope = 0, None
-    for fn, tag, sync in reversed(tape):
-      self._cur_paired = sync == 2
-      t = tag if self.streams is not None else 0
-      if t != cur:   # (one stream switch per run of closures, not per closure)
-        if scope is not None:
-          scope.__exit__(None, None, None)
-          scope = None
-        if t == 0:
-          self.join()
-        else:
-          scope = self.branch(t)
-          scope.__enter__()
-        cur = t
-      fn()
-    if scope is not None:
-      scope.__exit__(None, None, None)
-    self._cur_paired = False
-    assert self._bwd_pending is None, 'unpaired SyncBN backward'
-    self.join()
+    try:
+      for fn, tag, sync in reversed(tape):
+        self._cur_paired = sync == 2
+        t = tag if self.streams is not None else 0
+        if t != cur:   # (one stream switch per run of closures, not per closure)
+          # deferred weight-gradient reductions never cross a stream switch: what is pending was
+          # issued on the stream we are leaving
+          flush_wgrad_reduces(self)
+          if scope is not None:
+            scope.__exit__(None, None, None)
+            scope = None
+          if t == 0:
+            self.join()
+          else:
+            scope = self.branch(t)
+            scope.__enter__()
+          cur = t
+        fn()
+      flush_wgrad_reduces(self)
+    finally:
+      # (also on an exception out of a closure: torch's current stream must not stay on a branch
+      # stream, and a half-paired SyncBN backward must not leak into the next pass)
+      if scope is not None:
+        scope.__exit__(None, None, None)
+      self._cur_paired = False
+      pending, self._bwd_pending = self._bwd_pending, None
+      self.join()
+    assert pending is None, 'unpaired SyncBN backward'
 
   def mark_segment(self, name):
     """Call BEFORE running a top-level module in the forward pass: in the backward pass the
@@ -938,6 +951,51 @@ def _colsum(ctx, t2d_ptr, dtype_code, rows, c, row_scale=None, groups=1, out=Non
   return sums
 
 
+_RED_TABLES = {}
+
+
+def _wgrad(ctx, layer, args, wsz):
+  """se3ds_conv2d_wgrad(*args, out_scale=None, accumulate=0, workspace...) -- or, with
+  ctx.wgrad_defer, se3ds_conv2d_wgrad_partial into the layer's OWN slab scratch (it must outlive the
+  deferred reduction) with the reduction's row appended to the list."""
+  L = _L()
+  if ctx.wgrad_defer is None:
+    ws = _global_ws(ctx.device, 'wgrad', wsz)
+    _chk(L.se3ds_conv2d_wgrad(*args, None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
+         'se3ds_conv2d_wgrad')
+    return
+  ws = layer.__dict__.get('_wgrad_slab')
+  if ws is None or ws.numel() < wsz:
+    ws = torch.empty((int(wsz),), dtype=torch.uint8, device=ctx.device)
+    layer._wgrad_slab = ws
+  row = (_lib.c_i64 * 5)()
+  _chk(L.se3ds_conv2d_wgrad_partial(*args, ws.data_ptr(), ws.numel(), row, _lib.stream()),
+       'se3ds_conv2d_wgrad_partial')
+  if row[4]:
+    ctx.wgrad_defer.append((row[0], row[1], row[2], row[3]))
+
+
+def flush_wgrad_reduces(ctx):
+  """Runs the deferred split reductions collected so far as one launch on the current stream
+  (which must be ordered behind the weight-gradient kernels that wrote the slabs)."""
+  rows = ctx.wgrad_defer
+  if not rows:
+    return
+  ctx.wgrad_defer = []   # (a fresh list: `rows` is this launch's, also if a caller still holds it)
+  key = (str(ctx.device), tuple(rows))
+  ent = _RED_TABLES.get(key)
+  if ent is None:   # (pointers are stable: per-layer slabs, one gradient arena -- built once)
+    tile = int(_L().se3ds_wgrad_reduce_tile())
+    tab, first = [], 0
+    for part, splits, n4, dst in rows:
+      tab.append([part, splits, n4, dst, first])
+      first += (n4 + tile - 1) // tile
+    ent = (torch.tensor(tab, dtype=torch.int64, device=ctx.device), first)
+    _RED_TABLES[key] = ent
+  _chk(_L().se3ds_wgrad_reduce_multi(ent[0].data_ptr(), len(rows), ent[1], _lib.stream()),
+       'se3ds_wgrad_reduce_multi')
+
+
 def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act=ACT_NONE,
            alpha=0.0):
   """PadLayer(pad, circular=wrap) + conv (+ partial-conv renormalisation / spectral scale /
@@ -1075,14 +1133,11 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
                    'se3ds_conv2d_wgrad_swapped')
           else:
             wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, layer.cout, k, k)
-            ws = _global_ws(ctx.device, 'wgrad', wsz)
             with _Timed('wgrad', flops, tag):
-              _chk(L.se3ds_conv2d_wgrad(xd.data_ptr(), dys.data_ptr(), gk.data_ptr(), ctx.code, n, h,
-                                        w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
-                                        1 if wrap else 0, _lib.ptr(in_mask),
-                                        1 if ctx.binary_masks else 0, _lib.ptr(row_scale),
-                                        None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
-                   'se3ds_conv2d_wgrad')
+              _wgrad(ctx, layer, (xd.data_ptr(), dys.data_ptr(), gk.data_ptr(), ctx.code, n, h,
+                                  w, cin, ho, wo, layer.cout, k, k, s, pt, pl,
+                                  1 if wrap else 0, _lib.ptr(in_mask),
+                                  1 if ctx.binary_masks else 0, _lib.ptr(row_scale)), wsz)
       if x.requires_grad:
         prev = x.grad
         shape = (n,) + tuple(xd.shape[1:])
@@ -1175,13 +1230,10 @@ def conv_transpose2d(ctx: Ctx, x: Var, layer: ConvLayer):
           _colsum(ctx, dy.data_ptr(), ctx.code, n * H * W, layer.cout,
                   out=st.grad_views[layer.name + '/bias'])
         wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, hi, wi, layer.cout, cin_t, k, k)
-        ws = _global_ws(ctx.device, 'wgrad', wsz)
         gk = st.grad_views[layer.name + '/kernel']
         with _Timed('convT_wgrad', flops):
-          _chk(L.se3ds_conv2d_wgrad(dy.data_ptr(), xd.data_ptr(), gk.data_ptr(), ctx.code, n, H, W,
-                                    layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, 0, None,
-                                    None, 0, ws.data_ptr(), ws.numel(), _lib.stream()),
-               'se3ds_conv2d_wgrad')
+          _wgrad(ctx, layer, (dy.data_ptr(), xd.data_ptr(), gk.data_ptr(), ctx.code, n, H, W,
+                              layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, 0, None), wsz)
       if x.requires_grad:
         dx = ctx.empty(xd.shape)
         with _Timed('convT_dgrad', flops):

@@ -102,6 +102,35 @@ class AdamState:
                                              float(clip_norm), None, sn, _lib.stream()),
                'se3ds_multi_clip_by_norm_sn')
 
+  def clip_apply(self, t0, t1, clip_norm=5.0, fused_sn=False, ema_theta=None, one_minus_decay=0.0):
+    """One replica: clip_segment(t0, t1) + apply_segment over the same tensors in ONE pass over the
+    gradient arena (se3ds_multi_clip_adam_keras_ema): the clipped gradient only ever exists in
+    registers.  Bit-identical to the two calls.  Returns False (nothing done) when a test hook
+    wants to see the clipped arena (on_update) -- the caller then takes the separate passes.
+    Call begin_step() first, end_step() last, as for apply_segment."""
+    if self.on_update is not None:
+      return False
+    st = self.model.store
+    L = _lib.lib()
+    sn = self._sn_ptr(fused_sn)
+    c0, c1 = self._tcs_host[t0], self._tcs_host[t1]
+    if c1 <= c0:
+      return True
+    cache = self.__dict__.setdefault('_seg_tcs', {})
+    if (t0, t1) not in cache:
+      cache[(t0, t1)] = (self.tensor_chunk_start[t0:t1 + 1] - c0).contiguous()
+    tcs = cache[(t0, t1)]
+    _lib.check(L.se3ds_multi_sqnorm_sn(st.grad.data_ptr(), self.chunks.data_ptr() + 24 * c0, c1 - c0,
+                                       tcs.data_ptr(), t1 - t0, self.partial.data_ptr(),
+                                       self.sqnorm.data_ptr() + 4 * t0, sn, t0, _lib.stream()),
+               'se3ds_multi_sqnorm_sn')
+    _lib.check(L.se3ds_multi_clip_adam_keras_ema(
+        st.theta.data_ptr(), st.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+        self.chunks.data_ptr() + 24 * c0, c1 - c0, self.sqnorm.data_ptr(), float(clip_norm), sn,
+        self.lr, self.beta_1, self.beta_2, self.epsilon, self.iterations, _lib.ptr(ema_theta),
+        float(one_minus_decay), _lib.stream()), 'se3ds_multi_clip_adam_keras_ema')
+    return True
+
   def mean_clipped_norm(self, clip_norm=5.0):
     _lib.check(_lib.lib().se3ds_mean_clipped_norm(
         self.sqnorm.data_ptr(), len(self.model.store.trainable_names), float(clip_norm),

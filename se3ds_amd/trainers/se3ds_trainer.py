@@ -39,6 +39,13 @@ D_OVERLAP = os.environ.get('SE3DS_D_OVERLAP', '0') != '0'
 # measured SLOWER (221.0 vs 213.5 ms per step, same box): two MFMA-bound kernels co-running cost
 # more than the dependency chain gains.  Off; kept for A/B runs.
 WGRAD_STREAM = os.environ.get('SE3DS_WGRAD_STREAM', '0') != '0'
+# one replica: per-tensor clip (+ spectral fix-up) inside the Adam pass -- the gradient arena is read
+# once and never rewritten (AdamState.clip_apply).  Bit-identical; 0 = the two separate passes.
+FUSED_CLIP_ADAM = os.environ.get('SE3DS_FUSED_CLIP_ADAM', '1') != '0'
+# the split reductions of a module's weight gradients in ONE launch when the backward pass has left
+# the module (nn.flush_wgrad_reduces; one replica: on the optimiser's side stream) instead of one
+# launch behind every weight-gradient kernel.  Bit-identical; 0 = reduce right away.
+DEFER_WGRAD_REDUCE = os.environ.get('SE3DS_DEFER_WGRAD_REDUCE', '1') != '0'
 
 
 def _L():
@@ -362,8 +369,8 @@ class GAN(gan_manager.GANManager):
         ev.record()
       with torch.cuda.stream(opt):   # discriminator: its gradients are final behind pass 1
         opt.wait_event(ev)
-        d_norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
-        self.d_optimizer.apply_gradients(group, 1)
+        self._update_all(self.d_optimizer, False, None, 0.0)
+        d_norm = self.d_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
       self.g_optimizer.begin_step()
       def segment_done(name):
         if name not in segs:
@@ -376,15 +383,21 @@ class GAN(gan_manager.GANManager):
           opt.wait_event(done)
           if wdone is not None:
             opt.wait_event(wdone)
+          nn.flush_wgrad_reduces(ctx_g)   # (the module's deferred split reductions, one launch)
           G.spectral.backward_fixup(prefix=G.SEGMENTS[name], dots_only=FUSED_SN_CLIP)
-          self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP)
-          self.g_optimizer.apply_segment(e0, e1, ema_theta, ema_omd)
+          if not (FUSED_CLIP_ADAM and self.g_optimizer.clip_apply(
+              t0, t1, GRAD_CLIP_NORM, FUSED_SN_CLIP, ema_theta, ema_omd)):
+            self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP)
+            self.g_optimizer.apply_segment(e0, e1, ema_theta, ema_omd)
           # ... and the module's compute-dtype operand copies for the NEXT step (its backward is
           # over, nothing reads the old copies any more): 315 launches leave the critical path
           self._operand_group(G, name, ctx_g.dtype).prep(G.store.version + 1)
       ctx_g.on_segment = segment_done
+      if DEFER_WGRAD_REDUCE and ctx_g.wgrad_stream is None:
+        ctx_g.wgrad_defer = []
       ctx_g.backward()
       ctx_g.on_segment = None
+      ctx_g.wgrad_defer = None
       with torch.cuda.stream(opt):   # (the discriminator's pass 2 read its old copies until now)
         opt.wait_stream(main)
         self._operand_group(D, None, ctx_d.dtype).prep(D.store.version)
@@ -394,10 +407,10 @@ class GAN(gan_manager.GANManager):
     elif sync is None:
       ctx_g.backward()
       G.spectral.backward_fixup(dots_only=FUSED_SN_CLIP)
-      g_norm = self.g_optimizer.clip_gradients(GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP).clone()
-      d_norm = self.d_optimizer.clip_gradients(GRAD_CLIP_NORM).clone()
-      self.g_optimizer.apply_gradients(group, R, ema_theta, ema_omd)
-      self.d_optimizer.apply_gradients(group, R)
+      self._update_all(self.g_optimizer, FUSED_SN_CLIP, ema_theta, ema_omd)
+      g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
+      self._update_all(self.d_optimizer, False, None, 0.0)
+      d_norm = self.d_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
     else:
       # a module's gradients are fixed up, clipped and handed to the side stream as soon as
       # the backward pass leaves it; the all-reduce overlaps the rest of the backward pass
@@ -405,14 +418,18 @@ class GAN(gan_manager.GANManager):
         if name not in self._g_segments:
           return
         t0, t1, e0, e1 = self._g_segments[name]
+        nn.flush_wgrad_reduces(ctx_g)
         G.spectral.backward_fixup(prefix=G.SEGMENTS[name], dots_only=FUSED_SN_CLIP)
         self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP)
         sync.reduce_range(G.store.grad, e0, e1)
       ctx_g.on_segment = segment_done
       ctx_g.after_collective = sync.pump
+      if DEFER_WGRAD_REDUCE:
+        ctx_g.wgrad_defer = []
       ctx_g.backward()
       ctx_g.on_segment = None
       ctx_g.after_collective = None
+      ctx_g.wgrad_defer = None
       g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
       sync.finish()
       self.g_optimizer.apply_gradients(group, 1, ema_theta, ema_omd)
@@ -446,6 +463,18 @@ class GAN(gan_manager.GANManager):
     self.metrics['gen/wc_loss'].update_state(wc_loss)
     self.metrics['gen/grad_norm'].update_state(g_norm)
 
+  def _update_all(self, opt, fused_sn, ema_theta, ema_omd):
+    """One replica: per-tensor clip + Adam (+ EMA) over a model's whole arena -- in one pass
+    (AdamState.clip_apply) unless switched off or a test hook wants the clipped arena."""
+    nt = len(opt.model.store.trainable_names)
+    opt.begin_step()
+    if not (FUSED_CLIP_ADAM and opt.clip_apply(0, nt, GRAD_CLIP_NORM, fused_sn, ema_theta, ema_omd)):
+      opt.iterations -= 1   # (apply_gradients advances the counter itself)
+      opt.clip_gradients(GRAD_CLIP_NORM, fused_sn=fused_sn)
+      opt.apply_gradients(None, 1, ema_theta, ema_omd)
+    else:
+      opt.end_step()
+
   def _set_input_grad(self, x_all, flag):
     x_all.requires_grad = flag
     for v in getattr(self.discriminator, '_scale_inputs', []):
@@ -475,8 +504,7 @@ class GAN(gan_manager.GANManager):
     D.spectral.backward_fixup()
     sync = self._grad_sync()
     if sync is None:
-      self.d_optimizer.clip_gradients(GRAD_CLIP_NORM)
-      self.d_optimizer.apply_gradients(group, R)
+      self._update_all(self.d_optimizer, False, None, 0.0)
     else:
       self._sync_discriminator(sync)
       sync.finish()

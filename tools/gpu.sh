@@ -1,0 +1,103 @@
+#!/bin/bash
+# One parameterised script for every GPU-box job of a round (replaces the per-experiment one-offs):
+#   gpurun -- 'bash tools/gpu.sh <task> [args] [-- <task> [args] ...]'
+# tasks:
+#   tests [pytest args]         GPU suite (default: whole suite), log in gpurun_out/pytest_gpu.log
+#   smoke                       __graft_entry__.smoke()
+#   bench [bench.py args]       default bench line -> gpurun_out/bench_default.log
+#   ab 'ENV=v ENV=v' ...        A/B of the gan_step bench under env settings (baseline first), 2 reps
+#   abwarp 'ENV=v' ...          the same for --workload warp (random and room depth)
+#   prof_step TAG [ENV=v ...]   rocprofv3 kernel stats of the default bench -> gpurun_out/TAG_kernel_stats.csv
+#   prof_warp TAG               kernel stats of the warp bench, random + room depth
+#   pmc_conv TAG "SHAPE"        MFMA-busy / FETCH / WRITE counters of tools/one_conv.py SHAPE (3 passes)
+#   pmc_warp TAG                FETCH / WRITE counters of the warp kernels (2 passes)
+#   py <file.py> [args]         any python tool
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+ulimit -c 0
+mkdir -p gpurun_out
+line() { python -c "import json,sys
+d=json.loads(sys.stdin.readline()); r=d['roofline']
+print('ms/step %.2f value %.3f frac %.4f' % (d['ms_per_step'], d['value'], r['frac']), 'in_step %.4f' % r['frac_in_step'] if 'frac_in_step' in r else '')"; }
+task_tests() {
+  SECONDS=0
+  if [ $# -eq 0 ]; then set -- tests; fi
+  timeout 3000 python -m pytest "$@" -m gpu -x -q --durations=10 > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$? elapsed $SECONDS s"; tail -22 gpurun_out/pytest_gpu.log | cut -c1-200
+}
+task_smoke() {
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
+  echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log
+}
+task_bench() {
+  SECONDS=0
+  timeout 1200 python bench.py "$@" > gpurun_out/bench_default.log 2> gpurun_out/bench_default.err
+  echo "bench rc=$? elapsed $SECONDS s"; tail -1 gpurun_out/bench_default.log | cut -c1-7000; tail -3 gpurun_out/bench_default.err | cut -c1-300
+}
+task_ab() {
+  for rep in 1 2; do
+    for v in "SE3DS_NOP=1" "$@"; do
+      echo "== $v"
+      env $v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch-max --no-warp --no-shipped 2>gpurun_out/ab.err | line || tail -5 gpurun_out/ab.err
+    done
+  done
+}
+task_abwarp() {
+  for rep in 1 2; do
+    for v in "SE3DS_NOP=1" "$@"; do
+      for d in random room; do
+        echo "== $v ($d)"
+        env $v timeout 300 python bench.py --workload warp --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline 2>gpurun_out/ab.err | python -c "import json,sys
+d=json.loads(sys.stdin.readline()); r=d['roofline']
+print('us/render %.1f frac %.4f step_ms %.4f' % (1e3*r['ms_per_launch'], r['frac'], d['ms_per_step']))" || tail -5 gpurun_out/ab.err
+      done
+    done
+  done
+}
+task_prof_step() {
+  local tag=$1; shift
+  rm -rf gpurun_out/prof_tmp
+  local note="$* rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped   (3 warm-up + 10 timed + 1 instrumented train_g_d step = 14 steps; model build kernels included)"
+  ( for v in "$@"; do export "$v"; done
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o gan -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped > gpurun_out/prof_$tag.log 2>&1 )
+  python tools/rocpd_summary.py gpurun_out/prof_tmp/gan_results.db gpurun_out/${tag}_kernel_stats.csv "$note"
+  tail -1 gpurun_out/prof_$tag.log | cut -c1-400
+  head -24 gpurun_out/${tag}_kernel_stats.csv | cut -c1-160; tail -1 gpurun_out/${tag}_kernel_stats.csv
+  rm -rf gpurun_out/prof_tmp
+}
+task_prof_warp() {
+  local tag=$1
+  for d in random room; do
+    rm -rf gpurun_out/prof_tmp
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o warp -- python bench.py --workload warp --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
+    python tools/rocpd_summary.py gpurun_out/prof_tmp/warp_results.db gpurun_out/${tag}_warp_${d}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload warp --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline"
+    head -9 gpurun_out/${tag}_warp_${d}_kernel_stats.csv | cut -c1-150
+  done
+  rm -rf gpurun_out/prof_tmp
+}
+task_pmc_conv() {
+  local tag=$1 shape="$2"
+  local st=$(echo $shape | tr ' ' '_')
+  rm -rf gpurun_out/pmc_tmp_*
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d gpurun_out/pmc_tmp_a -o pmc -- python tools/one_conv.py $shape > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_tmp_f -o pmc -- python tools/one_conv.py $shape > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_tmp_w -o pmc -- python tools/one_conv.py $shape > /dev/null 2>&1
+  python tools/pmc_summary.py gpurun_out/${tag}_conv_pmc_$st.json --source=se3ds_amd/csrc/conv.hip "gpurun_out/pmc_tmp_a/*.db" "gpurun_out/pmc_tmp_f/*.db" "gpurun_out/pmc_tmp_w/*.db" 'igemm|wgrad'
+  rm -rf gpurun_out/pmc_tmp_*
+}
+task_pmc_warp() {
+  local tag=$1
+  rm -rf gpurun_out/pmc_tmp_*
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_tmp_f -o pmc -- python bench.py --workload warp --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_tmp_w -o pmc -- python bench.py --workload warp --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+  python tools/pmc_summary.py gpurun_out/${tag}_warp_pmc.json --source=se3ds_amd/csrc/geom.hip "gpurun_out/pmc_tmp_f/*.db" "gpurun_out/pmc_tmp_w/*.db" 'splat|unproject'
+  rm -rf gpurun_out/pmc_tmp_*
+}
+task_py() { timeout 1500 python "$@"; }
+args=()
+run_task() { if [ ${#args[@]} -gt 0 ]; then local t=${args[0]}; echo "##### $t ${args[*]:1}"; "task_$t" "${args[@]:1}"; fi; args=(); }
+for a in "$@"; do
+  if [ "$a" == "--" ]; then run_task; else args+=("$a"); fi
+done
+run_task
+du -sh gpurun_out | cut -c1-40
