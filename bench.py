@@ -187,7 +187,7 @@ def bench_warp(args, rank, world, dev):
 
   traffic, traffic_detail = (None, None)
   if (h, views, args.warp_depth) == (1024, 2, 'random'):
-    traffic, traffic_detail = _pmc_traffic('r03_warp_pmc.json', ('splat_pack',))
+    traffic, traffic_detail = _pmc_traffic('r04_warp_pmc.json', ('splat_sort',))
   out = {
       'metric': 'panoramas/sec (2-view unproject + 1 target render, 1024x2048 equirect)',
       'value': world * args.steps / dt, 'unit': 'panoramas/sec', 'n_gpus': world,
@@ -196,7 +196,8 @@ def bench_warp(args, rank, world, dev):
       'data': 'synthetic',
       'config': {'workload': f'warp cfg5 {h}x{w} V={views} (replicas only)' +
                              ('' if args.warp_depth == 'random' else f', {args.warp_depth} depth')},
-      'roofline': {'bound': 'hbm', 'kernel': 'project+splat (splat_pack_*: count, column scan, permute, per-tile resolve, sink)',
+      'roofline': {'bound': 'hbm', 'kernel': 'project+splat (splat_sort_kernel: pack + sort each chunk by target row; '
+                             'splat_sort_resolve_kernel: gather, z-min, features, outputs, sink)',
                    'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                    'traffic_detail': traffic_detail,

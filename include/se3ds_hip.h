@@ -102,6 +102,12 @@ int se3ds_feats_byte_range(const void* feats, int feat_dtype, int64_t count, flo
  * valid point violated the SE3DS_FEAT_BYTE_RANGE promise, else 0. */
 int se3ds_splat_promise_broken(const void* workspace, int n, int64_t m, uint32_t* broken_out,
                                void* stream);
+/* The same verdict, STICKY over calls: header word 3 of a splat workspace (byte 12) is OR-ed with 1
+ * by every packed / sorted splat that meets a feature outside [0, 255] under the promise, and is
+ * never cleared by the library.  The caller zeroes the first 256 bytes of a workspace once, and
+ * reads the flag whenever convenient (e.g. every n-th call, asynchronously): a broken promise is
+ * then detected late, never missed.  clear != 0 resets the word after reading it. */
+int se3ds_splat_promise_sticky(void* workspace, uint32_t* broken_out, int clear, void* stream);
 
 /* The same over the first `m` points of a preallocated point-cloud MEMORY of `capacity` points
  * per image -- xyz1 (N,4,capacity), feats (N,capacity,C) -- so that a trajectory appends frames in

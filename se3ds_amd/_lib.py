@@ -30,6 +30,7 @@ _SIGS = {
     'se3ds_project_to_feat': (c_int, [c_p, c_p, c_int, c_int, c_i64, c_int, c_int, c_int, c_f, c_f,
                                       c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
     'se3ds_splat_debug_indices': (c_int, [c_p, c_int, c_i64, c_p, c_p, c_p]),
+    'se3ds_splat_promise_sticky': (c_int, [c_p, c_p, c_int, c_p]),
     'se3ds_feats_byte_range': (c_int, [c_p, c_int, c_i64, c_f, c_p, c_p]),
     'se3ds_splat_promise_broken': (c_int, [c_p, c_int, c_i64, c_p, c_p]),
     'se3ds_debug_fast_fxy': (c_int, [c_p, c_i64, c_int, c_int, c_p, c_p, c_p, c_p]),

@@ -7,7 +7,9 @@
 // Reference semantics: utils/pano_utils.py, utils/point_cloud_utils.py (see the per-entry
 // citations in include/se3ds_hip.h).  Index math lives in include/se3ds_geom_math.h and is
 // shared bit-for-bit with the CPU oracle.  Built with -ffp-contract=off.
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 #include "common.h"
 #include "../../include/se3ds_geom_math.h"
@@ -122,6 +124,11 @@ unproject_perspective_kernel(const int32_t* __restrict__ feats, const float* __r
 //   address serialises at ~12 ns each -- 200-600 us at 4 M points; per-block partials plus a
 //   one-block reduce cost ~3 us);  then int32 idx[N*M], float z[N*M].
 constexpr int kMaxSinkBlocks = 2048;
+// Word 3 of the header (bytes 12..15, between sink_z and the sink features) is STICKY: the
+// packed / sorted splats OR a 1 into it when an int32 feature breaks the caller's
+// SE3DS_FEAT_BYTE_RANGE promise and nothing in the library ever clears it -- the owner of the
+// workspace zeroes the header once and reads it whenever convenient (se3ds_splat_promise_sticky).
+constexpr int kPromiseStickyWord = 3;
 struct SplatWs {
   uint32_t* sink_z;
   uint32_t* sink_feat;
@@ -1747,7 +1754,10 @@ splat_pack_count_kernel(const float* __restrict__ coords, const float* __restric
     const uint32_t v = wave_max_u32(smax[k]);
     if ((threadIdx.x & 63) == 0) s_red[1 + k][threadIdx.x >> 6] = v;
   }
-  if ((threadIdx.x & 63) == 0 && bad != 0u) atomicOr(&pw.ctl[1], 1u);
+  if ((threadIdx.x & 63) == 0 && bad != 0u) {
+    atomicOr(&pw.ctl[1], 1u);
+    atomicOr(&ws.sink_z[kPromiseStickyWord], 1u);   // sticky: survives later calls (host-cleared)
+  }
   __syncthreads();
   const int part = blockIdx.y * gridDim.x + blockIdx.x;
   if (threadIdx.x == 0) {
@@ -2160,6 +2170,10 @@ feats_byte_range_kernel(const T* __restrict__ f, int64_t count, float void_class
 }
 
 __global__ void splat_promise_kernel(PackWs pw, uint32_t* out) { out[0] = pw.ctl[1] != 0u ? 1u : 0u; }
+__global__ void splat_promise_sticky_kernel(uint32_t* hdr, uint32_t* out, int clear) {
+  out[0] = hdr[kPromiseStickyWord] != 0u ? 1u : 0u;
+  if (clear) hdr[kPromiseStickyWord] = 0u;
+}
 
 template <typename T, bool EQUIRECT>
 int launch_splat_packed(const float* coords, const float* offset, const T* feats, int n, int64_t m,
@@ -2216,6 +2230,749 @@ int launch_splat_packed(const float* coords, const float* offset, const T* feats
   return check_launch("splat(packed)");
 }
 
+// ------------------------------------------------------ sorted-chunk splat (round 4, two kernels)
+// The packed path above still moves 2.4x its algorithmic bytes (PMC): the point-order round trip of
+// the records (10 B per point out of P1, back into P3), an 8 MB chunk x tile histogram that P2 reads
+// and rewrites, a scattered 8-byte permutation, a separate sink launch.  Here the permutation never
+// touches HBM:
+//   S1 sort    : as P1 (coordinates + features read once, fp32 screen / dense binary64 queue), but a
+//                workgroup keeps its chunk's records in REGISTERS until the chunk's histogram over
+//                the target SUPERTILES (128 x kSY pixels) is complete, places them in LDS in
+//                supertile order and writes the chunk out with full-line stores: 8-byte records
+//                (9-bit pixel, 31-bit z, 3 x 8-bit features, the format above) + one byte with the
+//                pixel's upper bits (a supertile has 4096 / 8192 pixels), and one run descriptor
+//                (offset, count) per (supertile, chunk).
+//   S2 resolve : one workgroup per supertile GATHERS its runs from all chunks (a flat record index
+//                is mapped to (chunk, offset) by a binary search over the run prefix in LDS, so
+//                consecutive lanes read consecutive records whatever the run lengths are), z-min
+//                and byte-wise feature max in LDS (one packed word per pixel, CAS), outputs
+//                written directly.  A supertile with more than `slice` records is cut into 2 / 4 / 8
+//                bands of rows (every band reads all runs and keeps its rows -- bit-identical).  The
+//                sink (flat pixel 0 collects every invalid and occluded point) is folded by the LAST
+//                workgroup to finish: every workgroup ends with one ticket atomic behind its sink
+//                atomics; pixel 0 is published through atomics by its owner and written only by the
+//                last workgroup (no fences, no spinning: returned device-scope atomics are performed
+//                memory-side before the ticket is taken).
+// Traffic per cfg5 render: 100 MB in + 38 MB of records out, 38 MB in + 42 MB out = 218 MB for 159 MB
+// algorithmic (the packed path: ~310 nominal, 382 measured).  min / max do not depend on the record
+// order: bit-identical to every other path.
+constexpr int kSMaxPx = 2048;            // pixels per supertile (LDS tile of the resolve; 11-bit pixel)
+constexpr int kSThreads = 512;           // S1 workgroup
+constexpr int kSQueue = 1024;            // S1: points waiting for the binary64 path (2 per thread)
+constexpr int kSMaxSuper = 2048;         // supertiles per image (S1 LDS histogram, 11-bit field)
+constexpr int kSMaxChunks = 4096;        // chunks per image (S2 LDS run prefix)
+constexpr int kRThreads = 512;           // S2 workgroup
+constexpr int kRStash = 12;              // S2: records per thread and batch (6 144 per workgroup: an average
+                                         // supertile of cfg5 holds 4 096, its records stay in registers)
+constexpr uint32_t kSMetaNone = 0xffffffffu, kSMetaPending = 0xfffffffeu;
+
+struct SortWs {
+  uint32_t* ctl;      // [16]: 0 ticket, 1 promise violations (same slot as PackWs), 4.. pixel 0 (z, C feature words)
+  uint32_t* fpart2;   // [kSinkSlots][C] ordered max feature of the occluded points
+  uint32_t* runs;     // [n * nsuper][chunks]  offset << 16 | count
+  uint64_t* rec;      // [n * chunks][chunk_pts]
+  uint8_t* hi;        // [n * chunks][chunk_pts]
+  int chunks;         // per image
+  int chunk_pts;
+};
+// Supertile = `rows` FULL-WIDTH image rows (rows x width <= 2048 pixels; images wider than 2048 are
+// cut into column strips).  The shape matters: the pole rows of every SOURCE view (thousands of
+// pixels looking the same way) land on a near-vertical line of the target, and 32 x 128 supertiles
+// put 30 000 (random depth) to 86 000 (smooth room) records into the supertiles on that line against
+// a mean of 8 000 -- one workgroup then runs 4-10x longer than the rest.  A line crosses a row
+// once: full-row supertiles hold at most 1.35x (random) / 2.3x (room) the mean.
+struct SortGeom {
+  int pts, chunk_pts, chunks, super_w, rlog, super_x, super_y, nsuper, px;
+};
+inline int sort_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+inline SortGeom sort_geom(int64_t m, int height, int width, int pts_forced = 0) {
+  static const int pts_env = sort_env("SE3DS_SPLAT_PTS", 16) == 8 ? 8 : 16;
+  SortGeom g;
+  g.pts = pts_forced ? pts_forced : pts_env;
+  g.chunk_pts = kSThreads * g.pts;
+  g.chunks = (int)ceil_div(m > 0 ? m : 1, (int64_t)g.chunk_pts);
+  g.super_w = width <= kSMaxPx ? width : kSMaxPx;
+  g.rlog = 0;
+  while ((2 << g.rlog) * g.super_w <= kSMaxPx && (1 << g.rlog) < height) ++g.rlog;
+  g.super_x = ceil_div(width, g.super_w);
+  g.super_y = ceil_div(height, 1 << g.rlog);
+  g.nsuper = g.super_x * g.super_y;
+  g.px = g.super_w << g.rlog;
+  return g;
+}
+inline size_t sort_ws_bytes(int n, int64_t m, int height, int width) {
+  size_t worst = 0;
+  for (int pts = 8; pts <= 16; pts += 8) {   // (independent of the A/B environment switch)
+    const SortGeom g = sort_geom(m, height, width, pts);
+    const size_t b = 64 + align16(4 * kSinkSlots * kPMaxChannels) +
+                     align16(4 * (size_t)n * g.nsuper * g.chunks) +
+                     align16(8 * (size_t)n * g.chunks * g.chunk_pts) +
+                     align16((size_t)n * g.chunks * g.chunk_pts);
+    worst = b > worst ? b : worst;
+  }
+  return worst;
+}
+inline SortWs carve_sort_ws(void* base, int n, const SortGeom& g) {
+  char* p = (char*)base;
+  SortWs w;
+  w.ctl = (uint32_t*)p; p += 64;
+  w.fpart2 = (uint32_t*)p; p += align16(4 * kSinkSlots * kPMaxChannels);
+  w.runs = (uint32_t*)p; p += align16(4 * (size_t)n * g.nsuper * g.chunks);
+  w.rec = (uint64_t*)p; p += align16(8 * (size_t)n * g.chunks * g.chunk_pts);
+  w.hi = (uint8_t*)p;
+  w.chunks = g.chunks;
+  w.chunk_pts = g.chunk_pts;
+  return w;
+}
+
+// S1.  PTS points per thread (8 or 16).  Supertile of pixel (u, v): (v >> rlog, u / super_w).
+template <typename T, bool EQUIRECT, int C, bool DEBUG, int PTS>
+__global__ void __launch_bounds__(kSThreads, 4)   // (<= 128 VGPRs: two workgroups per CU)
+splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
+                  const T* __restrict__ feats, int64_t m, int64_t ld, int height, int width,
+                  uint64_t wmagic, float input_void, int nsuper, int super_x, int super_w, int rlog,
+                  int vec, SplatWs ws, SortWs sw) {
+  constexpr int kChunk = kSThreads * PTS;
+  constexpr int kIter = PTS / kPPts;
+  constexpr int kQPer = kSQueue / kSThreads;
+  extern __shared__ uint64_t s_dyn64[];          // [kChunk] records, [kChunk] hi bytes, counts, offsets
+  uint64_t* s_rec = s_dyn64;
+  uint8_t* s_hi = reinterpret_cast<uint8_t*>(s_dyn64 + kChunk);
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_hi + kChunk);   // [nsuper] counts, then offsets
+  __shared__ uint16_t s_queue[kSQueue];   // (point offsets inside the chunk: < 8192)
+  __shared__ uint32_t s_qn;
+  __shared__ uint32_t s_w[kSThreads / 64];
+  const int b = blockIdx.y;
+  for (int t = threadIdx.x; t < nsuper; t += kSThreads) s_cnt[t] = 0u;
+  if (threadIdx.x == 0) s_qn = 0u;
+  if (blockIdx.x == 0 && b == 0) {   // state of the resolve pass (this kernel runs first)
+    if (threadIdx.x < 16) sw.ctl[threadIdx.x] = 0u;
+    if ((int)threadIdx.x < kSinkSlots * C) sw.fpart2[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  const float* X = coords + (int64_t)b * 4 * ld;
+  const T* F = feats + (int64_t)b * ld * C;
+  float ox = 0.f, oy = 0.f, oz = 0.f;
+  if (EQUIRECT && offset) {
+    ox = offset[b * 3 + 0];
+    oy = offset[b * 3 + 1];
+    oz = offset[b * 3 + 2];
+  }
+  uint32_t sink = 0xffffffffu;
+  uint32_t smax[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) smax[k] = 0u;
+  uint32_t bad = 0u;
+  const int64_t lo = (int64_t)blockIdx.x * kChunk, hi = lo + kChunk < m ? lo + kChunk : m;
+
+  // a point whose pixel (u, v) is known: histogram rank + record; invalid: sink partials
+  auto emit = [&](bool valid, int u, int v, float pz, const int32_t (&f)[C], uint64_t* rec,
+                  uint32_t* meta) {
+    if (valid) {
+      const int sy_ = v >> rlog, sx_ = super_x == 1 ? 0 : u / super_w;
+      const uint32_t st = (uint32_t)(sy_ * super_x + sx_);
+      const uint32_t pix = (uint32_t)((v - (sy_ << rlog)) * super_w + (u - sx_ * super_w));
+      const uint32_t rank = atomicAdd(&s_cnt[st], 1u);
+      uint32_t fb[3] = {0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        fb[k] = (uint32_t)f[k] & 255u;
+        bad |= (uint32_t)f[k] >> 8;   // the byte-range promise (negative or > 255)
+      }
+      *rec = pack_rec(pix & 511u, pz, fb[0], fb[1], fb[2]);
+      *meta = st | (rank << 11) | ((pix >> 9) << 25);   // 11-bit supertile, 14-bit rank, pixel bits 9..
+    } else {
+      if (pz == pz) {
+        const uint32_t o = se3ds_f32_to_ordered(pz);
+        sink = o < sink ? o : sink;
+      }
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const uint32_t o = se3ds_f32_to_ordered((float)f[k]);
+        smax[k] = o > smax[k] ? o : smax[k];
+      }
+      *rec = 0ull;
+      *meta = kSMetaNone;
+    }
+  };
+  auto feat_valid = [&](const int32_t (&f)[C]) {
+    int v = 1;
+#pragma unroll
+    for (int k = 0; k < C; ++k) v &= ((float)f[k] != input_void);
+    return v;
+  };
+  auto exact = [&](int64_t i, float x, float y, float z, const int32_t (&f)[C], uint64_t* rec,
+                   uint32_t* meta) {
+    float px, py, pz;
+    if (EQUIRECT) {
+      se3ds_equirect_project(x, y, z, &px, &py, &pz);
+    } else {
+      px = x;
+      py = y;
+      pz = z;
+    }
+    const int32_t idx = se3ds_splat_index(px, py, pz, width, height, feat_valid(f));
+    int u = 0, v = 0;
+    if (idx >= 0) {
+      v = (int)(((uint64_t)(uint32_t)idx * wmagic) >> 40);
+      u = idx - v * width;
+    }
+    emit(idx >= 0, u, v, pz, f, rec, meta);
+    if (DEBUG) {
+      ws.idx[(int64_t)b * m + i] = idx;
+      ws.z[(int64_t)b * m + i] = pz;
+    }
+  };
+  auto exact_at = [&](int64_t i, uint64_t* rec, uint32_t* meta) {   // reloads point i
+    float x = X[i], y = X[ld + i], z = X[2 * ld + i];
+    if (EQUIRECT && offset) {
+      x = x - ox;
+      y = y - oy;
+      z = z - oz;
+    }
+    int32_t f[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) f[k] = (int32_t)F[i * C + k];
+    exact(i, x, y, z, f, rec, meta);
+  };
+  auto load_group = [&](int64_t i0, float (&x)[kPPts], float (&y)[kPPts], float (&z)[kPPts],
+                        int32_t (&f)[kPPts][C]) {
+    const bool full = i0 + kPPts <= hi;
+    if (full && vec) {
+      const float4 vx = *reinterpret_cast<const float4*>(X + i0);
+      const float4 vy = *reinterpret_cast<const float4*>(X + ld + i0);
+      const float4 vz = *reinterpret_cast<const float4*>(X + 2 * ld + i0);
+      x[0] = vx.x; x[1] = vx.y; x[2] = vx.z; x[3] = vx.w;
+      y[0] = vy.x; y[1] = vy.y; y[2] = vy.z; y[3] = vy.w;
+      z[0] = vz.x; z[1] = vz.y; z[2] = vz.z; z[3] = vz.w;
+      int32_t flat[kPPts * C];
+#pragma unroll
+      for (int q = 0; q < C; ++q) {
+        int32_t o[4];
+        Feat4<T>::load(F + i0 * C + 4 * q, true, o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) flat[4 * q + e] = o[e];
+      }
+#pragma unroll
+      for (int p = 0; p < kPPts; ++p)
+#pragma unroll
+        for (int k = 0; k < C; ++k) f[p][k] = flat[p * C + k];
+    } else {
+#pragma unroll
+      for (int p = 0; p < kPPts; ++p) {
+        const int64_t i = i0 + p < hi ? i0 + p : hi - 1;   // (the tail repeats the last point)
+        x[p] = X[i];
+        y[p] = X[ld + i];
+        z[p] = X[2 * ld + i];
+#pragma unroll
+        for (int k = 0; k < C; ++k) f[p][k] = (int32_t)F[i * C + k];
+      }
+    }
+  };
+
+  // ---- phase 1: every point's record and (supertile, rank) stay in registers
+  uint64_t rec[PTS];
+  uint32_t meta[PTS];
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int64_t i0 = lo + ((int64_t)it * kSThreads + threadIdx.x) * kPPts;
+#pragma unroll
+    for (int p = 0; p < kPPts; ++p) {
+      rec[it * kPPts + p] = 0ull;
+      meta[it * kPPts + p] = kSMetaNone;
+    }
+    if (i0 < hi) {
+      float x[kPPts], y[kPPts], z[kPPts];
+      int32_t f[kPPts][C];
+      load_group(i0, x, y, z, f);
+#pragma unroll
+      for (int p = 0; p < kPPts; ++p) {
+        if (i0 + p >= hi) continue;
+        float px = x[p], py = y[p], pzz = z[p];
+        if (EQUIRECT && offset) {
+          px = px - ox;
+          py = py - oy;
+          pzz = pzz - oz;
+        }
+        if (EQUIRECT) {
+          int u = 0, v = 0, ok = 0;
+          float pz;
+          if (se3ds_equirect_uv_fast(px, py, pzz, width, height, feat_valid(f[p]), &u, &v, &ok, &pz)) {
+            emit(ok != 0, u, v, pz, f[p], &rec[it * kPPts + p], &meta[it * kPPts + p]);
+            if (DEBUG) {
+              ws.idx[(int64_t)b * m + i0 + p] = ok ? v * width + u : -1;
+              ws.z[(int64_t)b * m + i0 + p] = pz;
+            }
+          } else {
+            // undecided (~2.5 %): queued for the dense binary64 pass below
+            meta[it * kPPts + p] = kSMetaPending;
+            const uint32_t slot = atomicAdd(&s_qn, 1u);
+            if (slot < (uint32_t)kSQueue) s_queue[slot] = (uint16_t)(i0 + p - lo);
+          }
+        } else {
+          exact(i0 + p, px, py, pzz, f[p], &rec[it * kPPts + p], &meta[it * kPPts + p]);
+        }
+      }
+    }
+  }
+  // ---- phase 2: the undecided points, densely (their records stay with the thread that ran them)
+  uint64_t qrec[kQPer];
+  uint32_t qmeta[kQPer];
+#pragma unroll
+  for (int r = 0; r < kQPer; ++r) {
+    qrec[r] = 0ull;
+    qmeta[r] = kSMetaNone;
+  }
+  if (EQUIRECT) {
+    __syncthreads();
+    const uint32_t qn = s_qn;
+    if (qn <= (uint32_t)kSQueue) {
+#pragma unroll
+      for (int r = 0; r < kQPer; ++r) {
+        const uint32_t q = threadIdx.x + r * kSThreads;
+        if (q < qn) exact_at(lo + s_queue[q], &qrec[r], &qmeta[r]);
+      }
+    } else {
+      // queue overflow (> 12 % undecided: lattice clouds): every thread takes its own marked points
+#pragma unroll
+      for (int j = 0; j < PTS; ++j) {
+        if (meta[j] != kSMetaPending) continue;
+        const int64_t i = lo + ((int64_t)(j / kPPts) * kSThreads + threadIdx.x) * kPPts + (j % kPPts);
+        exact_at(i, &rec[j], &meta[j]);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: exclusive scan of the supertile counts (<= 2048: four per thread), run descriptors
+  uint32_t all;
+  {
+    const int t0 = 4 * threadIdx.x;
+    uint32_t c[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      c[q] = t0 + q < nsuper ? s_cnt[t0 + q] : 0u;
+      sum += c[q];
+    }
+    uint32_t ex = block_excl_scan_u32<kSThreads / 64>(sum, s_w, &all);
+    uint32_t* R = sw.runs + ((int64_t)b * nsuper) * sw.chunks + blockIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (t0 + q < nsuper) {
+        s_cnt[t0 + q] = ex;   // (in place: every count was read before the scan's barriers)
+        R[(int64_t)(t0 + q) * sw.chunks] = (ex << 16) | c[q];
+      }
+      ex += c[q];
+    }
+  }
+  {
+    __syncthreads();
+    // ---- phase 4: placement in LDS, then full-line stores of the chunk
+    auto place = [&](uint64_t r, uint32_t mt) {
+      if (mt >= kSMetaPending) return;
+      const uint32_t pos = s_cnt[mt & 2047u] + ((mt >> 11) & 16383u);
+      s_rec[pos] = r;
+      s_hi[pos] = (uint8_t)(mt >> 25);
+    };
+#pragma unroll
+    for (int j = 0; j < PTS; ++j) place(rec[j], meta[j]);
+#pragma unroll
+    for (int r = 0; r < kQPer; ++r) place(qrec[r], qmeta[r]);
+    __syncthreads();
+    uint64_t* G = sw.rec + ((int64_t)b * sw.chunks + blockIdx.x) * kChunk;
+    uint8_t* H = sw.hi + ((int64_t)b * sw.chunks + blockIdx.x) * kChunk;
+    for (uint32_t j = 2 * threadIdx.x; j < all; j += 2 * kSThreads)
+      *reinterpret_cast<uint4*>(G + j) = *reinterpret_cast<const uint4*>(s_rec + j);
+    for (uint32_t j = 16 * threadIdx.x; j < all; j += 16 * kSThreads)
+      *reinterpret_cast<uint4*>(H + j) = *reinterpret_cast<const uint4*>(s_hi + j);
+  }
+  // ---- sink partials of the invalid points (as the packed path)
+  __shared__ uint32_t s_red[1 + C][kSThreads / 64];
+  sink = wave_min_u32(sink);
+  bad = wave_max_u32(bad);
+  if ((threadIdx.x & 63) == 0) s_red[0][threadIdx.x >> 6] = sink;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const uint32_t v = wave_max_u32(smax[k]);
+    if ((threadIdx.x & 63) == 0) s_red[1 + k][threadIdx.x >> 6] = v;
+  }
+  if ((threadIdx.x & 63) == 0 && bad != 0u) {
+    atomicOr(&sw.ctl[1], 1u);
+    atomicOr(&ws.sink_z[kPromiseStickyWord], 1u);
+  }
+  __syncthreads();
+  const int part = blockIdx.y * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0) {
+    uint32_t v = s_red[0][0];
+    for (int i = 1; i < kSThreads / 64; ++i) v = s_red[0][i] < v ? s_red[0][i] : v;
+    ws.zpart[part] = v;
+  }
+  if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + C) {
+    const int k = threadIdx.x - 64;
+    uint32_t v = 0u;
+    for (int i = 0; i < kSThreads / 64; ++i) v = s_red[1 + k][i] > v ? s_red[1 + k][i] : v;
+    ws.fpart[(int64_t)part * C + k] = v;
+  }
+}
+
+// byte-wise max of two words of three feature bytes
+__device__ __forceinline__ uint32_t bytemax3(uint32_t a, uint32_t b) {
+  const uint32_t x0 = a & 0xffu, y0 = b & 0xffu, x1 = a & 0xff00u, y1 = b & 0xff00u;
+  const uint32_t x2 = a & 0xff0000u, y2 = b & 0xff0000u;
+  return (x0 > y0 ? x0 : y0) | (x1 > y1 ? x1 : y1) | (x2 > y2 ? x2 : y2);
+}
+
+// S2.  One workgroup per (image, supertile).
+template <int C>
+__global__ void __launch_bounds__(kRThreads)
+splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int super_w, int rlog,
+                          float depth_scale, float output_void, float mask_void,
+                          float* __restrict__ depth, float* __restrict__ feat,
+                          float* __restrict__ mask, SplatWs ws, SortWs sw, uint32_t zpart_count) {
+  const int kPx = super_w << rlog;
+  extern __shared__ uint32_t s_dyn[];   // [kPx] z, [kPx] feature words, [chunks + 1] run prefix, [chunks] run base
+  uint32_t* s_z = s_dyn;
+  uint32_t* s_f = s_dyn + kPx;
+  uint32_t* s_cpre = s_f + kPx;             // NON-EMPTY runs only: first flat record index (+ sentinel)
+  uint32_t* s_cbase = s_cpre + sw.chunks + 1;   // ... and the record number of the run's first record
+  __shared__ uint32_t s_w[kRThreads / 64];
+  __shared__ uint32_t s_c[C][kRThreads / 64];
+  __shared__ uint32_t s_flag;
+  __shared__ uint32_t s_q[kRStash * kRThreads / 64];   // first run of every 64-record block of a batch
+  const int chunks = sw.chunks;
+  const int bs = blockIdx.x;
+  const int b = bs / nsuper, st = bs - b * nsuper;
+  const int sy_ = st / super_x, sx_ = st - sy_ * super_x;
+  const bool first = bs == 0;   // holds flat pixel 0, which also receives the sink
+  // this supertile's runs, compacted to the non-empty ones (a smooth scene leaves most chunks
+  // without a record here), with their exclusive record prefix; total records
+  uint32_t total = 0, nnz = 0;
+  {
+    const uint32_t* R = sw.runs + (int64_t)bs * chunks;
+    for (int c0 = 0; c0 < chunks; c0 += kRThreads) {
+      const int c = c0 + threadIdx.x;
+      const uint32_t d = c < chunks ? R[c] : 0u;
+      const uint32_t cnt = d & 0xffffu;
+      uint32_t all, alln;
+      const uint32_t ex = block_excl_scan_u32<kRThreads / 64>(cnt, s_w, &all);
+      const uint32_t exn = block_excl_scan_u32<kRThreads / 64>(cnt ? 1u : 0u, s_w, &alln);
+      if (cnt) {
+        s_cpre[nnz + exn] = total + ex;
+        s_cbase[nnz + exn] = (uint32_t)c * (uint32_t)sw.chunk_pts + (d >> 16);
+      }
+      total += all;
+      nnz += alln;
+    }
+    if (threadIdx.x == 0) s_cpre[nnz] = total;   // sentinel: every walk below stops here
+  }
+  {
+    uint32_t sink_o = 0xffffffffu;
+    if (first) {
+      uint32_t v = 0xffffffffu;
+      for (uint32_t i = threadIdx.x; i < zpart_count; i += kRThreads) {
+        const uint32_t z = ws.zpart[i];
+        v = z < v ? z : v;
+      }
+      v = wave_min_u32(v);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+      __syncthreads();
+      for (int i = 0; i < kRThreads / 64; ++i) sink_o = s_w[i] < sink_o ? s_w[i] : sink_o;
+    }
+    const bool have_sink_z = sink_o != 0xffffffffu;
+    const float sink_z = se3ds_ordered_to_f32(sink_o);
+    for (int p = threadIdx.x; p < kPx; p += kRThreads) {
+      s_z[p] = __float_as_uint(depth_scale);
+      s_f[p] = 0u;
+    }
+    __syncthreads();
+    // flat record index j -> record number inside this image: run k with cpre[k] <= j < cpre[k + 1],
+    // record cbase[k] + (j - cpre[k]).  A binary search per RECORD made the LDS pipe the kernel's
+    // bottleneck (11 conflicted reads per record against ~1.4 atomics): one search per aligned block
+    // of 64 records (one wave iteration) gives the block's first run, and each lane walks forward
+    // from there -- a few reads of nearly the same words, broadcast within the wave.
+    int steps = 0;
+    while ((1u << steps) < (nnz ? nnz : 1u)) ++steps;
+    const uint64_t* RB = sw.rec + (int64_t)b * chunks * sw.chunk_pts;
+    const uint8_t* HB = sw.hi + (int64_t)b * chunks * sw.chunk_pts;
+    const uint32_t last = total ? total - 1u : 0u;
+    auto block_table = [&](uint32_t base) {   // s_q[blk] for the blocks of the batch starting at `base`
+      __syncthreads();                        // (the previous batch's walks are over)
+      if (threadIdx.x < kRStash * kRThreads / 64) {
+        uint32_t jb = base + 64u * threadIdx.x;
+        jb = jb < total ? jb : last;
+        int lo_ = 0, hi_ = (int)nnz - 1;
+        for (int it = 0; it < steps; ++it) {
+          const int mid = (lo_ + hi_ + 1) >> 1;
+          const bool le = s_cpre[mid] <= jb;
+          lo_ = le ? mid : lo_;
+          hi_ = le ? hi_ : mid - 1;
+        }
+        s_q[threadIdx.x] = (uint32_t)lo_;
+      }
+      __syncthreads();
+    };
+    // (the kRStash walks of a thread advance TOGETHER: three predicated steps cover the usual case
+    // with kRStash independent LDS reads in flight per step, a loop takes the stragglers)
+    auto locate_all = [&](const uint32_t (&j)[kRStash], uint32_t (&a)[kRStash]) {
+      uint32_t k[kRStash];
+#pragma unroll
+      for (int q = 0; q < kRStash; ++q) k[q] = s_q[(threadIdx.x >> 6) + q * (kRThreads / 64)];
+#pragma unroll
+      for (int stp = 0; stp < 3; ++stp) {
+        uint32_t nx[kRStash];
+#pragma unroll
+        for (int q = 0; q < kRStash; ++q) nx[q] = s_cpre[k[q] + 1];
+#pragma unroll
+        for (int q = 0; q < kRStash; ++q) k[q] += nx[q] <= j[q] ? 1u : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < kRStash; ++q)
+        while (s_cpre[k[q] + 1] <= j[q]) ++k[q];
+      uint32_t cb[kRStash], cp[kRStash];
+#pragma unroll
+      for (int q = 0; q < kRStash; ++q) {
+        cb[q] = s_cbase[k[q]];
+        cp[q] = s_cpre[k[q]];
+      }
+#pragma unroll
+      for (int q = 0; q < kRStash; ++q) a[q] = cb[q] + (j[q] - cp[q]);
+    };
+    // Both passes walk the records in BATCHES of kRStash per thread (kRStash x 512 per workgroup):
+    // all searches, then all 2 x kRStash loads, then the LDS work.  A supertile of average weight
+    // is one batch and its records stay in registers between the passes; heavy ones (the source
+    // views' pole rows pile up in a few supertiles of ANY target) stream their later batches a
+    // second time (L2 hits).
+    constexpr uint32_t kBatch = kRStash * kRThreads;
+    uint64_t sr[kRStash];
+    uint32_t sp[kRStash];
+    auto load_batch = [&](uint32_t base) {
+      uint32_t sa[kRStash];
+      block_table(base);
+      uint32_t jj[kRStash];
+#pragma unroll
+      for (int k = 0; k < kRStash; ++k) {
+        const uint32_t j = base + threadIdx.x + k * kRThreads;
+        jj[k] = j < total ? j : last;   // (out-of-range slots re-read the last record, unused)
+      }
+      locate_all(jj, sa);
+#pragma unroll
+      for (int k = 0; k < kRStash; ++k) {
+        sr[k] = RB[sa[k]];
+        sp[k] = (uint32_t)HB[sa[k]];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // all 2 x kRStash loads are issued before the first use
+#pragma unroll
+      for (int k = 0; k < kRStash; ++k) sp[k] = rec_pix(sr[k]) | (sp[k] << 9);
+    };
+    // pass A: z-min
+    for (uint32_t base = 0; base < total; base += kBatch) {
+      load_batch(base);
+#pragma unroll
+      for (int k = 0; k < kRStash; ++k) {
+        const uint32_t j = base + threadIdx.x + k * kRThreads;
+        if (j < total) atomicMin(&s_z[sp[k]], rec_zbits(sr[k]));   // valid => z > 0
+      }
+    }
+    __syncthreads();
+    // pass B: survivors (z < zmin + 0.1) max their features; the rest feed the sink
+    uint32_t smax[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) smax[k] = 0u;
+    auto passb = [&](uint64_t r, uint32_t pix) {
+      const float z = __uint_as_float(rec_zbits(r));
+      float zm = __uint_as_float(s_z[pix]);
+      if (first && pix == 0u && have_sink_z) zm = sink_z < zm ? sink_z : zm;
+      const uint32_t fw = (uint32_t)(r >> 32) & 0xffffffu;
+      if (z < zm + 0.1f) {
+        uint32_t old = s_f[pix];
+        while (true) {
+          const uint32_t nw = bytemax3(old, fw);
+          if (nw == old) break;
+          const uint32_t prev = atomicCAS(&s_f[pix], old, nw);
+          if (prev == old) break;
+          old = prev;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const uint32_t o = se3ds_f32_to_ordered((float)((fw >> (16 - 8 * k)) & 255u));
+          smax[k] = o > smax[k] ? o : smax[k];
+        }
+      }
+    };
+    // (the registers still hold the LAST batch of pass A: walk the batches backwards)
+    if (total) {
+      const uint32_t nbat = (total + kBatch - 1) / kBatch;
+      for (uint32_t bi = nbat; bi-- > 0;) {
+        const uint32_t base = bi * kBatch;
+        if (bi + 1 != nbat) load_batch(base);
+#pragma unroll
+        for (int k = 0; k < kRStash; ++k)
+          if (base + threadIdx.x + k * kRThreads < total) passb(sr[k], sp[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const uint32_t v = wave_max_u32(smax[k]);
+      if ((threadIdx.x & 63) == 0) s_c[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+      uint32_t v = 0u;
+      for (int i = 0; i < kRThreads / 64; ++i) v = s_c[threadIdx.x][i] > v ? s_c[threadIdx.x][i] : v;
+      // (returned atomic: performed memory-side before this thread passes the barrier below)
+      if (v != 0u) s_c[threadIdx.x][0] = atomicMax(&sw.fpart2[(blockIdx.x % kSinkSlots) * C + threadIdx.x], v);
+    }
+    // outputs of this item's pixels -- all but flat pixel 0, which only the last workgroup writes
+    const int64_t hw = (int64_t)height * width;
+    for (int p = threadIdx.x; p < kPx; p += kRThreads) {
+      const int r = rlog ? p / super_w : 0;
+      const int y = (sy_ << rlog) + r, x = sx_ * super_w + (p - r * super_w);
+      if (y >= height || x >= width) continue;
+      const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
+      float z = __uint_as_float(s_z[p]);
+      if (i == 0 && have_sink_z) z = sink_z < z ? sink_z : z;
+      if (i == 0) {   // published for the fold: final z bits and the survivors' feature word
+        s_w[0] = atomicExch(&sw.ctl[4], __float_as_uint(z));
+        s_w[1] = atomicExch(&sw.ctl[5], s_f[p]);
+        continue;
+      }
+      float d = z < 0.0f ? 0.0f : (z > depth_scale ? depth_scale : z);
+      d = d / depth_scale;
+      bool all_ok = true;
+      const uint32_t fw = s_f[p];
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        // scatter_max over fill(output_void >= 0): a feature of 0 and "no survivor" coincide
+        const float fv = (float)((fw >> (16 - 8 * k)) & 255u);
+        const float v = fv > output_void ? fv : output_void;
+        feat[i * C + k] = v;
+        all_ok = all_ok && (v != mask_void);
+      }
+      depth[i] = d;
+      if (mask) mask[i] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+    }
+  }
+  // ---- ticket: the last workgroup to arrive folds the sink into flat pixel 0
+  __syncthreads();   // (this workgroup's sink / pixel-0 atomics have returned)
+  if (threadIdx.x == 0) s_flag = atomicAdd(&sw.ctl[0], 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (s_flag == 0u) return;
+  uint32_t fm[C];
+#pragma unroll
+  for (int k = 0; k < C; ++k) fm[k] = 0u;
+  for (uint32_t i = threadIdx.x; i < zpart_count * C; i += kRThreads) {   // invalid points (S1, a kernel ago)
+    const uint32_t v = ws.fpart[i];
+    const int k = i % C;
+#pragma unroll
+    for (int kk = 0; kk < C; ++kk)
+      if (kk == k) fm[kk] = v > fm[kk] ? v : fm[kk];
+  }
+  for (uint32_t i = threadIdx.x; i < (uint32_t)kSinkSlots * C; i += kRThreads) {   // occluded points (atomics)
+    const uint32_t v = atomicMax(&sw.fpart2[i], 0u);
+    const int k = i % C;
+#pragma unroll
+    for (int kk = 0; kk < C; ++kk)
+      if (kk == k) fm[kk] = v > fm[kk] ? v : fm[kk];
+  }
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const uint32_t v = wave_max_u32(fm[k]);
+    if ((threadIdx.x & 63) == 0) s_c[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float z = __uint_as_float(atomicOr(&sw.ctl[4], 0u));
+    const uint32_t fw = atomicOr(&sw.ctl[5], 0u);
+    float d = z < 0.0f ? 0.0f : (z > depth_scale ? depth_scale : z);
+    d = d / depth_scale;
+    bool all_ok = true;
+    for (int k = 0; k < C; ++k) {
+      uint32_t sv = 0u;
+      for (int i = 0; i < kRThreads / 64; ++i) sv = s_c[k][i] > sv ? s_c[k][i] : sv;
+      const float fv = (float)((fw >> (16 - 8 * k)) & 255u);
+      float v = fv > output_void ? fv : output_void;
+      if (sv != 0u) {
+        const float sf = se3ds_ordered_to_f32(sv);
+        v = sf > v ? sf : v;
+      }
+      feat[k] = v;
+      all_ok = all_ok && (v != mask_void);
+    }
+    depth[0] = d;
+    if (mask) mask[0] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+  }
+}
+
+// (set once per kernel and size: hipFuncSetAttribute on every launch is host time for nothing)
+inline bool sort_lds_attr(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> done;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find(fn);
+  if (it != done.end() && it->second >= bytes) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return false;
+  done[fn] = bytes;
+  return true;
+}
+
+template <typename T, bool EQUIRECT, int C, int PTS>
+int launch_splat_sorted_c(const float* coords, const float* offset, const T* feats, int n, int64_t m,
+                          int64_t ld, int height, int width, float depth_scale, float input_void,
+                          float output_void, float* depth, float* feat, float* mask, float mask_void,
+                          SplatWs ws, SortWs sw, const SortGeom& g, hipStream_t stream) {
+  const uint64_t wmagic = ((uint64_t)1 << 40) / (uint64_t)width + 1;
+  const dim3 g_pt((unsigned)g.chunks, (unsigned)n);
+  const int vec = (ld % 4 == 0) && ((uintptr_t)coords % 16 == 0) &&
+                  ((uintptr_t)feats % (sizeof(T) == 1 ? 4 : 16) == 0);
+  const char* e_dbg = getenv("SE3DS_SPLAT_DEBUG");
+  const bool dbg = e_dbg && atoi(e_dbg) != 0;
+  const size_t lds1 = (size_t)g.chunk_pts * 9 + 4 * (size_t)g.nsuper;
+  const size_t lds2 = 4 * (2 * (size_t)g.px + 2 * (size_t)g.chunks + 1);
+  const void* k1 = dbg ? (const void*)splat_sort_kernel<T, EQUIRECT, C, true, PTS>
+                       : (const void*)splat_sort_kernel<T, EQUIRECT, C, false, PTS>;
+  const void* k2 = (const void*)splat_sort_resolve_kernel<C>;
+  if (!sort_lds_attr(k1, lds1) || !sort_lds_attr(k2, lds2)) return SE3DS_E_LAUNCH;
+  if (dbg)
+    hipLaunchKernelGGL((splat_sort_kernel<T, EQUIRECT, C, true, PTS>), g_pt, dim3(kSThreads), lds1,
+                       stream, coords, offset, feats, m, ld, height, width, wmagic, input_void,
+                       g.nsuper, g.super_x, g.super_w, g.rlog, vec, ws, sw);
+  else
+    hipLaunchKernelGGL((splat_sort_kernel<T, EQUIRECT, C, false, PTS>), g_pt, dim3(kSThreads), lds1,
+                       stream, coords, offset, feats, m, ld, height, width, wmagic, input_void,
+                       g.nsuper, g.super_x, g.super_w, g.rlog, vec, ws, sw);
+  hipLaunchKernelGGL((splat_sort_resolve_kernel<C>), dim3((unsigned)(n * g.nsuper)), dim3(kRThreads),
+                     lds2, stream, height, width, g.nsuper, g.super_x, g.super_w, g.rlog, depth_scale,
+                     output_void, mask_void, depth, feat, mask, ws, sw, (uint32_t)(g.chunks * n));
+  return check_launch("splat(sorted)");
+}
+
+template <typename T, bool EQUIRECT>
+int launch_splat_sorted(const float* coords, const float* offset, const T* feats, int n, int64_t m,
+                        int64_t ld, int channels, int height, int width, float depth_scale,
+                        float input_void, float output_void, float* depth, float* feat, float* mask,
+                        float mask_void, void* workspace, const SortGeom& g, hipStream_t stream) {
+  SplatWs ws = carve_ws(workspace, n, m);
+  const size_t base = splat_hdr_bytes() + (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)m;
+  SortWs sw = carve_sort_ws((char*)workspace + align16(base), n, g);
+#define SE3DS_S(CC, PP)                                                                           \
+  return launch_splat_sorted_c<T, EQUIRECT, CC, PP>(coords, offset, feats, n, m, ld, height, width, \
+                                                    depth_scale, input_void, output_void, depth,  \
+                                                    feat, mask, mask_void, ws, sw, g, stream)
+#define SE3DS_SC(CC) if (g.pts == 8) SE3DS_S(CC, 8); else SE3DS_S(CC, 16);
+  switch (channels) {
+    case 1: SE3DS_SC(1)
+    case 2: SE3DS_SC(2)
+    default: SE3DS_SC(3)
+  }
+#undef SE3DS_SC
+#undef SE3DS_S
+}
+
 template <typename T, bool EQUIRECT>
 int launch_splat(const float* coords, const float* offset, const T* feats, int n, int64_t m,
                  int64_t ld,
@@ -2233,6 +2990,21 @@ int launch_splat(const float* coords, const float* offset, const T* feats, int n
         return e && atoi(e) == 0;
       }();
       const int64_t ptiles = (int64_t)ceil_div(height, kPTileY) * ceil_div(width, kPTileX);
+      // round 4: sorted chunks + gathering resolve (SE3DS_SPLAT_SORT: 0 off, 1 = when the image has
+      // enough supertiles to fill the chip (default), 2 = always)
+      static const int sort_mode = sort_env("SE3DS_SPLAT_SORT", 1);
+      const bool packable = !no_bin && !no_pack && m > 0 && channels <= kPMaxChannels &&
+          (std::is_same<T, uint8_t>::value || byte_range) && output_void >= 0.0f &&
+          (int64_t)n * m < ((int64_t)1 << 31) && (int64_t)height * width * width < ((int64_t)1 << 40);
+      if (packable && sort_mode != 0) {
+        const SortGeom sg = sort_geom(m, height, width);
+        if (sg.nsuper <= kSMaxSuper && sg.chunks <= kSMaxChunks &&
+            (int64_t)sg.chunks * n <= kMaxSinkBlocks && (int64_t)n * sg.nsuper < ((int64_t)1 << 24) &&
+            (sort_mode == 2 || (int64_t)n * sg.nsuper >= 128))
+          return launch_splat_sorted<T, EQUIRECT>(coords, offset, feats, n, m, ld, channels, height,
+                                                  width, depth_scale, input_void, output_void, depth,
+                                                  feat, mask, mask_void, workspace, sg, stream);
+      }
       if (!no_bin && !no_pack && m > 0 && channels <= kPMaxChannels && ptiles <= kMaxTiles &&
           (std::is_same<T, uint8_t>::value || byte_range) && output_void >= 0.0f &&
           (int64_t)n * ptiles < ((int64_t)1 << 20) && (int64_t)n * m < ((int64_t)1 << 31) &&
@@ -2844,8 +3616,10 @@ size_t se3ds_splat_workspace_bytes(int n, int64_t m, int height, int width, int 
   const size_t three_pass = bin_ws_bytes(n, m, height, width, c);
   const size_t single_pass = fused_ws_bytes(n, m, height, width, c);
   const size_t packed = pack_ws_bytes(n, m, height, width);
+  const size_t sorted = sort_ws_bytes(n, m, height, width);
   size_t bins = three_pass > single_pass ? three_pass : single_pass;
   if (packed > bins) bins = packed;
+  if (sorted > bins) bins = sorted;
   return align16(base) + bins + 16;
 }
 
@@ -2906,6 +3680,13 @@ int se3ds_splat_promise_broken(const void* workspace, int n, int64_t m, uint32_t
   pw.ctl = (uint32_t*)((char*)const_cast<void*>(workspace) + align16(base));
   hipLaunchKernelGGL(splat_promise_kernel, dim3(1), dim3(1), 0, as_stream(stream), pw, broken_out);
   return check_launch("splat_promise_broken");
+}
+
+int se3ds_splat_promise_sticky(void* workspace, uint32_t* broken_out, int clear, void* stream) {
+  if (!workspace || !broken_out) return SE3DS_E_BADSHAPE;
+  hipLaunchKernelGGL(splat_promise_sticky_kernel, dim3(1), dim3(1), 0, as_stream(stream),
+                     (uint32_t*)workspace, broken_out, clear);
+  return check_launch("splat_promise_sticky");
 }
 
 int se3ds_splat_debug_indices(const void* workspace, int n, int64_t m, int32_t* idx_out,

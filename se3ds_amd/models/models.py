@@ -29,6 +29,11 @@ def _quantize(x: torch.Tensor, out_dtype, mul=1.0, div=1.0, lo=0.0, hi=0.0, pre=
       0.0 if pre is None else float(pre[0]), 0.0 if pre is None else float(pre[1]), float(mul),
       float(div), float(lo), float(hi), out.data_ptr(), _lib.dtype_code(out), _lib.stream()),
       'se3ds_quantize')
+  if out_dtype == torch.int32 and lo <= hi:
+    # the clamp bounds hold by construction: the 8-byte splat's byte-range promise for this tensor
+    # needs no read-back (point_cloud_utils.byte_range)
+    from se3ds_amd.utils import point_cloud_utils
+    point_cloud_utils.set_int_range(out, int(lo), int(hi))
   return out
 
 

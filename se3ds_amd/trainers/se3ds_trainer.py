@@ -231,6 +231,10 @@ class GAN(gan_manager.GANManager):
 
     # ---- generator forward (both "tapes" of the reference share this forward)
     ctx_g = G.make_ctx(training=True, record=True, group=group, world=R)
+    # PartialConv fast paths assume {0, 1} masks (what the reference's input pipeline produces,
+    # indoor_datasets.py:281-304,577-585); `gan.binary_masks = False` takes the exact kernels for
+    # fractional proj_mask values
+    ctx_g.binary_masks = bool(getattr(self, 'binary_masks', True))
     if sync is not None:
       # the per-module clip of the gradient-synchronisation path runs inside the backward
       # closures and shares its scratch across modules: one stream (as with several replicas)
@@ -490,6 +494,7 @@ class GAN(gan_manager.GANManager):
     G, D = self.generator, self.discriminator
     # generator forward in training mode, outside any tape (:292-293)
     ctx_g = G.make_ctx(training=True, record=False, group=group, world=R)
+    ctx_g.binary_masks = bool(getattr(self, 'binary_masks', True))
     outs, _ = G.forward(ctx_g, inputs)
     depth_out, generated = outs[3], outs[6]
     ctx_d = D.make_ctx(training=True, record=True, group=group, world=R)

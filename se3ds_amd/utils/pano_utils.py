@@ -132,9 +132,10 @@ def equirectangular_to_pointcloud(feats: torch.Tensor, depth: torch.Tensor, void
     ok = point_cloud_utils.byte_range(feats, void_class)
     if out is not None:
       prev = getattr(res, '_se3ds_byte_range', None)
-      same = prev is not None and prev[1:] == (res.data_ptr(), res._version, tuple(res.shape))
+      same = (prev is not None and prev[1:4] == (res.data_ptr(), res._version, tuple(res.shape)) and
+              prev[4] == float(void_class))
       ok = ok and (prev[0] if same else off == 0)
-    point_cloud_utils.set_byte_range(res, ok)
+    point_cloud_utils.set_byte_range(res, ok, void_class)
   if out is not None:
     xyz1, res = xyz1[:, :, off:off + h * w], res[:, off:off + h * w]
   if is_scalar:

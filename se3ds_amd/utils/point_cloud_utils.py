@@ -1,6 +1,7 @@
 """Utility functions for processing 3D point clouds -- MI355X implementation of the
 reference's utils/point_cloud_utils.py (same names, arguments and error behaviour; torch
 CUDA tensors in place of tf.Tensor).  All arithmetic runs in libse3ds_hip.so."""
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -48,37 +49,112 @@ _workspaces = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-  """Grow-only scratch buffer per device (keeps allocation out of the trajectory loop)."""
+  """Grow-only scratch buffer per device (keeps allocation out of the trajectory loop).  Its
+  256-byte header is zeroed at creation: header word 3 is the library's STICKY promise-violation
+  flag (include/se3ds_hip.h, se3ds_splat_promise_sticky)."""
   key = str(device)
   ws = _workspaces.get(key)
   if ws is None or ws.numel() < nbytes:
+    _poll_promise(device, force=True)   # (a pending verdict of the old buffer is read first)
     ws = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=device)
+    ws[:256].zero_()
     _workspaces[key] = ws
   return ws
 
 
 FEAT_BYTE_RANGE = 0x100   # include/se3ds_hip.h SE3DS_FEAT_BYTE_RANGE
+# A broken byte-range promise makes the packed splat pack f & 255: silently wrong features.  The
+# kernels raise a sticky flag in the workspace; it is read back ASYNCHRONOUSLY every
+# _PROMISE_POLL_EVERY-th promised splat (a 1-thread kernel + a 4-byte copy into pinned memory,
+# examined at a later call without waiting), so a violation is reported a few calls late but never
+# missed.  SE3DS_CHECK_PROMISE=1: checked synchronously after every promised splat (debugging).
+_PROMISE_POLL_EVERY = 64
+_CHECK_PROMISE_SYNC = os.environ.get('SE3DS_CHECK_PROMISE') == '1'
+_promise_state = {}   # device -> dict(calls, pending=[(event, pinned flag)])
 
 
-def set_byte_range(t: torch.Tensor, ok: Optional[bool]):
-  """Records on the tensor whether its elements are all `void` or integers in [0, 255] (what the
-  8-byte packed splat needs from int32 features).  Writers that fill a tensor through raw
-  pointers (se3ds_unproject_equirect_into) call this; None forgets."""
-  t._se3ds_byte_range = None if ok is None else (bool(ok), t.data_ptr(), t._version, tuple(t.shape))
+class PromiseBroken(RuntimeError):
+  """An int32 feature outside [0, 255] (and != void) reached a splat that was promised
+  SE3DS_FEAT_BYTE_RANGE: the features it rendered are wrong."""
+
+
+def _poll_promise(device, force=False):
+  """Bookkeeping of the sticky flag (see above).  force: launch the read-back now and wait."""
+  key = str(device)
+  st = _promise_state.setdefault(key, dict(calls=0, pending=[]))
+  ws = _workspaces.get(key)
+  still = []
+  for ev, flag in st['pending']:
+    if force or ev.query():
+      ev.synchronize()
+      if int(flag[0]) != 0:
+        st['pending'] = []
+        raise PromiseBroken('SE3DS_FEAT_BYTE_RANGE was promised for int32 features that are not all '
+                            'void or in [0, 255]: the splats rendered since the last check are wrong '
+                            '(call point_cloud_utils.set_byte_range(t, None) after writing to a '
+                            'feature tensor through raw pointers)')
+    else:
+      still.append((ev, flag))
+  st['pending'] = still
+  if ws is None:
+    return
+  st['calls'] += 1
+  if force or _CHECK_PROMISE_SYNC or st['calls'] % _PROMISE_POLL_EVERY == 0:
+    dflag = torch.empty(1, dtype=torch.int32, device=ws.device)
+    _lib.check(_lib.lib().se3ds_splat_promise_sticky(_lib.ptr(ws), _lib.ptr(dflag), 1, _lib.stream()),
+               'se3ds_splat_promise_sticky')
+    hflag = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    hflag.copy_(dflag, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st['pending'].append((ev, hflag))
+    if force or _CHECK_PROMISE_SYNC:
+      _poll_promise_wait(st)
+
+
+def _poll_promise_wait(st):
+  pend, st['pending'] = st['pending'], []
+  for ev, flag in pend:
+    ev.synchronize()
+    if int(flag[0]) != 0:
+      raise PromiseBroken('SE3DS_FEAT_BYTE_RANGE was promised for int32 features that are not all '
+                          'void or in [0, 255]: the last splat rendered wrong features')
+
+
+def set_byte_range(t: torch.Tensor, ok: Optional[bool], void_class: float = None):
+  """Records on the tensor whether its elements are all `void_class` or integers in [0, 255] (what
+  the 8-byte packed splat needs from int32 features).  Writers that fill a tensor through raw
+  pointers (se3ds_unproject_equirect_into) call this; None forgets.  The verdict is only reused
+  for the SAME void class."""
+  t._se3ds_byte_range = None if ok is None else (
+      bool(ok), t.data_ptr(), t._version, tuple(t.shape), None if void_class is None else float(void_class))
+
+
+def set_int_range(t: torch.Tensor, lo: int, hi: int):
+  """Records that every element of the integer tensor `t` lies in [lo, hi] BY CONSTRUCTION (the
+  library's own quantisation kernel clamps to these bounds): byte_range() then answers without
+  reading the tensor back."""
+  t._se3ds_int_range = (int(lo), int(hi), t.data_ptr(), t._version, tuple(t.shape))
 
 
 def byte_range(t: torch.Tensor, void_class: float) -> bool:
   """True when the splat may be promised SE3DS_FEAT_BYTE_RANGE for `t` (uint8: by type; int32:
-  every element is `void_class` or in [0, 255]).  The int32 answer is computed ONCE per tensor
-  (`se3ds_feats_byte_range` + one host read) and cached on the tensor object, keyed by its
-  storage pointer, shape and torch version counter; the library's own in-place writers keep the
-  cache current."""
+  every element is `void_class` or in [0, 255]).  Known bounds (set_int_range) answer at once;
+  otherwise the int32 answer is computed ONCE per tensor and void class (`se3ds_feats_byte_range`
+  + one host read) and cached on the tensor object, keyed by its storage pointer, shape, torch
+  version counter and the void class; the library's own in-place writers keep the cache current."""
   if t.dtype == torch.uint8:
     return True
   if t.dtype != torch.int32:
     return False
+  same = (t.data_ptr(), t._version, tuple(t.shape))
+  rng = getattr(t, '_se3ds_int_range', None)
+  if rng is not None and rng[2:] == same:
+    lo, hi = rng[0], rng[1]
+    if hi <= 255 and (lo >= 0 or (lo == -1 and float(void_class) == -1.0)):
+      return True
   ent = getattr(t, '_se3ds_byte_range', None)
-  if ent is not None and ent[1:] == (t.data_ptr(), t._version, tuple(t.shape)):
+  if ent is not None and ent[1:4] == same and (ent[4] is None or ent[4] == float(void_class)):
     return ent[0]
   bad = torch.empty(1, dtype=torch.int32, device=t.device)
   tc = t.contiguous()
@@ -86,7 +162,7 @@ def byte_range(t: torch.Tensor, void_class: float) -> bool:
                                          float(void_class), _lib.ptr(bad), _lib.stream())
   _lib.check(rc, 'se3ds_feats_byte_range')
   ok = int(bad.item()) == 0
-  set_byte_range(t, ok)
+  set_byte_range(t, ok, void_class)
   return ok
 
 
@@ -133,6 +209,8 @@ def _splat(entry: str, coords, offset, feats, height, width, depth_scale, input_
                                  _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(),
                                  _lib.stream())
     _lib.check(rc, 'se3ds_project_to_feat')
+  if hint:
+    _poll_promise(dev)
   if is_scalar:
     out = out[..., 0]
   if with_mask:
@@ -259,4 +337,6 @@ class PointCloudMemory:
         _lib.ptr(depth), _lib.ptr(out), _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(),
         _lib.stream())
     _lib.check(rc, 'se3ds_project_equirect_memory')
+    if hint:
+      _poll_promise(dev)
     return (depth, out, mask) if with_mask else (depth, out)

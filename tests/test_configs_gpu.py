@@ -570,6 +570,53 @@ def test_cfg3_highres_bf16_step_properties():
   assert bool(torch.isfinite(gan.generator.store.theta).all())
 
 
+def test_cfg3_fullsize_fp32_forward_vs_oracle():
+  """The BENCHMARKED configuration's tensors, not only its loss scalars:
+  configs/highres/highres.gin at 512x1024 on the fp32 path -- generator forward in inference mode
+  on a calibrated state (as cfg2 does at 256x512), then the multi-scale discriminator on
+  [fake; real]: `rgb`, `depth` (N,512,1024,.) and both logit maps (18x34 and 10x18; their
+  257x513 / 129x257 / 65x129 / 33x65 / 17x33 predecessors are where tile-edge bugs would show)
+  within 1e-3 of oracle/nets_torch.py (image_models.py:132-193, :599-618)."""
+  size = 512
+  gan = _gin_gan('highres', torch.float32)
+  G, D = gan.generator, gan.discriminator
+  assert gan.image_size == 512 and G.hidden_dims == 128 and G.resnet_version == '101'
+  batch = synth_batch(1, size, seed=321)
+  _randomise_inference_state(G, batch=batch, seed=6)
+  dev_batch = {k: v.to(DEV) for k, v in batch.items()}
+  outs, _ = G.forward(G.make_ctx(False), dev_batch)
+  depth_g, rgb_g = outs[3], outs[6]
+  assert tuple(rgb_g.shape) == (1, size, 2 * size, 3) and tuple(depth_g.shape) == (1, size, 2 * size, 1)
+  ctx_d = D.make_ctx(False)
+  x_all = gan._disc_input(ctx_d, rgb_g, depth_g, dev_batch['image'], dev_batch['depth'])
+  logits_g = D.forward(ctx_d, x_all)
+  torch.cuda.synchronize()
+  cfg = _oracle_cfg(gan)
+  t0 = time.time()
+  with torch.no_grad():
+    gp, dp = _cpu_params(G), _cpu_params(D)
+    outs_o, _ = O.generator_forward(gp, dict(batch), False, **cfg['gen'])
+    fake = torch.cat([outs_o[6], outs_o[3]], dim=-1)
+    real = torch.cat([batch['image'], batch['depth']], dim=-1)
+    logits_o, _ = O.discriminator_forward(dp, torch.cat([fake, real], dim=0), False, **cfg['dis'])
+  print(f'cfg3 oracle forward (G + D, fp32, 512x1024): {time.time() - t0:.1f} s')
+  e_rgb = rel_err(rgb_g.cpu().numpy(), outs_o[6].numpy())
+  e_depth = rel_err(depth_g.cpu().numpy(), outs_o[3].numpy())
+  print(f'cfg3 fp32 forward: rgb err {e_rgb:.2e}, depth err {e_depth:.2e}; depth range '
+        f'{float(outs_o[3].min()):.3f}..{float(outs_o[3].max()):.3f}, rgb std {float(outs_o[6].std()):.3f}')
+  assert float(outs_o[6].std()) > 1e-3 and float(outs_o[3].max() - outs_o[3].min()) > 1e-3, 'trivial outputs'
+  assert e_rgb < 1e-3 and e_depth < 1e-3, (e_rgb, e_depth)
+  want_shapes = [(2, 18, 34, 1), (2, 10, 18, 1)]
+  for k, (sub_g, sub_o) in enumerate(zip(logits_g, logits_o)):
+    assert len(sub_g) == len(sub_o) == 7
+    for lvl, (a, b) in enumerate(zip(sub_g, sub_o)):   # every returned feature map, not only the logits
+      e = rel_err(a.data.float().cpu().numpy(), b.numpy())
+      assert e < 1e-3, (k, lvl, tuple(b.shape), e)
+    assert tuple(sub_o[-1].shape) == want_shapes[k], tuple(sub_o[-1].shape)
+    print(f'cfg3 fp32 discriminator {k}: maps {[tuple(t.shape[1:3]) for t in sub_o]}, logit err '
+          f'{rel_err(sub_g[-1].data.float().cpu().numpy(), sub_o[-1].numpy()):.2e}')
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
 def test_resstack_masking_on_hip_path(dtype):
   """layers_test.py:64-86 on the product's ResStack at the generator's stack-1 dimensions
@@ -600,7 +647,9 @@ def test_resstack_masking_on_hip_path(dtype):
 def test_cfg5_warp_1024x2048_two_views_bit_exact(depth_kind):
   """1024x2048, V = 2 source views (4.2 M points) rendered at a third position: unproject,
   project + splat, mask -- bit-exact vs oracle/warp_oracle.c (the C twin pinned against the
-  reference's golden vectors in tests/test_oracle_warp.py)."""
+  reference's golden vectors in tests/test_oracle_warp.py) AND vs oracle/warp_np.py (reference:
+  utils/point_cloud_utils.py:90-183, utils/pano_utils.py:117-161).  At this size the default
+  dispatch is the round-4 sorted-chunk splat."""
   import bench
   h, w, views = 1024, 2048, 2
   rng = np.random.default_rng(77)
@@ -629,19 +678,19 @@ def test_cfg5_warp_1024x2048_two_views_bit_exact(depth_kind):
   np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
   np.testing.assert_array_equal(m_g.cpu().numpy()[..., None], warp_np.proj_mask(d_o, f_o, -1))
   assert 0.2 < float(m_g.mean()) <= 1.0
-  if depth_kind == 'random':
-    # ... and once against the INDEPENDENT NumPy / libm statement (oracle/warp_np.py shares no
-    # arithmetic with the kernels: np.arctan2 / np.arccos in binary64 rounded to fp32, NumPy
-    # scatter-min / max), so the largest configuration is not only checked twin-vs-twin
-    for (rgb, depth, pos), xg, fg in zip(panos, xs_g, fs_g):
-      xn, fn = warp_np.equirectangular_to_pointcloud(rgb, depth, -1, 20.0)
-      xn = (xn + np.concatenate([pos, np.zeros((1, 1), F32)], 1)[:, :, None]).astype(F32)
-      np.testing.assert_array_equal(xg.cpu().numpy(), xn)
-      np.testing.assert_array_equal(fg.cpu().numpy(), fn)
-    rel = (mem_x - np.concatenate([target, np.zeros((1, 1), F32)], 1)[:, :, None]).astype(F32)
-    d_n, f_n = warp_np.project_feats_to_equirectangular(mem_f, rel, h, w, -1, 20.0)
-    np.testing.assert_array_equal(d_g.cpu().numpy(), d_n)
-    np.testing.assert_array_equal(f_g.cpu().numpy(), f_n)
+  # ... and against the INDEPENDENT NumPy / libm statement (oracle/warp_np.py shares no arithmetic
+  # with the kernels: np.arctan2 / np.arccos in binary64 rounded to fp32, NumPy scatter-min / max),
+  # for BOTH depth kinds: the smooth `room` input is the one with heavy tiles (banded resolve), so
+  # the largest configuration is never checked twin-vs-twin only
+  for (rgb, depth, pos), xg, fg in zip(panos, xs_g, fs_g):
+    xn, fn = warp_np.equirectangular_to_pointcloud(rgb, depth, -1, 20.0)
+    xn = (xn + np.concatenate([pos, np.zeros((1, 1), F32)], 1)[:, :, None]).astype(F32)
+    np.testing.assert_array_equal(xg.cpu().numpy(), xn)
+    np.testing.assert_array_equal(fg.cpu().numpy(), fn)
+  rel = (mem_x - np.concatenate([target, np.zeros((1, 1), F32)], 1)[:, :, None]).astype(F32)
+  d_n, f_n = warp_np.project_feats_to_equirectangular(mem_f, rel, h, w, -1, 20.0)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_n)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_n)
 
 
 def test_quantize_steps_bit_exact():

@@ -299,19 +299,24 @@ def test_bilinear_and_resampling_paths():
 
 
 _OLD = dict(SE3DS_SPLAT_PACKED='0')   # the 20-byte-record paths behind the 8-byte packed default
+_SORT = dict(SE3DS_SPLAT_SORT='2')    # round 4: sorted chunks + gathering resolve, also on small images
 @pytest.mark.parametrize('env_extra', [
     dict(SE3DS_SPLAT_SLICE='48'),                          # packed records, every tile banded
     dict(_OLD, SE3DS_SPLAT_SLICE='48'),                    # three-pass, 20-byte records, every tile banded
     dict(_OLD, SE3DS_SPLAT_FUSED='16'),                    # single-pass binning kernel, 16 points / thread
     dict(_OLD, SE3DS_SPLAT_FUSED='8', SE3DS_SPLAT_CAP='64', SE3DS_SPLAT_SLICE='48'),   # overflow + bands
-], ids=['packed-banded', 'three-pass-banded', 'single-pass', 'single-pass-overflow-banded'])
+    dict(_SORT),                                           # sorted chunks (16 points / thread) + gathering resolve
+    dict(_SORT, SE3DS_SPLAT_PTS='8'),                      # ... 8 points / thread (4096-point chunks)
+], ids=['packed-banded', 'three-pass-banded', 'single-pass', 'single-pass-overflow-banded', 'sorted',
+        'sorted-8pt'])
 def test_splat_banded_tiles_bit_exact(env_extra):
   """The splat parity tests re-run in a child process under switches that are read once per
   process: tiny slices (every tile of the small parity images is cut into bands of rows, in the
   packed and in the 20-byte-record resolve kernels), the 20-byte-record three-pass path that the
   8-byte packed path replaced as the default (SE3DS_SPLAT_PACKED=0; still what float features
   and more than 3 channels take), and the opt-in single-pass binning kernel (SE3DS_SPLAT_FUSED)
-  with tiny bin capacities (records spill into its overflow list)."""
+  with tiny bin capacities (records spill into its overflow list); and the round-4 sorted-chunk
+  path (SE3DS_SPLAT_SORT=2 takes it on images of any size) in its template variants."""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -371,6 +376,48 @@ def test_packed_splat_variants_and_byte_range_promise():
     assert rc == 0
     assert L.se3ds_splat_promise_broken(_lib.ptr(ws), 1, m, _lib.ptr(flag), _lib.stream()) == 0
     assert int(flag.item()) == want
+  # ... and STICKY in header word 3 of a workspace whose header the caller zeroed once: the clean
+  # call that follows a violation does not hide it; reading with clear = 1 resets it
+  ws[:256].zero_()
+  seq = [rng.integers(0, 5000, (1, m, 3)), rng.integers(0, 256, (1, m, 3))]
+  for feats in seq:
+    f = t(feats.astype(np.int32))
+    assert L.se3ds_project_equirect(_lib.ptr(xyz), None, _lib.ptr(f), _lib.I32 | point_cloud_utils.FEAT_BYTE_RANGE,
+                                    1, m, 3, h, w, DEPTH_SCALE, -1.0, 0.0, _lib.ptr(depth), _lib.ptr(out),
+                                    None, -1.0, _lib.ptr(ws), ws.numel(), _lib.stream()) == 0
+  for want in (1, 0):
+    assert L.se3ds_splat_promise_sticky(_lib.ptr(ws), _lib.ptr(flag), 1, _lib.stream()) == 0
+    assert int(flag.item()) == want
+  # the cached verdict belongs to ONE void class: all-(-1)-or-byte features are packable
+  # for void -1 and NOT for void 0 (their -1 entries are then ordinary, unpackable values)
+  tf = t(np.where(rng.uniform(size=(1, 2000, 3)) < 0.1, -1, rng.integers(0, 256, (1, 2000, 3))).astype(np.int32))
+  assert point_cloud_utils.byte_range(tf, -1)
+  assert not point_cloud_utils.byte_range(tf, 0)
+  assert point_cloud_utils.byte_range(tf, -1)
+  # bounds known by construction answer without reading the tensor back
+  point_cloud_utils.set_int_range(tf, -1, 255)
+  assert point_cloud_utils.byte_range(tf, -1)
+  # the wrapper reports a promise broken behind its back (a raw-pointer writer that forgot
+  # set_byte_range): the sticky flag is polled after promised splats
+  xyz_np = (rng.standard_normal((1, 4, m)) * 3).astype(F32)
+  good = t(rng.integers(0, 256, (1, m, 3)).astype(np.int32))
+  assert point_cloud_utils.byte_range(good, -1)
+  # (a raw-pointer write, no torch version bump: the float 3e9 reads back as the int32 1 328 730 206)
+  import se3ds_amd.hipops  # noqa: F401  (registers se3ds_fill's signature)
+  assert L.se3ds_fill(good.data_ptr() + 4 * 40, _lib.F32, 1, 3.0e9, _lib.stream()) == 0
+  assert point_cloud_utils.byte_range(good, -1)   # the stale cached verdict
+  old_every, point_cloud_utils._PROMISE_POLL_EVERY = point_cloud_utils._PROMISE_POLL_EVERY, 1
+  try:
+    with pytest.raises(point_cloud_utils.PromiseBroken):
+      for _ in range(3):   # (asynchronous: the verdict of call k is examined at call k + 1 or later)
+        pano_utils.project_feats_to_equirectangular(good, t(xyz_np), h, w, -1, DEPTH_SCALE)
+        torch.cuda.synchronize()
+  finally:
+    point_cloud_utils._PROMISE_POLL_EVERY = old_every
+    try:   # drain the flag this test raised on purpose (it is sticky: later tests share the workspace)
+      point_cloud_utils._poll_promise(dev(), force=True)
+    except point_cloud_utils.PromiseBroken:
+      pass
 
 
 def test_resize_branches_size_mult_crop_resize_and_mean_padding():

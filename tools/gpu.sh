@@ -8,7 +8,7 @@
 #   ab 'ENV=v ENV=v' ...        A/B of the gan_step bench under env settings (baseline first), 2 reps
 #   abwarp 'ENV=v' ...          the same for --workload warp (random and room depth)
 #   prof_step TAG [ENV=v ...]   rocprofv3 kernel stats of the default bench -> gpurun_out/TAG_kernel_stats.csv
-#   prof_warp TAG               kernel stats of the warp bench, random + room depth
+#   prof_warp TAG [ENV=v ...]   kernel stats of the warp bench, random + room depth
 #   pmc_conv TAG "SHAPE"        MFMA-busy / FETCH / WRITE counters of tools/one_conv.py SHAPE (3 passes)
 #   pmc_warp TAG                FETCH / WRITE counters of the warp kernels (2 passes)
 #   py <file.py> [args]         any python tool
@@ -66,7 +66,8 @@ task_prof_step() {
   rm -rf gpurun_out/prof_tmp
 }
 task_prof_warp() {
-  local tag=$1
+  local tag=$1; shift
+  for v in "$@"; do export "$v"; done
   for d in random room; do
     rm -rf gpurun_out/prof_tmp
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o warp -- python bench.py --workload warp --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
