@@ -2626,7 +2626,7 @@ __device__ __forceinline__ uint32_t bytemax3(uint32_t a, uint32_t b) {
 
 // S2.  One workgroup per (image, supertile).
 template <int C>
-__global__ void __launch_bounds__(kRThreads)
+__global__ void __launch_bounds__(kRThreads, 6)   // (<= 80 VGPRs: three workgroups per CU)
 splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int super_w, int rlog,
                           float depth_scale, float output_void, float mask_void,
                           float* __restrict__ depth, float* __restrict__ feat,
@@ -2714,31 +2714,34 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
       }
       __syncthreads();
     };
-    // (the kRStash walks of a thread advance TOGETHER: three predicated steps cover the usual case
-    // with kRStash independent LDS reads in flight per step, a loop takes the stragglers)
-    auto locate_all = [&](const uint32_t (&j)[kRStash], uint32_t (&a)[kRStash]) {
-      uint32_t k[kRStash];
+    // (the walks of a thread advance in GROUPS of four: three predicated steps cover the usual case
+    // with four independent LDS reads in flight per step, a loop takes the stragglers; a group's
+    // loads are issued as soon as its addresses are known -- they fly under the next group's walk)
+    constexpr int kWalk = 4;
+    static_assert(kRStash % kWalk == 0, "walk groups");
+    auto locate_group = [&](int q0, const uint32_t (&j)[kWalk], uint32_t (&a)[kWalk]) {
+      uint32_t k[kWalk];
 #pragma unroll
-      for (int q = 0; q < kRStash; ++q) k[q] = s_q[(threadIdx.x >> 6) + q * (kRThreads / 64)];
+      for (int q = 0; q < kWalk; ++q) k[q] = s_q[(threadIdx.x >> 6) + (q0 + q) * (kRThreads / 64)];
 #pragma unroll
       for (int stp = 0; stp < 3; ++stp) {
-        uint32_t nx[kRStash];
+        uint32_t nx[kWalk];
 #pragma unroll
-        for (int q = 0; q < kRStash; ++q) nx[q] = s_cpre[k[q] + 1];
+        for (int q = 0; q < kWalk; ++q) nx[q] = s_cpre[k[q] + 1];
 #pragma unroll
-        for (int q = 0; q < kRStash; ++q) k[q] += nx[q] <= j[q] ? 1u : 0u;
+        for (int q = 0; q < kWalk; ++q) k[q] += nx[q] <= j[q] ? 1u : 0u;
       }
 #pragma unroll
-      for (int q = 0; q < kRStash; ++q)
+      for (int q = 0; q < kWalk; ++q)
         while (s_cpre[k[q] + 1] <= j[q]) ++k[q];
-      uint32_t cb[kRStash], cp[kRStash];
+      uint32_t cb[kWalk], cp[kWalk];
 #pragma unroll
-      for (int q = 0; q < kRStash; ++q) {
+      for (int q = 0; q < kWalk; ++q) {
         cb[q] = s_cbase[k[q]];
         cp[q] = s_cpre[k[q]];
       }
 #pragma unroll
-      for (int q = 0; q < kRStash; ++q) a[q] = cb[q] + (j[q] - cp[q]);
+      for (int q = 0; q < kWalk; ++q) a[q] = cb[q] + (j[q] - cp[q]);
     };
     // Both passes walk the records in BATCHES of kRStash per thread (kRStash x 512 per workgroup):
     // all searches, then all 2 x kRStash loads, then the LDS work.  A supertile of average weight
@@ -2749,19 +2752,21 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
     uint64_t sr[kRStash];
     uint32_t sp[kRStash];
     auto load_batch = [&](uint32_t base) {
-      uint32_t sa[kRStash];
       block_table(base);
-      uint32_t jj[kRStash];
 #pragma unroll
-      for (int k = 0; k < kRStash; ++k) {
-        const uint32_t j = base + threadIdx.x + k * kRThreads;
-        jj[k] = j < total ? j : last;   // (out-of-range slots re-read the last record, unused)
-      }
-      locate_all(jj, sa);
+      for (int q0 = 0; q0 < kRStash; q0 += kWalk) {
+        uint32_t jj[kWalk], sa[kWalk];
 #pragma unroll
-      for (int k = 0; k < kRStash; ++k) {
-        sr[k] = RB[sa[k]];
-        sp[k] = (uint32_t)HB[sa[k]];
+        for (int q = 0; q < kWalk; ++q) {
+          const uint32_t j = base + threadIdx.x + (q0 + q) * kRThreads;
+          jj[q] = j < total ? j : last;   // (out-of-range slots re-read the last record, unused)
+        }
+        locate_group(q0, jj, sa);
+#pragma unroll
+        for (int q = 0; q < kWalk; ++q) {
+          sr[q0 + q] = RB[sa[q]];
+          sp[q0 + q] = (uint32_t)HB[sa[q]];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);   // all 2 x kRStash loads are issued before the first use
 #pragma unroll
@@ -2778,9 +2783,7 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
     }
     __syncthreads();
     // pass B: survivors (z < zmin + 0.1) max their features; the rest feed the sink
-    uint32_t smax[C];
-#pragma unroll
-    for (int k = 0; k < C; ++k) smax[k] = 0u;
+    uint32_t sbytes = 0u;   // byte-wise max of the occluded records' feature words
     auto passb = [&](uint64_t r, uint32_t pix) {
       const float z = __uint_as_float(rec_zbits(r));
       float zm = __uint_as_float(s_z[pix]);
@@ -2796,11 +2799,7 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
           old = prev;
         }
       } else {
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-          const uint32_t o = se3ds_f32_to_ordered((float)((fw >> (16 - 8 * k)) & 255u));
-          smax[k] = o > smax[k] ? o : smax[k];
-        }
+        sbytes = bytemax3(sbytes, fw);   // (converted to the sink's ordered floats once, below)
       }
     };
     // (the registers still hold the LAST batch of pass A: walk the batches backwards)
@@ -2816,7 +2815,9 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
     }
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-      const uint32_t v = wave_max_u32(smax[k]);
+      // (a feature of 0 never raises the sink's maximum over fill(0): ordered(0.0f) stays out)
+      const uint32_t fb = (sbytes >> (16 - 8 * k)) & 255u;
+      const uint32_t v = wave_max_u32(fb ? se3ds_f32_to_ordered((float)fb) : 0u);
       if ((threadIdx.x & 63) == 0) s_c[k][threadIdx.x >> 6] = v;
     }
     __syncthreads();

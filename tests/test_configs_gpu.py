@@ -323,7 +323,11 @@ def test_cfg1_generator_gradients_vs_fp64_yardstick():
   direct = {k: err(gh[k], g32[k].numpy()) for k in names}
   misses = [k for k in names if direct[k] >= 1e-3]
   print(f'{len(names)} tensors: max {max(direct.values()):.2e}, median {np.median(list(direct.values())):.2e}, '
-        f'{len(misses)} above 1e-3')
+        f'{len(misses)} above 1e-3, {len(names) - len(misses)} within 1e-3 of the fp32 oracle DIRECTLY')
+  # the count of tensors that meet north_star's 1e-3 bar directly is gated, so that a regression in
+  # direct agreement is visible even while the fp64 yardstick below still passes (measured in
+  # round 4: 74 of 954 -- at cfg1's depth two correct fp32 evaluations differ by 1e-2 on the rest)
+  assert len(names) - len(misses) >= 60, (len(names), len(misses))
   if misses:
     # 200+ layers of fp32 rounding and ReLU kinks (an activation within fp32 noise of zero flips its
     # derivative between two correct implementations): judge those tensors by the fp64 yardstick (as accurate as the fp32 oracle, factor 5); still no cosine fallback
