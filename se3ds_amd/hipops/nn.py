@@ -441,13 +441,28 @@ class Ctx:
     (t, cont); the second reduces both tensors in one collective and runs both continuations."""
     if self.world > 1:
       if self._cur_paired:
+        on_streams = self.streams is not None and t.is_cuda
         if self._bwd_pending is None:
-          self._bwd_pending = (t, cont)
+          ev = None
+          if on_streams:
+            ev = torch.cuda.Event()
+            ev.record()   # behind this branch's statistics kernel, on its stream
+          self._bwd_pending = (t, cont, ev, self.branch_tag)
           return
-        t0, cont0 = self._bwd_pending
+        t0, cont0, ev0, tag0 = self._bwd_pending
         self._bwd_pending = None
+        if ev0 is not None:
+          torch.cuda.current_stream(self.device).wait_event(ev0)
         self._allreduce_joint(t0, t)
-        cont0()
+        if ev0 is not None and tag0 != self.branch_tag:
+          # the twin's continuation runs on ITS stream, behind the copy-back issued on this one
+          ev1 = torch.cuda.Event()
+          ev1.record()
+          with self.branch(tag0):
+            torch.cuda.current_stream(self.device).wait_event(ev1)
+            cont0()
+        else:
+          cont0()
         cont()
         return
       self.allreduce_sum(t)
@@ -502,20 +517,38 @@ _PAIR_SYNCBN = os.environ.get('SE3DS_PAIR_SYNCBN', '1') != '0'
 
 
 class _PairSync:
-  """Rendezvous of two branch threads at their SyncBN sums (forward pass)."""
+  """Rendezvous of two branch threads at their SyncBN sums (forward pass).  With per-branch HIP
+  streams (Ctx.streams, round 4) the two sums live on two streams: the partner records an event
+  behind its statistics kernel, the leader's stream waits for it, reduces both tensors in one
+  collective, and the partner's stream waits for the event behind the copy-back."""
 
   def __init__(self, ctx, lead, other):
     self.ctx, self.lead, self.other = ctx, lead, other
     self.barrier = threading.Barrier(2)
     self.slot = {}
+    self.ev = {}
 
   def allreduce(self, t, tag):
+    ctx = self.ctx
+    streams = ctx.streams is not None and t.is_cuda
     self.slot[tag] = t
+    if streams and tag != self.lead:
+      e = torch.cuda.Event()
+      e.record()            # (this thread's current stream = its branch stream)
+      self.ev['in'] = e
     self.barrier.wait()
     if tag == self.lead:
-      # both statistics kernels are already enqueued on the (one) stream
-      self.ctx._allreduce_joint(self.slot[self.lead], self.slot[self.other])
+      if streams:
+        torch.cuda.current_stream(ctx.device).wait_event(self.ev['in'])
+      # both statistics kernels are enqueued (and, across streams, ordered by the event)
+      ctx._allreduce_joint(self.slot[self.lead], self.slot[self.other])
+      if streams:
+        e = torch.cuda.Event()
+        e.record()
+        self.ev['out'] = e
     self.barrier.wait()   # the partner continues only behind the enqueued copy-back
+    if streams and tag != self.lead:
+      torch.cuda.current_stream(ctx.device).wait_event(self.ev['out'])
 
 
 def _run_paired(ctx, fns):

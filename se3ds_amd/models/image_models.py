@@ -77,9 +77,11 @@ class _Model:
       # BRANCH stream while the other branch already writes its gradients into it (found as an
       # intermittent 1e-10 difference of the step-0 update, tools/step_compare.py).
       self.store.grad
-    if ctx.world == 1 and _DUAL_STREAM and nn.conv_profiler() is None:
+    if _DUAL_STREAM and nn.conv_profiler() is None and self.device.type == 'cuda':
       # (not while the bench times single convolution launches: overlapped kernels would be
-      # charged each other's time)
+      # charged each other's time.  Round 4: also with several replicas -- the lockstep branch
+      # threads issue onto their branch's stream and the paired SyncBN sums are ordered by events,
+      # so the schedule that is benchmarked on one GPU is the one every rank of a multi-GPU job runs)
       if getattr(self, '_branch_streams', None) is None:
         self._branch_streams = {1: torch.cuda.Stream(self.device), 2: torch.cuda.Stream(self.device)}
       ctx.streams = self._branch_streams

@@ -235,10 +235,6 @@ class GAN(gan_manager.GANManager):
     # indoor_datasets.py:281-304,577-585); `gan.binary_masks = False` takes the exact kernels for
     # fractional proj_mask values
     ctx_g.binary_masks = bool(getattr(self, 'binary_masks', True))
-    if sync is not None:
-      # the per-module clip of the gradient-synchronisation path runs inside the backward
-      # closures and shares its scratch across modules: one stream (as with several replicas)
-      ctx_g.streams = None
     outs, (push_rgb, push_depth) = G.forward(ctx_g, inputs)
     depth_out, generated = outs[3], outs[6]
 
@@ -416,16 +412,27 @@ class GAN(gan_manager.GANManager):
       self._update_all(self.d_optimizer, False, None, 0.0)
       d_norm = self.d_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
     else:
-      # a module's gradients are fixed up, clipped and handed to the side stream as soon as
-      # the backward pass leaves it; the all-reduce overlaps the rest of the backward pass
+      # Several replicas (round 4: the SAME stream schedule as the benchmarked one-replica step):
+      # when the backward pass leaves a module -- on the main stream or on a decoder's branch
+      # stream -- its deferred split reductions, spectral fix-up and per-tensor clip run on the
+      # optimiser's side stream behind an event (they share the optimiser's scratch: one stream
+      # for all of them), and the clipped slice is handed to the gradient all-reduce from there;
+      # the all-reduce overlaps the rest of the backward pass
+      opt = self._optimizer_stream(dev)
+      main = torch.cuda.current_stream(dev)
+      opt.wait_stream(main)
       def segment_done(name):
         if name not in self._g_segments:
           return
         t0, t1, e0, e1 = self._g_segments[name]
-        nn.flush_wgrad_reduces(ctx_g)
-        G.spectral.backward_fixup(prefix=G.SEGMENTS[name], dots_only=FUSED_SN_CLIP)
-        self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP)
-        sync.reduce_range(G.store.grad, e0, e1)
+        done = torch.cuda.Event()
+        done.record()   # on the stream that ran the module's backward
+        with torch.cuda.stream(opt):
+          opt.wait_event(done)
+          nn.flush_wgrad_reduces(ctx_g)
+          G.spectral.backward_fixup(prefix=G.SEGMENTS[name], dots_only=FUSED_SN_CLIP)
+          self.g_optimizer.clip_segment(t0, t1, GRAD_CLIP_NORM, fused_sn=FUSED_SN_CLIP)
+          sync.reduce_range(G.store.grad, e0, e1)   # (its `ready` event lands on this stream)
       ctx_g.on_segment = segment_done
       ctx_g.after_collective = sync.pump
       if DEFER_WGRAD_REDUCE:
@@ -434,6 +441,7 @@ class GAN(gan_manager.GANManager):
       ctx_g.on_segment = None
       ctx_g.after_collective = None
       ctx_g.wgrad_defer = None
+      main.wait_stream(opt)
       g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
       sync.finish()
       self.g_optimizer.apply_gradients(group, 1, ema_theta, ema_omd)

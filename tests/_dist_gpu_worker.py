@@ -144,7 +144,9 @@ image_models.SNMultiScaleDiscriminator.n_layers = 3
   dist.all_gather(ls, loss)
   assert abs(float(ls[0]) - float(ls[1])) > 0, 'both ranks report the same local loss'
   if rank == 0:
-    print('DIST_GPU_OK', [float(x) for x in got[0][:5]])
+    ctx_probe = gan.generator.make_ctx(training=True, record=False, group=gan.strategy.group, world=world)
+    print('streams=%d' % (0 if ctx_probe.streams is None else len(ctx_probe.streams)))
+    print('DIST_GPU_OK', [float(x).hex() for x in got[0]])
   faulthandler.cancel_dump_traceback_later()
   dist.destroy_process_group()
 

@@ -43,6 +43,28 @@ def test_two_replicas_share_one_gpu_over_gloo(own_comm):
   print(r.stdout[-600:])
 
 
+def test_two_replica_stream_schedule_is_bit_identical_to_one_stream():
+  """Round 4: with several replicas the decoders keep their two HIP streams (lockstep branch threads,
+  event-ordered paired SyncBN sums) and the per-module fix-up / clip / gradient hand-over runs on
+  the optimiser's side stream -- the schedule the one-GPU bench measures.  It only reorders
+  independent work: the two-replica worker's signature (parameter / Adam / EMA checksums after
+  train_g_d, train_d, train_g_d) must equal the one-stream run's BIT FOR BIT, and the SyncBN
+  collective count stays 2 x (all batch norms - those of one decoder branch)."""
+  sigs = {}
+  for dual in ('0', '1'):
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', SE3DS_DUAL_STREAM=dual,
+               SE3DS_GRAD_SYNC_OWN_COMM='0', **_LOOPBACK)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
+           os.path.join(ROOT, 'tests', '_dist_gpu_worker.py')]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    line = [l for l in r.stdout.splitlines() if 'DIST_GPU_OK' in l][-1]
+    sigs[dual] = line
+    assert ('streams=2' in r.stdout) == (dual == '1'), r.stdout[-800:]
+  assert sigs['0'] == sigs['1'], sigs
+
+
 def test_rccl_single_rank_api_paths():
   """The real `nccl` (= RCCL) backend with one rank: every collective shape of the multi-GPU step
   is accepted (the 8-GPU run itself is the driver's)."""
@@ -75,6 +97,18 @@ def test_bench_gpus_2_launches_two_ranks_on_one_gpu():
                     '--warmup', '1', '--no-cpu-baseline'], dict(SE3DS_BENCH_BACKEND='gloo'))
   assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0
   assert out['scaling'] == 'weak' and out['config']['workload'].startswith('warp')
+
+
+def test_bench_gan_step_two_gloo_ranks_on_one_gpu():
+  """PLUMBING ONLY: `bench.py --gpus 2` with the gan_step workload, both ranks on the one GPU over
+  gloo (small model: the figure says nothing about throughput) -- the launcher, the data-parallel
+  strategy with branch streams and side-stream gradient hand-over, barrier + max-over-ranks timing
+  and the line's n_gpus / global_batch / backend fields."""
+  out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '1', '--image-size',
+                    '128', '--no-cpu-baseline', '--no-warp', '--no-shipped', '--no-batch-max'],
+                   dict(SE3DS_BENCH_BACKEND='gloo'), timeout=900)
+  assert out['n_gpus'] == 2 and out['config']['global_batch'] == 2 and out['backend'] == 'gloo'
+  assert all(v == v for v in out['losses'].values()) and out['value'] > 0
 
 
 def test_gan_step_on_two_gpus_over_rccl():
