@@ -621,7 +621,13 @@ def _merge_paired(tape):
         for (seg_a, sync_a), (seg_b, sync_b) in zip(sa, sb):
           merged += seg_a + seg_b + [(sync_a[0], sync_a[1], 2), (sync_b[0], sync_b[1], 2)]
         merged += ta + tb
-    out += merged if merged is not None else run
+    if merged is None:
+      # asymmetric branches (different SyncBN counts, or not exactly two tags): no pairing, and NOT
+      # the recorded order either -- that is the host threads' interleaving and differs from rank
+      # to rank, so equal-shaped all-reduces of different layers could meet.  One branch after the
+      # other, by tag: the same order on every rank.
+      merged = [e for t in tags for e in run if e[1] == t]
+    out += merged
     i = j
   return out
 
@@ -1399,6 +1405,11 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
       out.bn_stats = None
       out.grad = None
       if dy is None:
+        if sync_bwd:
+          # no gradient reaches this norm on this replica / branch: its statistics gradients are
+          # zero, but the collective (and a paired twin parked in allreduce_then) still needs us
+          ctx.allreduce_then(torch.zeros((g, 2, c), dtype=torch.float32, device=ctx.device),
+                             lambda: None)
         return
       if post is not None:
         # y = act(.) + post: the activation mask must come from (y - post); recompute it
