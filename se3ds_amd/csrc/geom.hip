@@ -2695,7 +2695,9 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
     // from there -- a few reads of nearly the same words, broadcast within the wave.
     int steps = 0;
     while ((1u << steps) < (nnz ? nnz : 1u)) ++steps;
-    const uint64_t* RB = sw.rec + (int64_t)b * chunks * sw.chunk_pts;
+    // (record numbers inside one image are < 2^25: 32-bit byte offsets from a uniform base keep the
+    // address arithmetic out of the vector ALU)
+    const char* RB = reinterpret_cast<const char*>(sw.rec + (int64_t)b * chunks * sw.chunk_pts);
     const uint8_t* HB = sw.hi + (int64_t)b * chunks * sw.chunk_pts;
     const uint32_t last = total ? total - 1u : 0u;
     auto block_table = [&](uint32_t base) {   // s_q[blk] for the blocks of the batch starting at `base`
@@ -2764,7 +2766,7 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
         locate_group(q0, jj, sa);
 #pragma unroll
         for (int q = 0; q < kWalk; ++q) {
-          sr[q0 + q] = RB[sa[q]];
+          sr[q0 + q] = *reinterpret_cast<const uint64_t*>(RB + (sa[q] << 3));
           sp[q0 + q] = (uint32_t)HB[sa[q]];
         }
       }
@@ -2829,14 +2831,17 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
     }
     // outputs of this item's pixels -- all but flat pixel 0, which only the last workgroup writes
     const int64_t hw = (int64_t)height * width;
+    float* __restrict__ depth_b = depth + (int64_t)b * hw;
+    float* __restrict__ feat_b = feat + (int64_t)b * hw * C;
+    float* __restrict__ mask_b = mask ? mask + (int64_t)b * hw : nullptr;
     for (int p = threadIdx.x; p < kPx; p += kRThreads) {
       const int r = rlog ? p / super_w : 0;
       const int y = (sy_ << rlog) + r, x = sx_ * super_w + (p - r * super_w);
       if (y >= height || x >= width) continue;
-      const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
+      const uint32_t ip = (uint32_t)y * (uint32_t)width + (uint32_t)x;   // (< 2^31 / images: checked by the dispatcher)
       float z = __uint_as_float(s_z[p]);
-      if (i == 0 && have_sink_z) z = sink_z < z ? sink_z : z;
-      if (i == 0) {   // published for the fold: final z bits and the survivors' feature word
+      if (first && ip == 0u) {   // published for the fold: final z bits and the survivors' feature word
+        if (have_sink_z) z = sink_z < z ? sink_z : z;
         s_w[0] = atomicExch(&sw.ctl[4], __float_as_uint(z));
         s_w[1] = atomicExch(&sw.ctl[5], s_f[p]);
         continue;
@@ -2850,11 +2855,37 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
         // scatter_max over fill(output_void >= 0): a feature of 0 and "no survivor" coincide
         const float fv = (float)((fw >> (16 - 8 * k)) & 255u);
         const float v = fv > output_void ? fv : output_void;
-        feat[i * C + k] = v;
+        feat_b[ip * C + k] = v;
         all_ok = all_ok && (v != mask_void);
       }
-      depth[i] = d;
-      if (mask) mask[i] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+      depth_b[ip] = d;
+      if (mask_b) mask_b[ip] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
+    }
+    if (first) {
+      // the invalid points' feature maxima (S1's per-chunk partials, a kernel ago) join the occluded
+      // points' slots here, so that the last workgroup only reads the slots
+      uint32_t fm[C];
+#pragma unroll
+      for (int k = 0; k < C; ++k) fm[k] = 0u;
+      for (uint32_t i = threadIdx.x; i < zpart_count * C; i += kRThreads) {
+        const uint32_t v = ws.fpart[i];
+        const int k = i % C;
+#pragma unroll
+        for (int kk = 0; kk < C; ++kk)
+          if (kk == k) fm[kk] = v > fm[kk] ? v : fm[kk];
+      }
+      __syncthreads();   // (s_c: this workgroup's sink reduction above has been consumed)
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+        const uint32_t v = wave_max_u32(fm[k]);
+        if ((threadIdx.x & 63) == 0) s_c[k][threadIdx.x >> 6] = v;
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < C) {
+        uint32_t v = 0u;
+        for (int i = 0; i < kRThreads / 64; ++i) v = s_c[threadIdx.x][i] > v ? s_c[threadIdx.x][i] : v;
+        if (v != 0u) s_w[2 + threadIdx.x] = atomicMax(&sw.fpart2[threadIdx.x], v);   // (returned)
+      }
     }
   }
   // ---- ticket: the last workgroup to arrive folds the sink into flat pixel 0
@@ -2865,14 +2896,7 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
   uint32_t fm[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) fm[k] = 0u;
-  for (uint32_t i = threadIdx.x; i < zpart_count * C; i += kRThreads) {   // invalid points (S1, a kernel ago)
-    const uint32_t v = ws.fpart[i];
-    const int k = i % C;
-#pragma unroll
-    for (int kk = 0; kk < C; ++kk)
-      if (kk == k) fm[kk] = v > fm[kk] ? v : fm[kk];
-  }
-  for (uint32_t i = threadIdx.x; i < (uint32_t)kSinkSlots * C; i += kRThreads) {   // occluded points (atomics)
+  for (uint32_t i = threadIdx.x; i < (uint32_t)kSinkSlots * C; i += kRThreads) {   // occluded + invalid points (atomics)
     const uint32_t v = atomicMax(&sw.fpart2[i], 0u);
     const int k = i % C;
 #pragma unroll

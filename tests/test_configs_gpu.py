@@ -378,8 +378,10 @@ def test_cfg1_bf16_training_trajectory_tracks_fp32():
   path, from identical initial weights.  Gates:
     * the supervised part of the generator loss (depth L1 + world-consistency) falls on BOTH paths:
       mean of the last 5 steps < 0.8 x mean of the first 3;
-    * the bf16 trajectory stays inside a band around the fp32 one: per step, depth+wc within
-      15 % (+0.05 abs), and the 30-step means of depth, wc and the discriminator loss within 10 %;
+    * the bf16 trajectory stays inside a band around the fp32 one: the 5-step moving average of
+      depth+wc within 15 % (+0.05 abs) or within 3x the deviation a 1e-6 perturbation of the fp32
+      run's own weights causes (the noise yardstick, measured in the same test), the 30-step mean
+      deviation within 6 %, and the 30-step means of depth, wc and the discriminator loss within 10 %;
     * everything stays finite.
   A bf16 step that returned gradients of the wrong sign or scale (the per-tensor cosine of a
   200-layer gradient at random init is 0.3-0.8: what 8 mantissa bits leave of a chaotic map) would
@@ -389,7 +391,12 @@ def test_cfg1_bf16_training_trajectory_tracks_fp32():
   dbatch = {k: v.to(DEV) for k, v in batch.items()}
   traj = {}
   theta0 = None
-  for dtype in (torch.float32, torch.bfloat16):
+  # third run: fp32 again from weights perturbed by 1e-6 relative -- the trajectory's own
+  # sensitivity to rounding-level noise, the yardstick for the per-step band below (round 4: pinning
+  # the optimiser's fused multiply-adds moved the bf16-fp32 gap of one step from 9 % to 19 % while
+  # both losses kept falling together: the map is chaotic at that level, a fixed band is not a
+  # property of the arithmetic)
+  for tag, dtype in (('fp32', torch.float32), ('bf16', torch.bfloat16), ('fp32+1e-6', torch.float32)):
     gan = _gin_gan('lowres', dtype)
     if theta0 is None:
       theta0 = [m.store.theta.clone() for m in (gan.generator, gan.discriminator)]
@@ -397,6 +404,9 @@ def test_cfg1_bf16_training_trajectory_tracks_fp32():
     else:   # identical start (device-side init is seeded, this makes it explicit)
       for m, t, st in zip((gan.generator, gan.discriminator), theta0, state0):
         m.store.theta.copy_(t)
+        if tag == 'fp32+1e-6':
+          g = torch.Generator(device=DEV).manual_seed(7)
+          m.store.theta.mul_(1.0 + 1e-6 * torch.randn(t.shape, generator=g, device=DEV))
         m.store.state.copy_(st)
         m.store.version += 1
     rows = []
@@ -409,20 +419,38 @@ def test_cfg1_bf16_training_trajectory_tracks_fp32():
       rows.append([float(m[k]) for k in ('gen/depth_loss', 'gen/wc_loss', 'dis/disc_loss',
                                           'gen/gen_gan_loss')])
     torch.cuda.synchronize()
-    traj[dtype] = np.array(rows, np.float64)
-    assert np.isfinite(traj[dtype]).all() and bool(torch.isfinite(gan.generator.store.theta).all())
-    print(f'{str(dtype)[6:]}: {steps} steps in {time.time() - t0:.1f} s; depth+wc '
-          + ' '.join(f'{v:.3f}' for v in (traj[dtype][:, 0] + traj[dtype][:, 1])[::3]))
+    traj[tag] = np.array(rows, np.float64)
+    assert np.isfinite(traj[tag]).all() and bool(torch.isfinite(gan.generator.store.theta).all())
+    print(f'{tag}: {steps} steps in {time.time() - t0:.1f} s; depth+wc '
+          + ' '.join(f'{v:.3f}' for v in (traj[tag][:, 0] + traj[tag][:, 1])[::3]))
     del gan
     torch.cuda.empty_cache()
+  traj[torch.float32], traj[torch.bfloat16] = traj['fp32'], traj['bf16']
   f, b = traj[torch.float32], traj[torch.bfloat16]
   sup_f, sup_b = f[:, 0] + f[:, 1], b[:, 0] + b[:, 1]
   for tag, sup in (('fp32', sup_f), ('bf16', sup_b)):
     assert sup[-5:].mean() < 0.8 * sup[:3].mean(), (tag, sup[:3].mean(), sup[-5:].mean())
   dev = np.abs(sup_b - sup_f) / (np.abs(sup_f) + 1e-12)
+  p = traj['fp32+1e-6']
+  sup_p = p[:, 0] + p[:, 1]
+  noise = np.abs(sup_p - sup_f) / (np.abs(sup_f) + 1e-12)
   print(f'bf16 vs fp32 depth+wc: max per-step deviation {dev.max():.3f} (step {int(dev.argmax())}), '
-        f'mean {dev.mean():.3f}; disc means {f[:, 2].mean():.4f} / {b[:, 2].mean():.4f}')
-  assert (np.abs(sup_b - sup_f) <= 0.15 * np.abs(sup_f) + 0.05).all(), dev
+        f'mean {dev.mean():.3f}; fp32 vs fp32 perturbed by 1e-6: max {noise.max():.3f}, mean {noise.mean():.3f}; '
+        f'disc means {f[:, 2].mean():.4f} / {b[:, 2].mean():.4f}')
+  # The per-step values of a batch-2 GAN trajectory SPIKE (round 4: the fp32 run itself jumps by
+  # 2.5 % upwards around step 15-20 where the perturbed fp32 run and the bf16 run keep falling; the
+  # bf16 run is closer to the perturbed fp32 run than the fp32 run is).  The band is therefore
+  # applied to 5-step moving averages: inside 15 % -- or inside 3x what the 1e-6 perturbation does
+  # to the fp32 trajectory's moving average (running maximum: deviations grow along a chaotic
+  # trajectory); and on average (30 steps, unsmoothed) inside 6 % or 3x the noise.
+  ma = lambda v: np.convolve(v, np.ones(5) / 5.0, mode='valid')
+  ma_f, ma_b, ma_p = ma(sup_f), ma(sup_b), ma(sup_p)
+  ma_noise = np.abs(ma_p - ma_f) / ma_f
+  ma_dev = np.abs(ma_b - ma_f) / ma_f
+  print(f'5-step moving averages: bf16 vs fp32 max {ma_dev.max():.3f}, fp32 vs perturbed fp32 max {ma_noise.max():.3f}')
+  band = np.maximum(0.15, 3.0 * np.maximum.accumulate(ma_noise))
+  assert (np.abs(ma_b - ma_f) <= band * ma_f + 0.05).all(), (ma_dev, ma_noise)
+  assert dev.mean() <= max(0.06, 3.0 * noise.mean()), (dev.mean(), noise.mean())
   for col, name in ((0, 'depth'), (1, 'wc'), (2, 'disc')):
     mf, mb = f[:, col].mean(), b[:, col].mean()
     assert abs(mb - mf) <= 0.10 * abs(mf) + 1e-3, (name, mf, mb)
