@@ -13,6 +13,7 @@ from se3ds_amd import _lib
 from se3ds_amd import constants
 from se3ds_amd.models import image_models
 from se3ds_amd.utils import pano_utils
+from se3ds_amd.utils import point_cloud_utils
 
 
 def _quantize(x: torch.Tensor, out_dtype, mul=1.0, div=1.0, lo=0.0, hi=0.0, pre=None):
@@ -127,11 +128,20 @@ class SE3DSModel(object):
         rgb_coords=torch.zeros((self.batch_size, 4, 0), device=d),
         rgb=torch.zeros((self.batch_size, 0, 3), dtype=torch.int32, device=d))
 
+  @staticmethod
+  def _clone_state(state):
+    out = []
+    for t in state:
+      c = t.clone()
+      point_cloud_utils.propagate_int_range(c, t)   # (a copy keeps values and their known bounds)
+      out.append(c)
+    return MemoryState(*out)
+
   def get_memory_state(self) -> MemoryState:
-    return MemoryState(*[t.clone() for t in self._memory])
+    return self._clone_state(self._memory)
 
   def set_memory_state(self, state: MemoryState):
-    self._memory = MemoryState(*[t.clone() for t in state])
+    self._memory = self._clone_state(state)
 
   def write_memory_as_pointcloud(self, filename):
     """Writes memory at batch position 0 to an ASCII .ply file (reference :154-178)."""
@@ -172,11 +182,18 @@ class SE3DSModel(object):
     f_rgb_xyz1, f_rgb = pano_utils.compact_valid_points(rgb_xyz1, rgb_feats,
                                                         constants.INVALID_RGB_VALUE)
     f_rgb = f_rgb.to(self._memory.rgb.dtype)
+    # (the 'bilinear' unprojection returns fp32 like tf.image.resize; its values are still pano_rgb's
+    # integers or the void class, so pano_rgb's known bounds hold for the int32 copy)
+    point_cloud_utils.propagate_int_range(f_rgb, pano_rgb, extra=(constants.INVALID_RGB_VALUE,))
+    rgb_mem = torch.cat([self._memory.rgb, f_rgb], dim=1)
+    # (a concatenation keeps values: the known [-1, 255] bounds of both parts carry over, so the
+    # packed splat's byte-range promise for the grown memory needs no device read-back)
+    point_cloud_utils.propagate_int_range(rgb_mem, self._memory.rgb, f_rgb)
     self.set_memory_state(MemoryState(
         coords=torch.cat([self._memory.coords, f_xyz1], dim=2),
         feats=torch.cat([self._memory.feats, f_feats], dim=1),
         rgb_coords=torch.cat([self._memory.rgb_coords, f_rgb_xyz1], dim=2),
-        rgb=torch.cat([self._memory.rgb, f_rgb], dim=1)))
+        rgb=rgb_mem))
 
   def __call__(self, position, add_preds_to_memory: bool = False, sample_noise: bool = False,
                use_projected_rgb: bool = False, z: Optional[torch.Tensor] = None) -> OutputData:

@@ -136,6 +136,8 @@ def equirectangular_to_pointcloud(feats: torch.Tensor, depth: torch.Tensor, void
               prev[4] == float(void_class))
       ok = ok and (prev[0] if same else off == 0)
     point_cloud_utils.set_byte_range(res, ok, void_class)
+    if out is None:
+      point_cloud_utils.propagate_int_range(res, feats, extra=(void_class,))
   if out is not None:
     xyz1, res = xyz1[:, :, off:off + h * w], res[:, off:off + h * w]
   if is_scalar:
@@ -176,6 +178,7 @@ def mask_pano(pano: torch.Tensor, proportion: float = 0.125, masked_region_value
                                   masked_height, float(masked_region_value), _lib.ptr(out),
                                   _lib.stream())
   _lib.check(rc, 'se3ds_mask_pano')
+  point_cloud_utils.propagate_int_range(out, pano, extra=(masked_region_value,))
   return out
 
 
@@ -328,7 +331,9 @@ def compact_valid_points(xyz1: torch.Tensor, feats: torch.Tensor, void_class: fl
                              _lib.ptr(ws), ws.numel(), _lib.stream())
   _lib.check(rc, 'se3ds_compact_valid')
   k = int(cnt.item())
-  return xo[:, :, :k].contiguous(), fo[:, :k].contiguous()
+  fk = fo[:, :k].contiguous()
+  point_cloud_utils.propagate_int_range(fk, feats)   # (a compaction keeps values)
+  return xo[:, :, :k].contiguous(), fk
 
 
 # ------------------------------------------------------------------ fused perspective paths

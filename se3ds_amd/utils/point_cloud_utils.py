@@ -137,6 +137,39 @@ def set_int_range(t: torch.Tensor, lo: int, hi: int):
   t._se3ds_int_range = (int(lo), int(hi), t.data_ptr(), t._version, tuple(t.shape))
 
 
+def get_int_range(t: torch.Tensor):
+  """(lo, hi) recorded by set_int_range while the tensor is unchanged, else None."""
+  rng = getattr(t, '_se3ds_int_range', None)
+  if rng is not None and rng[2:] == (t.data_ptr(), t._version, tuple(t.shape)):
+    return rng[0], rng[1]
+  return None
+
+
+def propagate_int_range(dst: torch.Tensor, *srcs, extra=()):
+  """dst holds only values of `srcs` (copies, gathers, concatenations, compactions) and the
+  integers in `extra` (a void class): its bounds are the union of theirs -- when every source's
+  bounds are known.  Keeps byte_range() free of device read-backs along the model's call graph
+  (quantise -> mask_pano -> unproject -> compact -> concat -> splat)."""
+  if dst.dtype != torch.int32:
+    return
+  lo = hi = None
+  for t in srcs:
+    if t.numel() == 0:
+      continue
+    r = get_int_range(t)
+    if r is None:
+      return
+    lo = r[0] if lo is None else min(lo, r[0])
+    hi = r[1] if hi is None else max(hi, r[1])
+  for v in extra:
+    if float(v) != int(v):
+      return
+    lo = int(v) if lo is None else min(lo, int(v))
+    hi = int(v) if hi is None else max(hi, int(v))
+  if lo is not None:
+    set_int_range(dst, lo, hi)
+
+
 def byte_range(t: torch.Tensor, void_class: float) -> bool:
   """True when the splat may be promised SE3DS_FEAT_BYTE_RANGE for `t` (uint8: by type; int32:
   every element is `void_class` or in [0, 255]).  Known bounds (set_int_range) answer at once;
@@ -148,9 +181,9 @@ def byte_range(t: torch.Tensor, void_class: float) -> bool:
   if t.dtype != torch.int32:
     return False
   same = (t.data_ptr(), t._version, tuple(t.shape))
-  rng = getattr(t, '_se3ds_int_range', None)
-  if rng is not None and rng[2:] == same:
-    lo, hi = rng[0], rng[1]
+  rng = get_int_range(t)
+  if rng is not None:
+    lo, hi = rng
     if hi <= 255 and (lo >= 0 or (lo == -1 and float(void_class) == -1.0)):
       return True
   ent = getattr(t, '_se3ds_byte_range', None)

@@ -539,6 +539,11 @@ def test_cfg2_inference_256x512_fp32_with_warp():
     np.testing.assert_array_equal(ms.rgb_coords.cpu().numpy(), oracle.rgb_coords, tag)
     np.testing.assert_array_equal(ms.rgb.cpu().numpy(), oracle.rgb, tag)
   check_memory('after add_to_memory')
+  # the RGB memory's [-1, 255] bounds are known by construction along quantise -> mask_pano ->
+  # unproject -> compact -> concat -> copy: the packed splat's byte-range promise needs no device
+  # read-back (one blocking .item() per frame otherwise)
+  from se3ds_amd.utils import point_cloud_utils
+  assert point_cloud_utils.get_int_range(model._memory.rgb) == (-1, 255)
   # 2 feedback frames + 1 plain call (gan_manager.py:458-556's loop body; models.py:334-346; the
   # 4-frame roll-out proper is test_autoregressive_rollout_vs_oracle).
   # After every frame the oracle's memory is re-synchronised to the HIP memory: the fed-back
