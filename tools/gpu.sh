@@ -11,6 +11,7 @@
 #   prof_warp TAG [ENV=v ...]   kernel stats of the warp bench, random + room depth
 #   pmc_conv TAG "SHAPE"        MFMA-busy / FETCH / WRITE counters of tools/one_conv.py SHAPE (3 passes)
 #   pmc_warp TAG                FETCH / WRITE counters of the warp kernels (2 passes)
+#   pmc_step TAG [ENV=v ...]    MFMA-busy + shader clock of every kernel inside the step (1 pass, tools/pmc_step.py)
 #   py <file.py> [args]         any python tool
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -93,6 +94,15 @@ task_pmc_warp() {
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_tmp_w -o pmc -- python bench.py --workload warp --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
   python tools/pmc_summary.py gpurun_out/${tag}_warp_pmc.json --source=se3ds_amd/csrc/geom.hip "gpurun_out/pmc_tmp_f/*.db" "gpurun_out/pmc_tmp_w/*.db" 'splat|unproject'
   rm -rf gpurun_out/pmc_tmp_*
+}
+task_pmc_step() {
+  local tag=$1; shift
+  rm -rf gpurun_out/pmc_tmp_s
+  ( for v in "$@"; do export "$v"; done
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmc_tmp_s -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batch-max --no-warp --no-shipped > gpurun_out/pmc_step_$tag.log 2>&1 )
+  tail -1 gpurun_out/pmc_step_$tag.log | cut -c1-300
+  python tools/pmc_step.py "gpurun_out/pmc_tmp_s/*.db" gpurun_out/${tag}_step_pmc.json 40
+  rm -rf gpurun_out/pmc_tmp_s
 }
 task_py() { timeout 1500 python "$@"; }
 args=()
