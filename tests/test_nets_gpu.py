@@ -125,6 +125,17 @@ def test_conv_macro_tile_fwd_bwd(case, halo, monkeypatch):
   _run_conv_case(case, torch.bfloat16)
 
 
+@pytest.mark.parametrize('stages', ['0', '3', '4'])
+@pytest.mark.parametrize('case', [c for c in BIG_TILE_CASES if c[2] == 128 and c[3] == 3 and c[4] == 1])
+def test_conv_halo_128_channel_variants(case, stages, monkeypatch):
+  """The 128-output-channel halo layers: 4-wave workgroups with 32-channel K steps and three / four
+  weight stages (round 4, the default is four) and the 8-wave kernel they replace (stages=0)."""
+  monkeypatch.setenv('SE3DS_BIG_TILE', '1')
+  monkeypatch.setenv('SE3DS_HALO_TILE', '1')
+  monkeypatch.setenv('SE3DS_HALO_4W', stages)
+  _run_conv_case(case, torch.bfloat16)
+
+
 @pytest.mark.parametrize('k,cin,cout', [(3, 128, 128), (2, 64, 256)])
 def test_conv_transpose_macro_tile(k, cin, cout, monkeypatch):
   monkeypatch.setenv('SE3DS_BIG_TILE', '1')
