@@ -1422,6 +1422,8 @@ igemm_halo_kernel(const IgemmParams p) {
 // workgroup is the four pixel blocks of one 8 x 32 patch (4 waves), and TWO workgroups share a CU:
 // K steps of 32 channels (64-byte LDS rows) keep a workgroup at 2 x 22 KiB of patch + WST x 8 KiB of
 // weights, and the second workgroup's K loop runs under the first one's barriers and epilogue.
+// OPT-IN (SE3DS_HALO_4W=3|4): faster alone, slower inside the power-limited step -- see
+// halo_4w_stages() below.
 // Schedule (as wgrad_taps3_kernel): software-pipelined inside the wave, ONE barrier per K step --
 //   wait(q0 fragments) -> read q1 -> 8 MFMAs (q0) -> vmcnt -> BARRIER (weights of step k+1 landed
 //   everywhere, stage of step k-1 free) -> LDS-DMA of step k+WST-1's weights (+ one piece of the
@@ -3775,11 +3777,16 @@ static int halo_tile_channels(const IgemmParams& p) {
   return eff256 >= eff128 ? 256 : 128;
 }
 
-// SE3DS_HALO_4W: weight stages of igemm_halo4w_kernel for the 128-channel halo layers (3 / 4),
-// 0 = the 8-wave igemm_halo_kernel<., 128, 3>.  Read per call (tests switch it).
+// SE3DS_HALO_4W: 3 / 4 = igemm_halo4w_kernel with that many weight stages for the 128-channel halo
+// layers; default 0 = the 8-wave igemm_halo_kernel<., 128, 3>.  Read per call (tests switch it).
+// Measured (round 4): alone the 4-wave kernel is 13-43 % faster (tools/conv_bench.py)
+// and 6-8 % faster inside the serial instrumented step (128->128 layers 31.0 -> 29.0 ms), but the
+// other conv kernels of that same step then take 1.5 ms LONGER and the overlapped step is 2-3 ms
+// SLOWER (202.9 -> 205.4 ms): higher MFMA occupancy, lower shader clock (2.02 -> 1.93 GHz in the
+// PMC pass) -- the step is power-limited, and this kernel saves time, not energy.
 static int halo_4w_stages() {
   const char* e = getenv("SE3DS_HALO_4W");
-  const int v = e ? atoi(e) : 4;
+  const int v = e ? atoi(e) : 0;
   return v == 3 || v == 4 ? v : 0;
 }
 

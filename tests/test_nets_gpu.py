@@ -129,7 +129,8 @@ def test_conv_macro_tile_fwd_bwd(case, halo, monkeypatch):
 @pytest.mark.parametrize('case', [c for c in BIG_TILE_CASES if c[2] == 128 and c[3] == 3 and c[4] == 1])
 def test_conv_halo_128_channel_variants(case, stages, monkeypatch):
   """The 128-output-channel halo layers: 4-wave workgroups with 32-channel K steps and three / four
-  weight stages (round 4, the default is four) and the 8-wave kernel they replace (stages=0)."""
+  weight stages (round 4, opt-in: faster alone, slower inside the power-limited step) and the
+  default 8-wave kernel (stages=0)."""
   monkeypatch.setenv('SE3DS_BIG_TILE', '1')
   monkeypatch.setenv('SE3DS_HALO_TILE', '1')
   monkeypatch.setenv('SE3DS_HALO_4W', stages)
