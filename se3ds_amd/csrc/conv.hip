@@ -390,6 +390,161 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
   }
 }
 
+// The same epilogue for accumulators of v_mfma_f32_16x16x32_bf16 (igemm_halo_kernel<..., M16>): 64
+// channels x 64 pixels of one wave as acc[i][j], i = 16-channel block, j = 16-pixel block (j >> 1 =
+// the 32-pixel fragment, j & 1 its half); lane (g = lane / 16, c = lane % 16) holds channels
+// i*16 + g*4 .. +3 of pixel c of block j.  Only the parking phase differs from
+// store_wave_lds_impl<2, 32>: scratch layout, statistics and write-back are shared.
+// opix[j]: output pixel of (block j, lane % 16) or -1.
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+template <bool BNB = false>
+__device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (&acc)[4][4],
+                                                 const int64_t (&opix)[4], int co_base, int lane,
+                                                 unsigned char* scratch, float* stats_row = nullptr) {
+  constexpr int NI = 2, PXC = 32;
+  constexpr int RB = NI * 64 + 16;   // padded row bytes
+  constexpr int LPP = NI * 4;        // lanes per pixel in the write-back
+  constexpr int PPI = 64 / LPP;      // pixels per store instruction
+  const float scale = p.scale ? *p.scale : 1.0f;
+  const int g = lane >> 4, c16 = lane & 15;
+  const float slope = p.act == 0 ? 1.0f : (p.act == 1 ? 0.0f : p.act_alpha);
+  uint16_t* __restrict__ out = (uint16_t*)p.out;
+  int64_t* offs = reinterpret_cast<int64_t*>(scratch + PXC * RB);
+  float4 bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    bv[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + co_base + i * 16 + g * 4)
+                   : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int form = p.row_a ? (p.bias ? 3 : 2) : (p.bias ? 1 : 0);
+  float cs1 = 0.f, cs2 = 0.f;
+  const bool bnb = BNB && stats_row != nullptr && p.bn_x != nullptr;
+  float bs1[8], bs2[8], bmu[8];
+  if (BNB && bnb) {
+    const int c0 = co_base + (lane % LPP) * 8;
+#pragma unroll
+    for (int h4 = 0; h4 < 2; ++h4) {
+      const float4 m4 = *reinterpret_cast<const float4*>(p.bn_mean + c0 + h4 * 4);
+      bmu[h4 * 4] = m4.x; bmu[h4 * 4 + 1] = m4.y; bmu[h4 * 4 + 2] = m4.z; bmu[h4 * 4 + 3] = m4.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs1[e] = 0.f; bs2[e] = 0.f; }
+  }
+#pragma unroll
+  for (int J = 0; J < 2; ++J) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = J * 2 + jj;
+      const int64_t o = opix[j];
+      const int64_t oc = o < 0 ? 0 : o;
+      const float ra = p.row_a ? p.row_a[oc] : 1.0f;
+      const float rb = p.row_b ? p.row_b[oc] : 1.0f;
+      const int lp = jj * 16 + c16;
+      if (g == 0) offs[lp] = o;
+      auto emit = [&](auto form_c) {
+        constexpr int F = decltype(form_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float b4[4] = {bv[i].x, bv[i].y, bv[i].z, bv[i].w};
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t = acc[i][j][e] * scale;
+            if (F == 1) t = t + b4[e];
+            else if (F == 2) t = t * ra;
+            else if (F == 3) t = ((t - b4[e]) * ra + b4[e]) * rb;
+            v[e] = t > 0.f ? t : t * slope;
+          }
+          uint2 pk;
+          pk.x = pack2_bf16(v[0], v[1]);
+          pk.y = pack2_bf16(v[2], v[3]);
+          if (o < 0) pk = make_uint2(0u, 0u);   // (keeps the column sums clean)
+          *reinterpret_cast<uint2*>(scratch + lp * RB + (i * 16 + g * 4) * 2) = pk;
+        }
+      };
+      if (form == 0) emit(std::integral_constant<int, 0>());
+      else if (form == 1) emit(std::integral_constant<int, 1>());
+      else if (form == 2) emit(std::integral_constant<int, 2>());
+      else emit(std::integral_constant<int, 3>());
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (stats_row != nullptr && !bnb) {
+      // batch-norm statistics of the stored (rounded) outputs: lane = channel
+#pragma unroll 8
+      for (int px = 0; px < PXC; ++px) {
+        const float v = bf16_to_f32(*reinterpret_cast<const uint16_t*>(scratch + px * RB + lane * 2));
+        cs1 += v;
+        cs2 += v * v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PXC / PPI; ++k) {
+      const int px = k * PPI + lane / LPP, c8 = lane % LPP;
+      uint4 v = *reinterpret_cast<const uint4*>(scratch + px * RB + c8 * 16);
+      const int64_t po = offs[px];
+      if (po >= 0) {
+        if (p.addend) {
+          const uint4 a = *reinterpret_cast<const uint4*>((const uint16_t*)p.addend + po * p.oC +
+                                                          co_base + c8 * 8);
+          uint32_t* vw = reinterpret_cast<uint32_t*>(&v);
+          const uint32_t* aw = reinterpret_cast<const uint32_t*>(&a);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
+            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+            vw[q] = pack2_bf16(lo, hi);
+          }
+        }
+        *reinterpret_cast<uint4*>(out + po * p.oC + co_base + c8 * 8) = v;
+        if (BNB && bnb) {
+          const int64_t e0 = po * p.oC + co_base + c8 * 8;
+          const uint4 xr = *reinterpret_cast<const uint4*>(p.bn_x + e0);
+          const unsigned mb = p.bn_mask ? p.bn_mask[e0 >> 3] : 0xffu;
+          const uint32_t* vw = reinterpret_cast<const uint32_t*>(&v);
+          const uint32_t* xw = reinterpret_cast<const uint32_t*>(&xr);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float d0 = __uint_as_float(vw[q] << 16) *
+                             act_grad_from_bit((mb >> (2 * q)) & 1u, p.bn_act, p.bn_alpha);
+            const float d1 = __uint_as_float(vw[q] & 0xffff0000u) *
+                             act_grad_from_bit((mb >> (2 * q + 1)) & 1u, p.bn_act, p.bn_alpha);
+            const float x0 = __uint_as_float(xw[q] << 16), x1 = __uint_as_float(xw[q] & 0xffff0000u);
+            bs1[2 * q] += d0;
+            bs2[2 * q] += d0 * (x0 - bmu[2 * q]);
+            bs1[2 * q + 1] += d1;
+            bs2[2 * q + 1] += d1 * (x1 - bmu[2 * q + 1]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (BNB && bnb) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int m = 8; m < 64; m <<= 1) {
+        bs1[e] += __shfl_xor(bs1[e], m, 64);
+        bs2[e] += __shfl_xor(bs2[e], m, 64);
+      }
+    }
+    if (lane < 8) {
+      float* r1 = stats_row + co_base + lane * 8;
+      float* r2 = stats_row + p.oC + co_base + lane * 8;
+      const float4 ra4 = *reinterpret_cast<const float4*>(p.bn_rstd + co_base + lane * 8);
+      const float4 rb4 = *reinterpret_cast<const float4*>(p.bn_rstd + co_base + lane * 8 + 4);
+      bs2[0] *= ra4.x; bs2[1] *= ra4.y; bs2[2] *= ra4.z; bs2[3] *= ra4.w;
+      bs2[4] *= rb4.x; bs2[5] *= rb4.y; bs2[6] *= rb4.z; bs2[7] *= rb4.w;
+      *reinterpret_cast<float4*>(r1) = make_float4(bs1[0], bs1[1], bs1[2], bs1[3]);
+      *reinterpret_cast<float4*>(r1 + 4) = make_float4(bs1[4], bs1[5], bs1[6], bs1[7]);
+      *reinterpret_cast<float4*>(r2) = make_float4(bs2[0], bs2[1], bs2[2], bs2[3]);
+      *reinterpret_cast<float4*>(r2 + 4) = make_float4(bs2[4], bs2[5], bs2[6], bs2[7]);
+    }
+  } else if (stats_row != nullptr) {
+    stats_row[co_base + lane] = cs1;
+    stats_row[p.oC + co_base + lane] = cs2;
+  }
+}
+
 template <int NI, bool BNB = false>
 __device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&acc)[NI][2],
                                                const int64_t (&opix)[2], int co_base, int lane,
@@ -1133,9 +1288,17 @@ igemm_big_kernel(const IgemmParams p) {
 //   pixel (y0 + a, x0 + b) is patch pixel (a + dy, b + dx) with (dy, dx) = (ky, kx) forward and
 //   (2 - ky, 2 - kx) for the data gradient.  16-byte chunks are XOR-swizzled with (r >> 1) & 7;
 //   the 32 consecutive rows of a fragment read stay conflict-free for any start row.
-template <int MODE, int CO, int WST, bool BNB = false>
+// M16 (round 4): the MFMAs are v_mfma_f32_16x16x32_bf16 -- twice as many as of the 32x32x16 shape
+// for the same fragment bytes; the register-only probe
+// (tools/probes/mfma_ceiling.hip) sustains 1.80-1.86 PFLOP/s of them on random data against
+// 1.65-1.67 under the package power limit.  Fragments: lane (g = lane / 16, r = lane % 16) reads the
+// 16-byte chunk 4 * phase + g of row r of a 16-row block (conflict-free under the same swizzle);
+// accumulators acc16[i][j], i = 16-channel block (8 / 4), j = 16-pixel block (4); epilogue
+// store_wave_lds16.
+template <int MODE, int CO, int WST, bool BNB = false, bool M16 = false>
 __global__ void __launch_bounds__(512)
 igemm_halo_kernel(const IgemmParams p) {
+  constexpr int CB16 = CO / 32;   // M16: 16-channel blocks of a wave (8 / 4)
   typedef uint16_t T;
   constexpr int EPC = 8, ROW2 = 128, TH = 8, TW = 32, PC = TW + 2, XROWS = (TH + 2) * PC;
   constexpr int XPIECES = (XROWS + 7) / 8;          // 43 LDS-DMA pieces of 8 rows
@@ -1150,7 +1313,7 @@ igemm_halo_kernel(const IgemmParams p) {
   // MFMA-busy (its fragment reads book ~50 % of the 256 B/clk LDS pipe, one 1 KiB read per MFMA
   // against 0.75 for the 256-channel tile; the tap-fused weight gradient of the same layer,
   // with 1.2 half-size reads per MFMA and no activation-sized output, runs at 1 190 TFLOP/s).
-  constexpr int QP = 8 / (2 * NI), NP = 4 / QP;
+  constexpr int QP = 8 / (2 * NI), NP = 4 / QP;   // (M16: phase = (k32 step, channel half): 16 MFMAs)
   constexpr int DIST = WST - 1;   // weight tiles are fetched DIST K steps ahead
   static_assert(WST == 2 || WST == 3, "weight stages");
   __shared__ __attribute__((aligned(16))) unsigned char wst0[WT];
@@ -1234,7 +1397,8 @@ igemm_halo_kernel(const IgemmParams p) {
       __builtin_amdgcn_global_load_lds((gas_ptr)zlane, (las_ptr)sink, 16, 0, 0);
   };
 
-  f32x16_t acc[NI][2];
+  f32x16_t acc[M16 ? 1 : NI][2];
+  f32x4_t acc16[M16 ? CB16 : 1][M16 ? 4 : 1];
   // first patch slab and the first DIST weight tiles of the current item
   auto issue_prologue = [&]() {
 #pragma unroll
@@ -1255,6 +1419,12 @@ igemm_halo_kernel(const IgemmParams p) {
   int rb[2];   // patch row of this lane's pixel (tap offset 0) for the two 32-pixel fragments
 #pragma unroll
   for (int j = 0; j < 2; ++j) rb[j] = (wn * 2 + j) * PC + l32;
+  // M16: 16-row blocks.  Byte offset of this lane's chunk in phase 0; phase 1 is the same ^ 64
+  // (chunk index 4 * phase + g under the XOR swizzle); pixel block j sits j / 2 patch rows and
+  // (j & 1) * 16 columns behind block 0.
+  const int g16 = lane >> 4, r16 = lane & 15;
+  const int wo16 = (wm * (CO / 2) + r16) * ROW2 + ((g16 ^ ((r16 >> 1) & 7)) << 4);
+  int rb16 = wn * 2 * PC + r16;
 
   // Persistent over work items (grid = one workgroup per CU): the next item's prologue DMA is
   // issued before this item's epilogue, and the epilogue's stores drain under the next item's
@@ -1263,12 +1433,21 @@ igemm_halo_kernel(const IgemmParams p) {
   // regular K-step prefetch instead was measured slower (1.63 vs 1.43 ms on 3x3 128->128
   // @512x1024) and was dropped.
   for (;;) {
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < CB16; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+  } else {
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): prologue landed, older stores retired
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();   // ping-pong: channel half 1 runs one slot behind
@@ -1303,10 +1482,37 @@ igemm_halo_kernel(const IgemmParams p) {
       xr[j] = xcur + r * ROW2;
       xsw[j] = (r >> 1) & 7;
     }
+    int xo16[4];
+    uint4 xq16[M16 ? 4 : 1];
+    if constexpr (M16) {
+      asm volatile("" : "+v"(rb16));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rb16 + ((j >> 1) * PC + (j & 1) * 16 + toff);
+        xo16[j] = (r << 7) | ((g16 ^ ((r >> 1) & 7)) << 4);
+      }
+    }
 #pragma unroll
     for (int ph = 0; ph < NP; ++ph) {
       // ---- read slot
       uint4 wf[QP][NI], xf[QP][2];
+      uint4 wq16[M16 ? 4 : 1];
+      if constexpr (M16) {
+        // CO 256: phase = (k32 step ph / 2, 64-channel half ph % 2); the pixel fragments of a
+        // k32 step are read with its first half and stay in registers for the second.
+        // CO 128: phase = k32 step, all four 16-channel blocks.
+        constexpr int ks = CO == 256 ? 1 : 0;   // ph >> ks = k32 step
+        const int b0 = CO == 256 ? (ph & 1) * 4 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          wq16[i] = *reinterpret_cast<const uint4*>(wcur + (b0 + i) * 16 * ROW2 +
+                                                    (wo16 ^ ((ph >> ks) << 6)));
+        if (CO == 128 || (ph & 1) == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            xq16[j] = *reinterpret_cast<const uint4*>(xcur + (xo16[j] ^ ((ph >> ks) << 6)));
+        }
+      } else {
 #pragma unroll
       for (int qq = 0; qq < QP; ++qq) {
         const int c = (ph * QP + qq) * 2 + half;
@@ -1317,14 +1523,15 @@ igemm_halo_kernel(const IgemmParams p) {
         for (int j = 0; j < 2; ++j)
           xf[qq][j] = *reinterpret_cast<const uint4*>(xr[j] + ((c ^ xsw[j]) * 16));
       }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (NP == 4 && ph < 2) {
         issue_w(wnxt, 2 * ph, wfar, ntap, nslab, has_next);
         issue_w(wnxt, 2 * ph + 1, wfar, ntap, nslab, has_next);
       }
       if (NP == 2 && ph == 0) {
-        issue_w(wnxt, 0, wfar, ntap, nslab, has_next);
-        issue_w(wnxt, 1, wfar, ntap, nslab, has_next);
+#pragma unroll
+        for (int j = 0; j < WS; ++j) issue_w(wnxt, j, wfar, ntap, nslab, has_next);
       }
       if (ph == NP - 2 + (NP == 2)) issue_x(xnxt, xsl, xfar, xfm, xslab, x_piece);
       if (ph == NP - 1) {
@@ -1340,6 +1547,15 @@ igemm_halo_kernel(const IgemmParams p) {
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA slot
+      if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc16[(CO == 256 ? (ph & 1) * 4 : 0) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, wq16[i]), __builtin_bit_cast(bf16x8_t, xq16[j]),
+                acc16[(CO == 256 ? (ph & 1) * 4 : 0) + i][j], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int qq = 0; qq < QP; ++qq)
 #pragma unroll
@@ -1349,6 +1565,7 @@ igemm_halo_kernel(const IgemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                 __builtin_bit_cast(bf16x8_t, wf[qq][i]), __builtin_bit_cast(bf16x8_t, xf[qq][j]),
                 acc[i][j], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -1389,6 +1606,7 @@ igemm_halo_kernel(const IgemmParams p) {
     opix[j] = (y < p.oH && x < p.oW) ? ((int64_t)cur.img * p.oH + y) * p.oW + x : -1;
   }
   const int co_base = cur.n0 + wm * (CO / 2);
+  const int opy0 = cur.y0, opx0 = cur.x0, opimg = cur.img;
   // Every wave is past its last fragment read.  xb1 is the epilogue scratch (the last K steps'
   // idle copies only touch `sink`); xb0 and the first weight stages hold / take the next item's
   // first slab and weight tiles.
@@ -1404,11 +1622,25 @@ igemm_halo_kernel(const IgemmParams p) {
   // so that the epilogue issues no global load, was measured slower: 1.62 vs 1.44 ms on the
   // 3x3 128->128 @512x1024 layer)
   unsigned char* scratch = xb1 + wave * kEpiScratch<2>;
+  if constexpr (M16) {
+    int64_t opix16[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = opy0 + wn * 2 + (j >> 1), x = opx0 + (j & 1) * 16 + r16;
+      opix16[j] = (y < p.oH && x < p.oW) ? ((int64_t)opimg * p.oH + y) * p.oW + x : -1;
+    }
+    store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[0]), opix16, co_base, lane,
+                          scratch, stats_row);
+    if (CO == 256)
+      store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[CB16 - 4]), opix16,
+                            co_base + 64, lane, scratch, stats_row);
+  } else {
   store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane,
                          scratch, stats_row);
   if (NI == 4)
     store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64,
                            lane, scratch, stats_row);
+  }
   if (!have) break;
   }
 }
@@ -2430,6 +2662,13 @@ wgrad_taps_kernel(const WgradTapsParams p) {
 //    vmcnt(0) in front of the reads).
 // Restrictions (the launcher falls back to wgrad_taps_kernel): no gather mask, no wrap, full
 // 128-channel dy blocks.
+// M16 (round 4): v_mfma_f32_16x16x32_bf16 (1.80-1.86 vs 1.65-1.67 PFLOP/s sustained under the
+// power limit, tools/probes/mfma_ceiling.hip).  A slot is one 32-pixel row of the step x one
+// 16-channel half of the wave's input channels: 18 MFMAs (3 x 3 taps x 2 output-channel blocks);
+// lane (g = lane / 16, i = lane % 16) holds pixels 8g .. 8g+7 of the row for channel i of a block
+// (the transposing reads give a 16-lane group 4 pixels x 16 channels); accumulators
+// acc16[tap][output block][input block], rows g*4 .. +3 = output channels, column i = input channel.
+template <bool M16>
 __global__ void __launch_bounds__(512)
 wgrad_taps3_kernel(const WgradTapsParams p) {
   typedef uint16_t T;
@@ -2531,11 +2770,23 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
     }
   };
 
-  f32x16_t acc[9];
+  f32x16_t acc[M16 ? 1 : 9];
+  f32x4_t acc16[M16 ? 9 : 1][2][2];
+  if constexpr (M16) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc16[t][cb][b][r] = 0.f;
+  } else {
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  }
 
   mask_ahead(fp, nsteps > 0);
   issue(fp, stage0, nsteps > 0);
@@ -2560,6 +2811,119 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
     xlane[pp] = (YT + (half * 8 + jrow) * XROW + ((xcol >> 3) << 4) + xlo) ^ (swz << 6);
   }
   const int ylane = (half * 8 + jrow) * YROW + yo;
+
+  if constexpr (M16) {
+    const int g4 = lane >> 4;                                    // pixel octet of the 32-pixel row
+    const int ycol6 = cw * 32 + qcol * 4;                        // (+ 16 per output block)
+    const int yo6 = (((ycol6 >> 3) ^ ((jrow & 3) << 2)) << 4) + ((ycol6 & 4) << 1);
+    const int ylane6 = (g4 * 8 + jrow) * YROW + yo6;
+    const int xcol6 = iw * 32 + qcol * 4;                        // (+ 16 per input block)
+    int xlane6[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int swz = pp ^ ((jrow >> 1) & 1);
+      xlane6[pp] = (YT + (g4 * 8 + jrow) * XROW + ((xcol6 >> 3) << 4) + ((xcol6 & 4) << 1)) ^ (swz << 6);
+    }
+    // dy fragments of row a: two 16-channel blocks (block 1 = chunk index + 2: bit 5, untouched by
+    // the row swizzle of bits 6-7)
+    auto read_y = [&](const unsigned char* cur, int a, uint4 (&yf)[2]) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const unsigned char* yp = cur + (ylane6 ^ (cb << 5)) + a * 32 * YROW;
+        uint2 v0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)yp));
+        uint2 v1 = __builtin_bit_cast(
+            uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(yp + 4 * YROW)));
+        yf[cb] = make_uint4(v0.x, v0.y, v1.x, v1.y);
+      }
+    };
+    // x windows (12 pixels) of row a, input block b, for the three tap rows
+    auto read_x = [&](const unsigned char* cur, int a, int b, uint2 (&xr)[3][3]) {
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const unsigned char* xp = cur + (xlane6[(a + ky) & 1] ^ (b << 5)) + (a + ky) * PC * XROW;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+          xr[ky][w] = __builtin_bit_cast(
+              uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(xp + w * 4 * XROW)));
+      }
+    };
+    auto mfma18 = [&](auto b_c, const uint4 (&yf)[2], const uint2 (&xr)[3][3]) {
+      constexpr int B = decltype(b_c)::value;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const uint2 v0 = xr[ky][0], v1 = xr[ky][1], v2 = xr[ky][2];
+        const uint4 f[3] = {make_uint4(v0.x, v0.y, v1.x, v1.y),
+                            make_uint4(__builtin_amdgcn_alignbit(v0.y, v0.x, 16),
+                                       __builtin_amdgcn_alignbit(v1.x, v0.y, 16),
+                                       __builtin_amdgcn_alignbit(v1.y, v1.x, 16),
+                                       __builtin_amdgcn_alignbit(v2.x, v1.y, 16)),
+                            make_uint4(v0.y, v1.x, v1.y, v2.x)};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+            acc16[ky * 3 + kx][cb][B] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, yf[cb]), __builtin_bit_cast(bf16x8_t, f[kx]),
+                acc16[ky * 3 + kx][cb][B], 0, 0, 0);
+      }
+    };
+#define TAPS_WAIT_LDS() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                             __builtin_amdgcn_sched_barrier(0); } while (0)
+    uint4 yE[2], yO[2];
+    uint2 xA[3][3], xB[3][3];
+    const std::integral_constant<int, 0> B0;
+    const std::integral_constant<int, 1> B1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): steps 0 and 1 landed
+    __builtin_amdgcn_s_barrier();
+    if (nsteps > 0) { read_y(stage0, 0, yE); read_x(stage0, 0, 0, xA); }
+    auto step = [&](unsigned char* cur, unsigned char* nxt, unsigned char* far, int st) {
+      TAPS_WAIT_LDS();
+      read_x(cur, 0, 1, xB);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma18(B0, yE, xA);
+      TAPS_WAIT_LDS();
+      read_y(cur, 1, yO);
+      read_x(cur, 1, 0, xA);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma18(B1, yE, xB);
+      TAPS_WAIT_LDS();
+      read_x(cur, 1, 1, xB);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma18(B0, yO, xA);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of step st+1 landed
+      __builtin_amdgcn_s_barrier();         // ... everyone's did; every wave is done with `far`
+      __builtin_amdgcn_sched_barrier(0);
+      issue(fp, far, st + 2 < nsteps);
+      advance(fp);
+      mask_ahead(fp, st + 3 < nsteps);
+      TAPS_WAIT_LDS();
+      if (st + 1 < nsteps) { read_y(nxt, 0, yE); read_x(nxt, 0, 0, xA); }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma18(B1, yO, xB);
+    };
+#undef TAPS_WAIT_LDS
+    for (int st = 0; st < nsteps; st += 3) {
+      step(stage0, stage1, stage2, st);
+      if (st + 1 < nsteps) step(stage1, stage2, stage0, st + 1);
+      if (st + 2 < nsteps) step(stage2, stage0, stage1, st + 2);
+    }
+    // acc16[t][cb][b][r]: ci = ci0 + iw*32 + b*16 + lane%16, co = co0 + cw*32 + cb*16 + 4*(lane/16) + r
+    const int64_t K6 = (int64_t)9 * p.Cin;
+    float* __restrict__ dw6 = p.dw + (int64_t)split * K6 * p.Cout;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int ci6 = ci0 + iw * 32 + b * 16 + (lane & 15);
+        float* row = dw6 + ((int64_t)t * p.Cin + ci6) * p.Cout + co0 + cw * 32 + g4 * 4;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          *reinterpret_cast<float4*>(row + cb * 16) =
+              make_float4(acc16[t][cb][b][0], acc16[t][cb][b][1], acc16[t][cb][b][2], acc16[t][cb][b][3]);
+      }
+    return;
+  }
 
   auto read_frag = [&](const unsigned char* cur, int kq, uint4& yf, uint2 (&xr)[3][3]) {
     const int a = kq >> 1;
@@ -3790,6 +4154,13 @@ static int halo_4w_stages() {
   return v == 3 || v == 4 ? v : 0;
 }
 
+// SE3DS_HALO_M16: the 8-wave halo kernels with v_mfma_f32_16x16x32_bf16 (default; 0 = 32x32x16;
+// read per call).  Step A/B on one box, 256-channel tile only: 204.3 / 202.6 -> 200.2 / 200.0 ms.
+static bool halo_m16() {
+  const char* e = getenv("SE3DS_HALO_M16");
+  return e ? atoi(e) != 0 : true;
+}
+
 static int big_tile_channels(const IgemmParams& p, int mode) {
   const int g_big_tile = big_tile_mode();
   if (g_big_tile == 0) return 0;
@@ -3935,7 +4306,11 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       p.halo_tx = ceil_div(p.oW, 32);
       const int64_t items = (int64_t)p.N * p.halo_ty * p.halo_tx * (p.oC / co);
       dim3 grid((unsigned)(items < 256 ? items : 256));   // persistent: one workgroup per CU
-      if (co == 256) {
+      if (co == 256 && halo_m16()) {
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256, 2, false, true>), grid, dim3(512), 0, s, p);
+        else if (p.bn_x) hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2, true, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2, false, true>), grid, dim3(512), 0, s, p);
+      } else if (co == 256) {
         if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256, 2>), grid, dim3(512), 0, s, p);
         else if (p.bn_x) hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2>), grid, dim3(512), 0, s, p);
@@ -3949,7 +4324,11 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
         if (w4 == 3) { SE3DS_H4(3); } else { SE3DS_H4(4); }
 #undef SE3DS_H4
       } else {
-        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3>), grid, dim3(512), 0, s, p);
+        if (halo_m16()) {
+          if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3, false, true>), grid, dim3(512), 0, s, p);
+          else if (p.bn_x) hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3, true, true>), grid, dim3(512), 0, s, p);
+          else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3, false, true>), grid, dim3(512), 0, s, p);
+        } else if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3>), grid, dim3(512), 0, s, p);
         else if (p.bn_x) hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 128, 3>), grid, dim3(512), 0, s, p);
       }
@@ -4196,7 +4575,8 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
       dim3 tgrid((unsigned)(cin / 64), (unsigned)(cout / 128), (unsigned)tsplits);
       static const bool taps3 = [] { const char* e = getenv("SE3DS_WGRAD_TAPS3"); return !e || atoi(e) != 0; }();
       if (taps3 && !wrap_w)
-        hipLaunchKernelGGL(wgrad_taps3_kernel, tgrid, dim3(512), 0, s, q);
+        if (halo_m16()) hipLaunchKernelGGL(wgrad_taps3_kernel<true>, tgrid, dim3(512), 0, s, q);
+        else hipLaunchKernelGGL(wgrad_taps3_kernel<false>, tgrid, dim3(512), 0, s, q);
       else
         hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(512), 0, s, q);
       const int64_t tnel = (int64_t)9 * cin * cout;

@@ -137,6 +137,22 @@ def test_conv_halo_128_channel_variants(case, stages, monkeypatch):
   _run_conv_case(case, torch.bfloat16)
 
 
+@pytest.mark.parametrize('case', [c for c in BIG_TILE_CASES if c[2] % 128 == 0 and c[3] == 3 and c[4] == 1] + [
+    ('partial_spectral', 128, 256, 3, 1, 'VALID', 1, False, True, True, 2, 24, 40),   # gather mask, ragged tiles
+    ('plain', 256, 512, 3, 1, 'VALID', 1, True, False, False, 1, 16, 64),            # circular width, 2 channel tiles
+])
+@pytest.mark.parametrize('m16', ['0', '1'])
+def test_conv_halo_mfma_shapes(case, m16, monkeypatch):
+  """The 8-wave halo kernels with v_mfma_f32_16x16x32_bf16 (SE3DS_HALO_M16=1, the default: other
+  fragment and accumulator layouts, own epilogue parking) and with 32x32x16 (=0); forward, data
+  gradient and the fused statistics."""
+  monkeypatch.setenv('SE3DS_BIG_TILE', '1')
+  monkeypatch.setenv('SE3DS_HALO_TILE', '1')
+  monkeypatch.setenv('SE3DS_HALO_M16', m16)
+  monkeypatch.setenv('SE3DS_HALO_4W', '0')
+  _run_conv_case(case, torch.bfloat16)
+
+
 @pytest.mark.parametrize('k,cin,cout', [(3, 128, 128), (2, 64, 256)])
 def test_conv_transpose_macro_tile(k, cin, cout, monkeypatch):
   monkeypatch.setenv('SE3DS_BIG_TILE', '1')
