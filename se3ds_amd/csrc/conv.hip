@@ -598,6 +598,32 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)
     if (opix[j] >= 0) store_pixel<T, NI>(p, acc, j, opix[j], co_base, half, scale);
 }
 
+// store_tile for the 16x16x32 accumulator layout (bf16, LDS epilogue only): CB 16-channel blocks
+// of one wave as acc[CB][4]; pixel block j holds tile rows m_base + j*16 + lane % 16.
+template <int MODE, int CB, bool BNB = false>
+__device__ __forceinline__ void store_tile16(const IgemmParams& p, f32x4_t (&acc)[CB][4], int64_t m_base,
+                                             int co_base, int64_t Mc, int cH, int cW, int py, int px,
+                                             int lane, unsigned char* scratch, float* stats_row) {
+  const int s = p.stride;
+  int64_t opix[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t m = m_base + j * 16 + (lane & 15);
+    opix[j] = -1;
+    if (m >= Mc) continue;
+    const int n = (int)(m / ((int64_t)cH * cW));
+    const int rem = (int)(m - (int64_t)n * cH * cW);
+    int a = rem / cW, b = rem - a * cW;
+    if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
+    opix[j] = ((int64_t)n * p.oH + a) * p.oW + b;
+  }
+  store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[0]), opix, co_base, lane, scratch,
+                        stats_row);
+  if (CB == 8)
+    store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[CB - 4]), opix, co_base + 64, lane,
+                          scratch, stats_row);
+}
+
 template <typename T, int MODE>
 __global__ void __launch_bounds__(kThreads, 2)
 igemm_kernel(const IgemmParams p) {
@@ -851,9 +877,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned char* lds) {
                                                     // these kernels uses it on gfx950)
 }
 
-template <typename T, int MODE, bool BNB = false>
+// M16 (bf16 only): v_mfma_f32_16x16x32_bf16 (see igemm_halo_kernel).
+template <typename T, int MODE, bool BNB = false, bool M16 = false>
 __global__ void __launch_bounds__(kThreads, 2)
 igemm_glds_kernel(const IgemmParams p) {
+  static_assert(!M16 || sizeof(T) == 2, "16x16x32: bf16");
   using tt = TT<T>;
   constexpr int EPC = tt::EPC, BK2 = 2 * tt::BK;
   constexpr int ROW2 = 128, TILE2 = 128 * ROW2;
@@ -990,12 +1018,22 @@ igemm_glds_kernel(const IgemmParams p) {
   };
 
   f32x16_t acc[2][2], tot[2][2];
+  f32x4_t acc16[M16 ? 4 : 1][4];
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+  } else {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+  }
 
   if (nk > 0) {
     setup_tap(0);
@@ -1007,6 +1045,29 @@ igemm_glds_kernel(const IgemmParams p) {
     if (has_next) issue(nxt);   // DMA for the next tile flies under the MFMAs below
     const unsigned char* wt = cur;
     const unsigned char* xt = cur + TILE2;
+    if constexpr (M16) {
+      // two k32 steps per K step; lane (g, r): chunk 4 * step + g of row r of a 16-row block
+      const int g16 = lane >> 4, r16 = lane & 15;
+      const int sw16 = (g16 ^ ((r16 >> 1) & 7)) << 4;
+      const int wo16 = (wm * 64 + r16) * ROW2 + sw16, xo16 = TILE2 + (wn * 64 + r16) * ROW2 + sw16;
+#pragma unroll
+      for (int kp = 0; kp < 2; ++kp) {
+        uint4 wq[4], xq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          wq[i] = *reinterpret_cast<const uint4*>(cur + i * 16 * ROW2 + (wo16 ^ (kp << 6)));
+          xq[i] = *reinterpret_cast<const uint4*>(cur + i * 16 * ROW2 + (xo16 ^ (kp << 6)));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, wq[i]), __builtin_bit_cast(bf16x8_t, xq[j]), acc16[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+      return;
+    }
 #pragma unroll
     for (int kp = 0; kp < 2; ++kp) {
       uint4 wf[2][2], xf[2][2];
@@ -1037,8 +1098,13 @@ igemm_glds_kernel(const IgemmParams p) {
   // (DGRAD: only in the instantiation with fused batch-norm backward statistics)
   float* stats_row = ((MODE == MODE_FWD || BNB) && p.stats)
                          ? p.stats + ((int64_t)(tile_m * (BM / 64) + wn) * 2) * p.oC : nullptr;
+  if constexpr (M16) {
+    store_tile16<MODE, 4, BNB>(p, acc16, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py, px,
+                               lane, stage0 + wave * kEpiScratch<2>, stats_row);
+  } else {
   store_tile<T, MODE, 2, BNB>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py,
                               px, half, l32, stage0 + wave * kEpiScratch<2>, stats_row);
+  }
 }
 
 // ------------------------------------------------------------------ 256-pixel macro tiles
@@ -1049,9 +1115,11 @@ igemm_glds_kernel(const IgemmParams p) {
 // fill-bound; this tile doubles (CO = 128: x1.33) the FLOPs per byte filled and, with a
 // 128 x 64 wave tile, needs 0.75 fragment reads per MFMA instead of 1.  Requires oC % CO == 0
 // and reduction channels % 64 == 0, and the same gather restrictions as igemm_glds_kernel.
-template <int MODE, int CO, bool BNB = false>
+// M16: v_mfma_f32_16x16x32_bf16 (see igemm_halo_kernel).
+template <int MODE, int CO, bool BNB = false, bool M16 = false>
 __global__ void __launch_bounds__(512)
 igemm_big_kernel(const IgemmParams p) {
+  constexpr int CB16 = CO / 32;
   typedef uint16_t T;
   constexpr int EPC = 8, BK2 = 64, ROW2 = 128, PIX = 256;
   constexpr int WT = CO * ROW2, XT = PIX * ROW2, STAGE = WT + XT;
@@ -1174,13 +1242,23 @@ igemm_big_kernel(const IgemmParams p) {
     }
   };
 
-  f32x16_t acc[NI][2];
+  f32x16_t acc[M16 ? 1 : NI][2];
+  f32x4_t acc16[M16 ? CB16 : 1][4];
+  if constexpr (M16) {
+#pragma unroll
+    for (int i = 0; i < CB16; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+  } else {
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
 
   if (nk > 0) {
     setup_tap();
@@ -1194,6 +1272,11 @@ igemm_big_kernel(const IgemmParams p) {
   const int wrow0 = wm * (CO / 2) + l32, xrow0 = wn * 64 + l32;
   // (row >> 1) & 7 is unchanged by adding multiples of 32 rows: one swizzle term per operand
   const int wsw = (wrow0 >> 1) & 7, xsw = (xrow0 >> 1) & 7;
+  // M16: byte offsets of this lane's chunk in k32 step 0 (step 1: ^ 64); blocks are 16 rows apart
+  const int g16 = lane >> 4, r16 = lane & 15;
+  const int sw16 = (g16 ^ ((r16 >> 1) & 7)) << 4;
+  const int wo16 = (wm * (CO / 2) + r16) * ROW2 + sw16;
+  const int xo16 = WT + (wn * 64 + r16) * ROW2 + sw16;
 
   // Ping-pong schedule.  A K step is NP phases; a phase is a READ slot (fragment ds_reads for 8
   // MFMAs, plus LDS-DMA issue for the next tile) and an MFMA slot (8 MFMAs = 256 pipe cycles),
@@ -1213,10 +1296,24 @@ igemm_big_kernel(const IgemmParams p) {
   auto k_step = [&](unsigned char* cur, unsigned char* nxt, const bool has_next) {
     const unsigned char* wt = cur + wrow0 * ROW2;
     const unsigned char* xt = cur + WT + xrow0 * ROW2;
+    uint4 xq16[M16 ? 4 : 1];
 #pragma unroll
     for (int ph = 0; ph < NP; ++ph) {
       // ---- read slot
       uint4 wf[QP][NI], xf[QP][2];
+      uint4 wq16[M16 ? 4 : 1];
+      if constexpr (M16) {
+        constexpr int ks = CO == 256 ? 1 : 0;   // ph >> ks = k32 step
+        const int b0 = CO == 256 ? (ph & 1) * 4 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          wq16[i] = *reinterpret_cast<const uint4*>(cur + (b0 + i) * 16 * ROW2 + (wo16 ^ ((ph >> ks) << 6)));
+        if (CO == 128 || (ph & 1) == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            xq16[j] = *reinterpret_cast<const uint4*>(cur + j * 16 * ROW2 + (xo16 ^ ((ph >> ks) << 6)));
+        }
+      } else {
 #pragma unroll
       for (int qq = 0; qq < QP; ++qq) {
         const int c = (ph * QP + qq) * 2 + half;
@@ -1226,6 +1323,7 @@ igemm_big_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           xf[qq][j] = *reinterpret_cast<const uint4*>(xt + j * 32 * ROW2 + ((c ^ xsw) * 16));
+      }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (has_next) {
@@ -1246,6 +1344,15 @@ igemm_big_kernel(const IgemmParams p) {
       __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
       __builtin_amdgcn_sched_barrier(0);
       // ---- MFMA slot
+      if constexpr (M16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc16[(CO == 256 ? (ph & 1) * 4 : 0) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, wq16[i]), __builtin_bit_cast(bf16x8_t, xq16[j]),
+                acc16[(CO == 256 ? (ph & 1) * 4 : 0) + i][j], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int qq = 0; qq < QP; ++qq)
 #pragma unroll
@@ -1255,6 +1362,7 @@ igemm_big_kernel(const IgemmParams p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                 __builtin_bit_cast(bf16x8_t, wf[qq][i]), __builtin_bit_cast(bf16x8_t, xf[qq][j]),
                 acc[i][j], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -1269,9 +1377,17 @@ igemm_big_kernel(const IgemmParams p) {
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
   float* stats_row = ((MODE == MODE_FWD || BNB) && p.stats)
                          ? p.stats + ((int64_t)(tile_m * (PIX / 64) + wn) * 2) * p.oC : nullptr;
+  if constexpr (M16) {
+    if ((p.oC & 7) == 0) {   // (always: oC % CO == 0)
+      store_tile16<MODE, CB16, BNB>(p, acc16, (int64_t)tile_m * PIX + wn * 64, n0 + wm * (CO / 2), Mc, cH,
+                                    cW, py, px, lane,
+                                    (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>, stats_row);
+    }
+  } else {
   store_tile<T, MODE, NI, BNB>(p, acc, (int64_t)tile_m * PIX + wn * 64, n0 + wm * (CO / 2), Mc, cH, cW,
                           py, px, half, l32,
                           (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>, stats_row);
+  }
 }
 
 // ------------------------------------------------------------------ halo-resident 3x3 tiles
@@ -4154,8 +4270,8 @@ static int halo_4w_stages() {
   return v == 3 || v == 4 ? v : 0;
 }
 
-// SE3DS_HALO_M16: the 8-wave halo kernels with v_mfma_f32_16x16x32_bf16 (default; 0 = 32x32x16;
-// read per call).  Step A/B on one box, 256-channel tile only: 204.3 / 202.6 -> 200.2 / 200.0 ms.
+// SE3DS_HALO_M16: the LDS-DMA forward / data-gradient kernels (halo, 256-pixel macro tile, 128 x 128)
+// and the tap-fused weight gradient with v_mfma_f32_16x16x32_bf16 (default; 0 = 32x32x16; read per call).  Step A/B on one box, 256-channel tile only: 204.3 / 202.6 -> 200.2 / 200.0 ms.
 static bool halo_m16() {
   const char* e = getenv("SE3DS_HALO_M16");
   return e ? atoi(e) != 0 : true;
@@ -4341,10 +4457,18 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       const int tiles = fill_classes(p, mode, 256);
       if (tiles <= 0) return SE3DS_OK;
       dim3 grid((unsigned)tiles, (unsigned)(p.oC / co));
-      if (co == 256) {
+      if (co == 256 && halo_m16()) {
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_big_kernel<MODE_FWD, 256, false, true>), grid, dim3(512), 0, s, p);
+        else if (p.bn_x) hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 256, true, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 256, false, true>), grid, dim3(512), 0, s, p);
+      } else if (co == 256) {
         if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_big_kernel<MODE_FWD, 256>), grid, dim3(512), 0, s, p);
         else if (p.bn_x) hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 256, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 256>), grid, dim3(512), 0, s, p);
+      } else if (halo_m16()) {
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_big_kernel<MODE_FWD, 128, false, true>), grid, dim3(512), 0, s, p);
+        else if (p.bn_x) hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 128, true, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 128, false, true>), grid, dim3(512), 0, s, p);
       } else {
         if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_big_kernel<MODE_FWD, 128>), grid, dim3(512), 0, s, p);
         else if (p.bn_x) hipLaunchKernelGGL((igemm_big_kernel<MODE_DGRAD, 128, true>), grid, dim3(512), 0, s, p);
@@ -4361,7 +4485,12 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_glds_kernel<float, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
       else hipLaunchKernelGGL((igemm_glds_kernel<float, MODE_DGRAD>), grid, dim3(kThreads), 0, s, p);
     } else {
-      if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
+      // (the 16x16x32 epilogue has no ragged channel tiles)
+      if ((p.oC % BN) == 0 && halo_m16()) {
+        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_FWD, false, true>), grid, dim3(kThreads), 0, s, p);
+        else if (p.bn_x) hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_DGRAD, true, true>), grid, dim3(kThreads), 0, s, p);
+        else hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_DGRAD, false, true>), grid, dim3(kThreads), 0, s, p);
+      } else if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_FWD>), grid, dim3(kThreads), 0, s, p);
       else if (p.bn_x) hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_DGRAD, true>), grid, dim3(kThreads), 0, s, p);
       else hipLaunchKernelGGL((igemm_glds_kernel<uint16_t, MODE_DGRAD>), grid, dim3(kThreads), 0, s, p);
     }

@@ -125,6 +125,17 @@ def test_conv_macro_tile_fwd_bwd(case, halo, monkeypatch):
   _run_conv_case(case, torch.bfloat16)
 
 
+@pytest.mark.parametrize('big', ['0', '1'])
+@pytest.mark.parametrize('case', BIG_TILE_CASES)
+def test_conv_lds_dma_kernels_mfma_32x32x16(case, big, monkeypatch):
+  """SE3DS_HALO_M16=0: the 256-pixel macro tile (big=1) and the 128 x 128 tile (big=0) with the
+  32x32x16 MFMA shape (the default since round 4 is 16x16x32, which every other test runs)."""
+  monkeypatch.setenv('SE3DS_BIG_TILE', big)
+  monkeypatch.setenv('SE3DS_HALO_TILE', '0')
+  monkeypatch.setenv('SE3DS_HALO_M16', '0')
+  _run_conv_case(case, torch.bfloat16)
+
+
 @pytest.mark.parametrize('stages', ['0', '3', '4'])
 @pytest.mark.parametrize('case', [c for c in BIG_TILE_CASES if c[2] == 128 and c[3] == 3 and c[4] == 1])
 def test_conv_halo_128_channel_variants(case, stages, monkeypatch):
