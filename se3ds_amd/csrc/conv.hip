@@ -1728,28 +1728,42 @@ igemm_halo_kernel(const IgemmParams p) {
   // first slab and weight tiles.
   float* stats_row = ((MODE == MODE_FWD || BNB) && p.stats)
                          ? p.stats + ((int64_t)(cur.tile * 4 + wn) * 2) * p.oC : nullptr;
-  item += gridDim.x;
-  const bool have = item < nitems;
-  if (have) {
-    setup_item(item, cur, xptr, xmk, wbase);
-    issue_prologue();
-  }
+  // The next item's pointers and prologue DMA are set up BEFORE the stores (they drain under the
+  // next K loop) -- except in the 16x16x32 variant of the 256-channel tile, where the pointer set
+  // on top of 128 live accumulators and the epilogue's temporaries spilled ~45 registers per item
+  // (20 MB of scratch writes per launch of the dominant layer, whose workgroups have ONE item).
+  constexpr bool LATE = M16 && CO == 256;
+  bool have = false;
+  auto next_item = [&]() {
+    item += gridDim.x;
+    have = item < nitems;
+    if (have) {
+      setup_item(item, cur, xptr, xmk, wbase);
+      issue_prologue();
+    }
+  };
+  if (!LATE) next_item();
   // (an epilogue scratch of its own that is not an LDS-DMA target, with the bias staged in LDS
   // so that the epilogue issues no global load, was measured slower: 1.62 vs 1.44 ms on the
   // 3x3 128->128 @512x1024 layer)
   unsigned char* scratch = xb1 + wave * kEpiScratch<2>;
   if constexpr (M16) {
+    // (the lane index is laundered: everything the epilogue derives from it -- scratch addresses,
+    // pixel offsets, bias pointers -- is otherwise hoisted above the K loop as loop-invariant and
+    // spilled there: 45 registers, 20 MB of scratch traffic per launch of the dominant layer)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
     int64_t opix16[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int y = opy0 + wn * 2 + (j >> 1), x = opx0 + (j & 1) * 16 + r16;
+      const int y = opy0 + wn * 2 + (j >> 1), x = opx0 + (j & 1) * 16 + (lane_e & 15);
       opix16[j] = (y < p.oH && x < p.oW) ? ((int64_t)opimg * p.oH + y) * p.oW + x : -1;
     }
-    store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[0]), opix16, co_base, lane,
+    store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[0]), opix16, co_base, lane_e,
                           scratch, stats_row);
     if (CO == 256)
       store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[CB16 - 4]), opix16,
-                            co_base + 64, lane, scratch, stats_row);
+                            co_base + 64, lane_e, scratch, stats_row);
   } else {
   store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane,
                          scratch, stats_row);
@@ -1757,6 +1771,7 @@ igemm_halo_kernel(const IgemmParams p) {
     store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[NI - 2]), opix, co_base + 64,
                            lane, scratch, stats_row);
   }
+  if (LATE) next_item();
   if (!have) break;
   }
 }
@@ -2817,7 +2832,10 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
   for (int j = 0; j < 2; ++j) {
     const int r = (wave * 2 + j) * 4 + (lane >> 4);
     ya[j] = r >> 5; yb[j] = r & 31;
-    const int ch = (lane & 15) ^ ((r & 3) << 2);
+    // (M16: chunk bit 1 ^= bit 3 of the row -- the four 16-lane groups of a transposing read then
+    // address pixel octets 8 rows apart, which would otherwise share their banks: 2 x the LDS
+    // cycles, tools/probes/lds_conflict.hip patterns 7 / 8)
+    const int ch = (lane & 15) ^ ((r & 3) << 2) ^ (M16 ? ((r >> 3) & 1) << 1 : 0);
     yoff[j] = ((int64_t)ya[j] * p.Wo + yb[j]) * p.Cout + co0 + ch * 8;
     yzero[j] = zero + ch * 8;
   }
@@ -2829,7 +2847,7 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
     const int r = (wave + 8 * j) * 8 + (lane >> 3);
     xa[j] = r / PC; xb[j] = r - xa[j] * PC;
     if (r >= XR) xa[j] = 1 << 20;   // rows past the halo: always out of bounds
-    const int ch = (lane & 7) ^ ((r & 2) << 1);
+    const int ch = (lane & 7) ^ ((r & 2) << 1) ^ (M16 ? ((r >> 3) & 1) << 1 : 0);
     xoff[j] = ((int64_t)(r >= XR ? 0 : xa[j]) * p.W + xb[j]) * p.Cin + ci0 + ch * 8;
     xzero[j] = zero + ch * 8;
   }
@@ -2932,7 +2950,7 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
     const int g4 = lane >> 4;                                    // pixel octet of the 32-pixel row
     const int ycol6 = cw * 32 + qcol * 4;                        // (+ 16 per output block)
     const int yo6 = (((ycol6 >> 3) ^ ((jrow & 3) << 2)) << 4) + ((ycol6 & 4) << 1);
-    const int ylane6 = (g4 * 8 + jrow) * YROW + yo6;
+    const int ylane6 = ((g4 * 8 + jrow) * YROW + yo6) ^ ((g4 & 1) << 5);   // (row bit 3 = g4 & 1)
     const int xcol6 = iw * 32 + qcol * 4;                        // (+ 16 per input block)
     int xlane6[2];
 #pragma unroll
@@ -2940,6 +2958,10 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
       const int swz = pp ^ ((jrow >> 1) & 1);
       xlane6[pp] = (YT + (g4 * 8 + jrow) * XROW + ((xcol6 >> 3) << 4) + ((xcol6 & 4) << 1)) ^ (swz << 6);
     }
+    // halo row r = 34 m + 8 g4 + (2 m + 4 w + jrow): bit 3 = (g4 & 1) ^ bit 3 of t = 2 m + 4 w + jrow,
+    // which is 0 for 2 m + 4 w < 6, 1 for 8 .. 12, (jrow >= 2) for 6 and (jrow < 2) for 14
+    const int j6 = (jrow >> 1) & 1;
+    const int xs[4] = {(g4 & 1) << 5, ((g4 & 1) ^ 1) << 5, ((g4 & 1) ^ j6) << 5, ((g4 & 1) ^ j6 ^ 1) << 5};
     // dy fragments of row a: two 16-channel blocks (block 1 = chunk index + 2: bit 5, untouched by
     // the row swizzle of bits 6-7)
     auto read_y = [&](const unsigned char* cur, int a, uint4 (&yf)[2]) {
@@ -2956,11 +2978,14 @@ wgrad_taps3_kernel(const WgradTapsParams p) {
     auto read_x = [&](const unsigned char* cur, int a, int b, uint2 (&xr)[3][3]) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
-        const unsigned char* xp = cur + (xlane6[(a + ky) & 1] ^ (b << 5)) + (a + ky) * PC * XROW;
 #pragma unroll
-        for (int w = 0; w < 3; ++w)
+        for (int w = 0; w < 3; ++w) {
+          const int K = 2 * (a + ky) + 4 * w;
+          const int sel = K < 6 ? 0 : (K == 6 ? 2 : (K == 14 ? 3 : 1));
+          const unsigned char* xp = cur + (xlane6[(a + ky) & 1] ^ (b << 5) ^ xs[sel]) + (a + ky) * PC * XROW;
           xr[ky][w] = __builtin_bit_cast(
               uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(xp + w * 4 * XROW)));
+        }
       }
     };
     auto mfma18 = [&](auto b_c, const uint4 (&yf)[2], const uint2 (&xr)[3][3]) {
