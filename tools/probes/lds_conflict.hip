@@ -45,6 +45,11 @@ __device__ __forceinline__ int pattern(int v, int lane) {
     case 12: return r16 * 144 + g * 32;                                      // 16x16x32, blocks i = g (other loop order)
     // ---- ds_read_b128 of the epilogue's write-back (8 lanes per pixel row)
     case 13: return (lane >> 3) * 144 + (lane & 7) * 16;
+    // ---- fragment reads that start at an arbitrary patch row (tap offsets)
+    case 14: { const int r = r16 + 1;  return r * 128 + ((g ^ ((r >> 1) & 7)) << 4); }
+    case 15: { const int r = r16 + 35; return r * 128 + ((g ^ ((r >> 1) & 7)) << 4); }
+    case 16: { const int r = l32 + 1;  return r * 128 + ((half ^ ((r >> 1) & 7)) << 4); }
+    case 17: { const int r = r16 + 35; return r * 128 + (((4 + g) ^ ((r >> 1) & 7)) << 4); }   // k32 step 1
     default: return lane * 16;
   }
 }
@@ -62,7 +67,7 @@ __global__ void __launch_bounds__(64) probe(int iters, uint32_t* out) {
       asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::
                    "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)ptr),
                    "v"(make_uint2(acc, it)) : "memory");
-    } else if (V <= 5 || V == 13) {
+    } else if (V <= 5 || V >= 13) {
       uint4 v;
       asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v)
                    : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)ptr) : "memory");
@@ -87,6 +92,7 @@ int main() {
     run<0>(out); run<1>(out); run<2>(out); run<3>(out); run<4>(out); run<5>(out);
     run<6>(out); run<7>(out); run<8>(out); run<9>(out);
     run<10>(out); run<11>(out); run<12>(out); run<13>(out);
+    run<14>(out); run<15>(out); run<16>(out); run<17>(out);
   }
   hipDeviceSynchronize();
   printf("done\n");
