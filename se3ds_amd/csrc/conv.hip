@@ -1476,7 +1476,10 @@ igemm_halo_kernel(const IgemmParams p) {
 #pragma unroll
     for (int sl = 0; sl < XS; ++sl) {
       const int r = (sl * 8 + wave) * 8 + lrow;
-      const int ch = (lane & 7) ^ ((r >> 1) & 7);
+      // M16: the patch rows are swizzled with r & 7 -- a 16-row x 4-chunk fragment that starts at
+      // an arbitrary patch row (tap offsets) is conflict-free only under that one of eight
+      // candidates (tools/probes/lds_swz.hip); (r >> 1) & 7 conflicts for 12 of 16 start rows
+      const int ch = (lane & 7) ^ (M16 ? (r & 7) : ((r >> 1) & 7));
       const int pr = r / PC, pc = r - pr * PC;
       const int sy = oy0 + pr;
       int sx = ox0 + pc;
@@ -1605,7 +1608,7 @@ igemm_halo_kernel(const IgemmParams p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = rb16 + ((j >> 1) * PC + (j & 1) * 16 + toff);
-        xo16[j] = (r << 7) | ((g16 ^ ((r >> 1) & 7)) << 4);
+        xo16[j] = (r << 7) | ((g16 ^ (r & 7)) << 4);
       }
     }
 #pragma unroll
