@@ -402,7 +402,11 @@ __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (
                                                  const int64_t (&opix)[4], int co_base, int lane,
                                                  unsigned char* scratch, float* stats_row = nullptr) {
   constexpr int NI = 2, PXC = 32;
-  constexpr int RB = NI * 64 + 16;   // padded row bytes
+  // Rows of exactly 128 bytes, 16-byte chunk index ^= pixel & 7 (no padding): the padded 144-byte
+  // rows of store_wave_lds_impl run both the parking writes and the write-back reads at twice their
+  // conflict-free cycle count (tools/probes/lds_epi.hip: 33 conflict cycles per 67 active for either
+  // layout; 128-byte rows: write-back 0 / 34); the statistics reads are a permutation of one row.
+  constexpr int RB = NI * 64;
   constexpr int LPP = NI * 4;        // lanes per pixel in the write-back
   constexpr int PPI = 64 / LPP;      // pixels per store instruction
   const float scale = p.scale ? *p.scale : 1.0f;
@@ -458,7 +462,8 @@ __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (
           pk.x = pack2_bf16(v[0], v[1]);
           pk.y = pack2_bf16(v[2], v[3]);
           if (o < 0) pk = make_uint2(0u, 0u);   // (keeps the column sums clean)
-          *reinterpret_cast<uint2*>(scratch + lp * RB + (i * 16 + g * 4) * 2) = pk;
+          // channels i*16 + g*4 .. +3: chunk 2 i + g / 2, half (g & 1)
+          *reinterpret_cast<uint2*>(scratch + lp * RB + (((2 * i + (g >> 1)) ^ (lp & 7)) << 4) + (g & 1) * 8) = pk;
         }
       };
       if (form == 0) emit(std::integral_constant<int, 0>());
@@ -471,7 +476,8 @@ __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (
       // batch-norm statistics of the stored (rounded) outputs: lane = channel
 #pragma unroll 8
       for (int px = 0; px < PXC; ++px) {
-        const float v = bf16_to_f32(*reinterpret_cast<const uint16_t*>(scratch + px * RB + lane * 2));
+        const float v = bf16_to_f32(*reinterpret_cast<const uint16_t*>(
+            scratch + px * RB + (((lane >> 3) ^ (px & 7)) << 4) + (lane & 7) * 2));
         cs1 += v;
         cs2 += v * v;
       }
@@ -479,7 +485,7 @@ __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (
 #pragma unroll
     for (int k = 0; k < PXC / PPI; ++k) {
       const int px = k * PPI + lane / LPP, c8 = lane % LPP;
-      uint4 v = *reinterpret_cast<const uint4*>(scratch + px * RB + c8 * 16);
+      uint4 v = *reinterpret_cast<const uint4*>(scratch + px * RB + ((c8 ^ (px & 7)) << 4));
       const int64_t po = offs[px];
       if (po >= 0) {
         if (p.addend) {
