@@ -58,7 +58,7 @@ print('us/render %.1f frac %.4f step_ms %.4f' % (1e3*r['ms_per_launch'], r['frac
 task_prof_step() {
   local tag=$1; shift
   rm -rf gpurun_out/prof_tmp
-  local note="$* rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped   (3 warm-up + 10 timed + 1 instrumented train_g_d step = 14 steps; model build kernels included)"
+  local note="$* rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped   (3 warm-up + 10 timed + 2 instrumented train_g_d steps = 15 steps; model build kernels included)"
   ( for v in "$@"; do export "$v"; done
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o gan -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped > gpurun_out/prof_$tag.log 2>&1 )
   python tools/rocpd_summary.py gpurun_out/prof_tmp/gan_results.db gpurun_out/${tag}_kernel_stats.csv "$note"
