@@ -139,7 +139,7 @@ def _warp_inputs(rng, h, w, views, dev, depth_kind='random'):
 
 
 def bench_warp(args, rank, world, dev):
-  from se3ds_amd.utils import pano_utils
+  from se3ds_amd.utils import pano_utils, point_cloud_utils
   h, w, views = args.warp_height, 2 * args.warp_height, 2
   rng = np.random.default_rng(1234 + rank)
   panos, target = _warp_inputs(rng, h, w, views, dev, args.warp_depth)
@@ -149,17 +149,20 @@ def bench_warp(args, rank, world, dev):
   P = h * w
 
   M = views * P
-  mem_x = torch.empty((1, 4, M), dtype=torch.float32, device=dev)   # the point-cloud memory
-  mem_f = torch.empty((1, M, 3), dtype=torch.int32, device=dev)
+  # the point-cloud memory of the trajectory loops (eval_metric.py:144-239), preallocated
+  mem = point_cloud_utils.PointCloudMemory(1, 3, torch.int32, dev, capacity=M)
 
   def step():
-    # every view is unprojected straight into its window of the memory (the concat of
-    # eval_metric.py:238-239 / models.py:239-245 without a copy), then one target is rendered
-    for v, (rgb, depth, pos) in enumerate(g):
-      pano_utils.equirectangular_to_pointcloud(rgb, depth, -1, 20.0, position=pos,
-                                               out=(mem_x, mem_f, v * P))
-    return pano_utils.project_feats_to_equirectangular(mem_f, mem_x, h, w, -1, 20.0, offset=tgt,
-                                                       with_mask=True), (mem_x, mem_f)
+    # ONE library call per trajectory step (se3ds_warp_views_to_target, round 5): every view is
+    # unprojected straight into its window of the memory (the concat of eval_metric.py:238-239 /
+    # models.py:239-245 without a copy), then one target is rendered.  SE3DS_WARP_SEPARATE=1: the
+    # four separate calls of round 4 (A/B).
+    mem.clear()
+    if os.environ.get('SE3DS_WARP_SEPARATE') == '1':
+      for rgb, depth, pos in g:
+        mem.append_equirect(rgb, depth, -1, 20.0, position=pos)
+      return mem.project(h, w, -1, 20.0, position=tgt, with_mask=True)
+    return mem.append_views_and_project(g, -1, 20.0, tgt, h, w, with_mask=True)
 
   for _ in range(args.warmup):
     step()
@@ -171,19 +174,27 @@ def bench_warp(args, rank, world, dev):
   dt = _max_over_ranks(time.perf_counter() - t0, world, dev)
 
   # dominant kernel chain = project+splat on a resident memory: HIP events on the launch stream
-  _, (mem_x, mem_f) = step()
-  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  step()
+  def timed(fn, reps):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(reps):
+      fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps
   reps = max(10, args.steps)
-  torch.cuda.synchronize()
-  ev0.record()
-  for _ in range(reps):
-    pano_utils.project_feats_to_equirectangular(mem_f, mem_x, h, w, -1, 20.0, offset=tgt,
-                                                with_mask=True)
-  ev1.record()
-  torch.cuda.synchronize()
-  proj_ms = ev0.elapsed_time(ev1) / reps
+  proj_ms = timed(lambda: mem.project(h, w, -1, 20.0, position=tgt, with_mask=True), reps)
   algo_bytes = 28 * M + 20 * P  # 28 B/point in, 16 B/px out + 4 B/px mask
   achieved = algo_bytes / (proj_ms * 1e-3) / 1e9
+  # the other kernel of the step: one view's unproject (44 B per pixel: 4 depth + 12 features in,
+  # 16 coordinates + 12 features out), into its window of the memory
+  rgb0, depth0, pos0 = g[0]
+  unp_ms = timed(lambda: pano_utils.equirectangular_to_pointcloud(
+      rgb0, depth0, -1, 20.0, position=pos0, out=(mem._x, mem._f, 0)), reps)
+  unp_bytes = 44 * P
+  kernels_ms = views * unp_ms + proj_ms
 
   traffic, traffic_detail = (None, None)
   if (h, views, args.warp_depth) == (1024, 2, 'random'):
@@ -201,11 +212,31 @@ def bench_warp(args, rank, world, dev):
                    'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                    'traffic_detail': traffic_detail,
-                   'ms_per_launch': proj_ms, 'algorithmic_bytes': algo_bytes},
+                   'ms_per_launch': proj_ms, 'algorithmic_bytes': algo_bytes,
+                   # VALU side of the two splat kernels (tracked PMC pass, profiles/r05_warp_valu_pmc.json)
+                   'valu_frac': _warp_valu_frac() if (h, views) == (1024, 2) else None,
+                   'unproject': {'kernel': 'unproject_equirect_vec4_kernel (one view)',
+                                 'ms_per_launch': unp_ms, 'algorithmic_bytes': unp_bytes,
+                                 'achieved': unp_bytes / (unp_ms * 1e-3) / 1e9, 'unit': 'GB/s',
+                                 'frac': unp_bytes / (unp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                   # host + launch overhead of the step: wall per step over the sum of its kernels
+                   # timed alone (views x unproject + project/splat)
+                   'step_over_kernels': (1e3 * dt / args.steps) / kernels_ms},
   }
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline_warp(panos, target, h, w)
   return out
+
+
+def _warp_valu_frac():
+  """VALU-busy fraction of the splat kernels from the tracked counter pass, or None."""
+  path = os.path.join(ROOT, 'profiles', 'r05_warp_valu_pmc.json')
+  try:
+    with open(path) as f:
+      d = json.load(f)
+    return {k: v.get('valu_busy_frac') for k, v in d.get('kernels', {}).items()}
+  except (OSError, ValueError):
+    return None
 
 
 def cpu_baseline_warp(panos, target, h, w):
@@ -278,6 +309,15 @@ def main():
     wargs.steps, wargs.warmup, wargs.no_cpu_baseline = 50, 5, True
     w = bench_warp(wargs, rank, world, dev)
     out['warp'] = {k: w[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'config', 'roofline')}
+    # ... and at north_star's stated size, 512 x 1024 (2 views -> 1 target)
+    wargs.warp_height = 512
+    w5 = bench_warp(wargs, rank, world, dev)
+    r5 = w5['roofline']
+    out['warp']['at_512'] = {
+        'config': w5['config'], 'value': w5['value'], 'ms_per_step': w5['ms_per_step'],
+        'ms_per_launch': r5['ms_per_launch'], 'achieved': r5['achieved'], 'frac': r5['frac'],
+        'unit': 'GB/s', 'algorithmic_bytes': r5['algorithmic_bytes'], 'unproject': r5['unproject'],
+        'step_over_kernels': r5['step_over_kernels']}
   out['backend'] = (dist.get_backend() if world > 1 else None)
   out['world_size'] = (dist.get_world_size() if world > 1 else 1)
   if rank == 0:

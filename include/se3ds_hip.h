@@ -98,8 +98,9 @@ int se3ds_project_equirect(const float* xyz1, const float* offset, const void* f
  * device uint32 (written, not accumulated). */
 int se3ds_feats_byte_range(const void* feats, int feat_dtype, int64_t count, float void_class,
                            uint32_t* bad_out, void* stream);
-/* After a packed splat call (same workspace, same n / m): *broken_out (device uint32) = 1 if a
- * valid point violated the SE3DS_FEAT_BYTE_RANGE promise, else 0. */
+/* After a packed / sorted splat call (same workspace, same n / m): *broken_out (device uint32) = 1
+ * if a valid point of THAT call violated the SE3DS_FEAT_BYTE_RANGE promise, else 0 (the verdict is
+ * an epoch the violating workgroups exchange into the workspace: nothing is zeroed per call). */
 int se3ds_splat_promise_broken(const void* workspace, int n, int64_t m, uint32_t* broken_out,
                                void* stream);
 /* The same verdict, STICKY over calls: header word 3 of a splat workspace (byte 12) is OR-ed with 1
@@ -119,6 +120,27 @@ int se3ds_project_equirect_memory(const float* xyz1, const float* offset, const 
                                   float output_void, float* depth, float* feat, float* mask,
                                   float mask_void, void* workspace, size_t workspace_bytes,
                                   void* stream);
+
+/* One trajectory step as ONE host call: `views` source panoramas are unprojected into consecutive
+ * windows [m_offset + v*H*W, ...) of a point-cloud memory (se3ds_unproject_equirect_into each, with
+ * view_position[v] (N,3) added, or view_position == NULL) and ONE target is rendered from the
+ * memory's first m_offset + views*H*W points, relative to `target` (N,3)
+ * (se3ds_project_equirect_memory) -- utils/eval_metric.py:153-166,233-240 and the RE10K notebook's
+ * cell 15 per step, trainers/gan_manager.py:476-485,540-541.  view_feats / view_depth /
+ * view_position are HOST arrays of `views` device pointers.  The launches are queued back to
+ * back: from Python the four separate calls of a 2-view step cost 154 us of host time for 124 us
+ * of kernels.  feat_dtype may carry SE3DS_FEAT_BYTE_RANGE (a promise about every view's features
+ * AND what the memory already holds).  views == 0 renders the memory as it is. */
+int se3ds_warp_views_to_target(const void* const* view_feats, int feat_dtype,
+                               const float* const* view_depth, const float* const* view_position,
+                               int views, int n, int height, int width, int channels,
+                               float void_class, float depth_scale, const float* sin_el,
+                               const float* cos_el, const float* sin_hd, const float* cos_hd,
+                               float* mem_xyz1, void* mem_feats, int64_t capacity, int64_t m_offset,
+                               const float* target, int out_height, int out_width,
+                               float output_void, float* depth, float* feat, float* mask,
+                               float mask_void, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* project_to_feat -- reference utils/point_cloud_utils.py:90-183 on already transformed
  * coordinates (N,4,M) = (x, y, z, 1).  Same outputs/semantics as above. */
@@ -427,6 +449,26 @@ int se3ds_norm_bwd_apply_rows(const void* dy, const void* x, int dtype, int64_t 
                               void* dres, const void* act_mask, const float* sum_row,
                               const float* out_row, float* colsum_dst, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* Batch-norm backward (one group, bf16) in TWO launches instead of three (round 5): statistics
+ * partials + apply in the channel-group layout (64 channels = one 128-byte line per row and
+ * workgroup); every apply workgroup folds the <= 64 partial rows of its own channels in a prologue,
+ * the stand-alone column reduction between se3ds_norm_bwd_stats and se3ds_norm_bwd_apply is gone
+ * (layers.py:235-251: the backward of every BatchNormalization of the generator).  dbeta_out /
+ * dgamma_out (c floats, or NULL) receive sum dz / sum dz * xhat, sums_out ([2][c] or NULL) both.
+ * With sum_row / out_row (the rows variant, se3ds_norm_bwd_apply_rows): dx is stored pre-scaled and
+ * colpart[se3ds_norm_bwd_cg_col_rows(r, c)][c] receives the bias-gradient partials as compact slabs
+ * -- reduce them with se3ds_wgrad_reduce_multi (row: colpart, rows, c / 4, destination).
+ * workspace: se3ds_norm_bwd_cg_workspace_bytes(c).  SE3DS_E_UNSUPPORTED where
+ * se3ds_norm_bwd_cg_supported() is 0 (c % 64, c < 512, other dtypes; SE3DS_NORM_CG=0). */
+int se3ds_norm_bwd_cg_supported(int dtype, int64_t r, int c, int act, int has_mask, int in_act);
+size_t se3ds_norm_bwd_cg_workspace_bytes(int c);
+int se3ds_norm_bwd_cg_col_rows(int64_t r, int c);
+int se3ds_norm_bwd_cg(const void* dy, const void* x, int dtype, int64_t r, int c, const float* mean,
+                      const float* rstd, const float* gamma, float count, int act, float alpha,
+                      void* dx, void* dres, const void* act_mask, int in_act, float in_alpha,
+                      float* dbeta_out, float* dgamma_out, float* sums_out, const float* sum_row,
+                      const float* out_row, float* colpart, void* workspace, size_t workspace_bytes,
+                      void* stream);
 /* inference-mode backward: dx = dpre*scale; dres = dpre. */
 int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r, int c,
                      const float* scale, int act, float alpha, void* dx, void* dres,

@@ -27,6 +27,9 @@ _SIGS = {
                                        c_f, c_f, c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
     'se3ds_project_equirect_memory': (c_int, [c_p, c_p, c_p, c_int, c_int, c_i64, c_i64, c_int, c_int,
                                               c_int, c_f, c_f, c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
+    'se3ds_warp_views_to_target': (c_int, [c_p, c_int, c_p, c_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p,
+                                           c_int, c_int, c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
     'se3ds_project_to_feat': (c_int, [c_p, c_p, c_int, c_int, c_i64, c_int, c_int, c_int, c_f, c_f,
                                       c_f, c_p, c_p, c_p, c_f, c_p, c_sz, c_p]),
     'se3ds_splat_debug_indices': (c_int, [c_p, c_int, c_i64, c_p, c_p, c_p]),

@@ -92,8 +92,11 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
     nn.set_conv_profiler(None)
   summ = prof.summary()
   if os.environ.get('SE3DS_BENCH_SHAPES'):
+    # per-shape table of the instrumented step (SE3DS_BENCH_SHAPES=all: every shape, else the top 40)
     rows = sorted(prof.by_shape().items(), key=lambda kv: -kv[1][0])
-    for (kind, tag), (ms_, fl, cnt) in rows[:40]:
+    if os.environ['SE3DS_BENCH_SHAPES'] != 'all':
+      rows = rows[:40]
+    for (kind, tag), (ms_, fl, cnt) in rows:
       print(f'SHAPE {ms_:8.2f} ms {fl / max(ms_, 1e-9) / 1e9:7.0f} TF/s x{cnt:3d} {kind:6s} {tag}')
   peak = BF16_PEAK_TFLOPS if args.dtype == 'bf16' else F32_PEAK_TFLOPS
   achieved = summ['flops'] / (summ['ms'] * 1e-3) / 1e12 if summ['ms'] > 0 else 0.0

@@ -7,6 +7,7 @@
 // Reference semantics: utils/pano_utils.py, utils/point_cloud_utils.py (see the per-entry
 // citations in include/se3ds_hip.h).  Index math lives in include/se3ds_geom_math.h and is
 // shared bit-for-bit with the CPU oracle.  Built with -ffp-contract=off.
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
@@ -81,6 +82,81 @@ unproject_equirect_kernel(const T* __restrict__ feats, const float* __restrict__
   }
 }
 
+// Four pixels per thread (round 5): 4-byte features, C = 1 or 3, width % 4 == 0, 16-byte aligned
+// bases and windows.  The scalar kernel above moves 44 B per pixel through eleven dword accesses
+// (three of them stride-12 loads, three stride-12 stores) and a 64-bit division: 25 us for the
+// 92 MB of a 1024 x 2048 view = 3.7 TB/s.  Here a thread owns four consecutive pixels of one row:
+// depth, the heading tables and the four coordinate planes are one 16-byte access each, the C = 3
+// features three 16-byte loads and stores; row / column come from one 32-bit division per thread.
+// Same arithmetic per pixel, in the same order (-ffp-contract=off): bit-identical outputs.
+template <typename T, int C>
+__global__ void __launch_bounds__(kBlock)
+unproject_equirect_vec4_kernel(const T* __restrict__ feats, const float* __restrict__ depth,
+                               const float* __restrict__ sin_el, const float* __restrict__ cos_el,
+                               const float* __restrict__ sin_hd, const float* __restrict__ cos_hd,
+                               const float* __restrict__ position, int height, int width,
+                               float void_class, float depth_scale, float* __restrict__ xyz1,
+                               T* __restrict__ feats_out, int64_t m_total, int64_t m_offset) {
+  static_assert(sizeof(T) == 4 && (C == 1 || C == 3), "4-byte features, 1 or 3 channels");
+  const int b = blockIdx.y;
+  const uint32_t qw = (uint32_t)width >> 2;          // quads per row
+  const uint32_t nq = (uint32_t)height * qw;         // quads per image (< 2^29: checked by the launcher)
+  const int64_t p = (int64_t)height * width;
+  float pos_x = 0.f, pos_y = 0.f, pos_z = 0.f;
+  if (position) {
+    pos_x = position[b * 3 + 0];
+    pos_y = position[b * 3 + 1];
+    pos_z = position[b * 3 + 2];
+  }
+  const T vc = FeatIO<T>::cast_void(void_class);
+  float* X = xyz1 + (int64_t)b * 4 * m_total + m_offset;
+  for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < nq; q += gridDim.x * kBlock) {
+    const uint32_t r = q / qw;
+    const uint32_t col = (q - r * qw) << 2;
+    const int64_t i = (int64_t)q << 2;
+    const float4 d4 = *reinterpret_cast<const float4*>(depth + (int64_t)b * p + i);
+    const float4 ch4 = *reinterpret_cast<const float4*>(cos_hd + col);
+    const float4 sh4 = *reinterpret_cast<const float4*>(sin_hd + col);
+    const float se = sin_el[r], ce = cos_el[r];
+    T f[4 * C];
+    const T* fi = feats + ((int64_t)b * p + i) * C;
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+      *reinterpret_cast<uint4*>(&f[4 * k]) = *reinterpret_cast<const uint4*>(fi + 4 * k);
+    const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float cc[4] = {ch4.x, ch4.y, ch4.z, ch4.w};
+    const float ss[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+    float xo[4], yo[4], zo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = dd[e];
+      const bool valid = (d > 0.0f) && (d < 1.0f);
+      const float mask = valid ? 1.0f : 0.0f;
+      const float rad = (d * depth_scale) * mask;
+      const float rs = rad * se;
+      float x = rs * cc[e];
+      float y = rs * ss[e];
+      float z = rad * ce;
+      if (position) {
+        x = x + pos_x;
+        y = y + pos_y;
+        z = z + pos_z;
+      }
+      xo[e] = x; yo[e] = y; zo[e] = z;
+#pragma unroll
+      for (int k = 0; k < C; ++k) f[e * C + k] = valid ? f[e * C + k] : vc;
+    }
+    *reinterpret_cast<float4*>(X + i) = make_float4(xo[0], xo[1], xo[2], xo[3]);
+    *reinterpret_cast<float4*>(X + m_total + i) = make_float4(yo[0], yo[1], yo[2], yo[3]);
+    *reinterpret_cast<float4*>(X + 2 * m_total + i) = make_float4(zo[0], zo[1], zo[2], zo[3]);
+    *reinterpret_cast<float4*>(X + 3 * m_total + i) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    T* fo = feats_out + ((int64_t)b * m_total + m_offset + i) * C;
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+      *reinterpret_cast<uint4*>(fo + 4 * k) = *reinterpret_cast<const uint4*>(&f[4 * k]);
+  }
+}
+
 // ------------------------------------------------------------------ unproject (perspective)
 __global__ void __launch_bounds__(kBlock)
 unproject_perspective_kernel(const int32_t* __restrict__ feats, const float* __restrict__ depth,
@@ -129,6 +205,18 @@ constexpr int kMaxSinkBlocks = 2048;
 // SE3DS_FEAT_BYTE_RANGE promise and nothing in the library ever clears it -- the owner of the
 // workspace zeroes the header once and reads it whenever convenient (se3ds_splat_promise_sticky).
 constexpr int kPromiseStickyWord = 3;
+// The PER-CALL verdict (se3ds_splat_promise_broken) lives in the control words of the packed /
+// sorted workspaces: a violating workgroup EXCHANGES this call's epoch into ctl[1], the first
+// workgroup stores the epoch into ctl[kPromiseEpochWord], and the reader compares the two.  Round 4
+// zeroed ctl[1] from block (0, 0) of the same launch whose other blocks OR into it: a block that
+// finished before block (0, 0) started lost its bit.  Nothing is zeroed now.
+constexpr int kPromiseEpochWord = 6;
+inline uint32_t next_splat_epoch() {
+  static std::atomic<uint32_t> epoch{0};
+  uint32_t e = ++epoch;
+  if (e == 0u) e = ++epoch;
+  return e;
+}
 struct SplatWs {
   uint32_t* sink_z;
   uint32_t* sink_feat;
@@ -1448,6 +1536,7 @@ struct PackWs {
   uint64_t* rec_pt;       // [n][mp]  records in point order
   uint64_t* rec;          // [n * m]  records in tile order
   int64_t mp;             // padded points per image (chunks * per)
+  uint32_t epoch;         // this call's promise epoch (kPromiseEpochWord)
 };
 __host__ __device__ inline ChunkGeom pack_geom(int64_t m, int n) {
   int64_t cap = kMaxSinkBlocks / (n > 0 ? n : 1);
@@ -1559,7 +1648,7 @@ splat_pack_count_kernel(const float* __restrict__ coords, const float* __restric
   for (int t = threadIdx.x; t < ntiles; t += kPThreads) s_hist[t] = 0u;
   if (threadIdx.x == 0) s_qn = 0u;
   if (blockIdx.x == 0 && b == 0) {   // state of the later passes (this kernel runs first)
-    if (threadIdx.x == 0) pw.ctl[1] = 0u;
+    if (threadIdx.x == 0) pw.ctl[kPromiseEpochWord] = pw.epoch;
     if ((int)threadIdx.x < kSinkSlots * C) pw.fpart2[threadIdx.x] = 0u;
   }
   __syncthreads();
@@ -1755,7 +1844,7 @@ splat_pack_count_kernel(const float* __restrict__ coords, const float* __restric
     if ((threadIdx.x & 63) == 0) s_red[1 + k][threadIdx.x >> 6] = v;
   }
   if ((threadIdx.x & 63) == 0 && bad != 0u) {
-    atomicOr(&pw.ctl[1], 1u);
+    atomicExch(&pw.ctl[1], pw.epoch);
     atomicOr(&ws.sink_z[kPromiseStickyWord], 1u);   // sticky: survives later calls (host-cleared)
   }
   __syncthreads();
@@ -2169,7 +2258,9 @@ feats_byte_range_kernel(const T* __restrict__ f, int64_t count, float void_class
   if ((threadIdx.x & 63) == 0 && bad != 0u) atomicAdd(bad_out, bad);
 }
 
-__global__ void splat_promise_kernel(PackWs pw, uint32_t* out) { out[0] = pw.ctl[1] != 0u ? 1u : 0u; }
+__global__ void splat_promise_kernel(PackWs pw, uint32_t* out) {
+  out[0] = pw.ctl[1] == pw.ctl[kPromiseEpochWord] ? 1u : 0u;
+}
 __global__ void splat_promise_sticky_kernel(uint32_t* hdr, uint32_t* out, int clear) {
   out[0] = hdr[kPromiseStickyWord] != 0u ? 1u : 0u;
   if (clear) hdr[kPromiseStickyWord] = 0u;
@@ -2183,6 +2274,7 @@ int launch_splat_packed(const float* coords, const float* offset, const T* feats
   SplatWs ws = carve_ws(workspace, n, m);
   const size_t base = splat_hdr_bytes() + (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)m;
   PackWs pw = carve_pack_ws((char*)workspace + align16(base), n, m, height, width);
+  pw.epoch = next_splat_epoch();
   const int tiles_x = ceil_div(width, kPTileX), tiles_y = ceil_div(height, kPTileY);
   const int ntiles = tiles_x * tiles_y, nb = n * ntiles;
   const ChunkGeom cg = pack_geom(m, n);
@@ -2274,7 +2366,20 @@ struct SortWs {
   uint8_t* hi;        // [n * chunks][chunk_pts]
   int chunks;         // per image
   int chunk_pts;
+  int cstride;        // row length of `runs`: 8 * ceil(chunks / 8), see run_slot()
+  uint32_t epoch;     // this call's promise epoch (kPromiseEpochWord)
 };
+// Column of chunk c in a supertile's row of the run table.  A chunk is one S1 workgroup and
+// workgroup b runs on XCD b % 8 (observed placement, MI355X_MICROARCH.md; used for speed only): with
+// the chunks of one XCD next to each other, the 4-byte descriptors that XCD's workgroups write into
+// one supertile row fill whole lines of THAT XCD's L2 before they are written back.  Round 4 stored
+// column c: every 128-byte line of the table was assembled from partial write-backs of all eight
+// L2s (S1 wrote 51 MB for 39 MB of payload).
+__host__ __device__ inline int run_slot(int c, int cstride) { return (c & 7) * (cstride >> 3) + (c >> 3); }
+__host__ __device__ inline int run_chunk(int slot, int cstride) {
+  const int per = cstride >> 3;
+  return (slot % per) * 8 + slot / per;
+}
 // Supertile = `rows` FULL-WIDTH image rows (rows x width <= 2048 pixels; images wider than 2048 are
 // cut into column strips).  The shape matters: the pole rows of every SOURCE view (thousands of
 // pixels looking the same way) land on a near-vertical line of the target, and 32 x 128 supertiles
@@ -2290,13 +2395,23 @@ inline int sort_env(const char* name, int dflt) {
 }
 inline SortGeom sort_geom(int64_t m, int height, int width, int pts_forced = 0) {
   static const int pts_env = sort_env("SE3DS_SPLAT_PTS", 16) == 8 ? 8 : 16;
+  // SE3DS_SPLAT_SUPERPX (A/B): pixels per supertile, 256 .. 2048 (default 2048 = one full row of
+  // a 1024 x 2048 target; smaller supertiles = more, lighter resolve workgroups)
+  static const int super_px = [] {
+    const int v = sort_env("SE3DS_SPLAT_SUPERPX", kSMaxPx);
+    return v >= 256 && v <= kSMaxPx ? v : kSMaxPx;
+  }();
   SortGeom g;
   g.pts = pts_forced ? pts_forced : pts_env;
   g.chunk_pts = kSThreads * g.pts;
   g.chunks = (int)ceil_div(m > 0 ? m : 1, (int64_t)g.chunk_pts);
-  g.super_w = width <= kSMaxPx ? width : kSMaxPx;
+  g.super_w = width <= super_px ? width : super_px;
+  if (width > g.super_w) {   // column strips of equal width (the last one may be ragged)
+    const int strips = ceil_div(width, g.super_w);
+    g.super_w = ceil_div(width, strips);
+  }
   g.rlog = 0;
-  while ((2 << g.rlog) * g.super_w <= kSMaxPx && (1 << g.rlog) < height) ++g.rlog;
+  while ((2 << g.rlog) * g.super_w <= super_px && (1 << g.rlog) < height) ++g.rlog;
   g.super_x = ceil_div(width, g.super_w);
   g.super_y = ceil_div(height, 1 << g.rlog);
   g.nsuper = g.super_x * g.super_y;
@@ -2308,7 +2423,7 @@ inline size_t sort_ws_bytes(int n, int64_t m, int height, int width) {
   for (int pts = 8; pts <= 16; pts += 8) {   // (independent of the A/B environment switch)
     const SortGeom g = sort_geom(m, height, width, pts);
     const size_t b = 64 + align16(4 * kSinkSlots * kPMaxChannels) +
-                     align16(4 * (size_t)n * g.nsuper * g.chunks) +
+                     align16(4 * (size_t)n * kSMaxSuper * (size_t)(8 * ceil_div(g.chunks, 8))) +
                      align16(8 * (size_t)n * g.chunks * g.chunk_pts) +
                      align16((size_t)n * g.chunks * g.chunk_pts);
     worst = b > worst ? b : worst;
@@ -2320,11 +2435,13 @@ inline SortWs carve_sort_ws(void* base, int n, const SortGeom& g) {
   SortWs w;
   w.ctl = (uint32_t*)p; p += 64;
   w.fpart2 = (uint32_t*)p; p += align16(4 * kSinkSlots * kPMaxChannels);
-  w.runs = (uint32_t*)p; p += align16(4 * (size_t)n * g.nsuper * g.chunks);
+  w.cstride = 8 * ceil_div(g.chunks, 8);
+  w.runs = (uint32_t*)p; p += align16(4 * (size_t)n * g.nsuper * w.cstride);
   w.rec = (uint64_t*)p; p += align16(8 * (size_t)n * g.chunks * g.chunk_pts);
   w.hi = (uint8_t*)p;
   w.chunks = g.chunks;
   w.chunk_pts = g.chunk_pts;
+  w.epoch = 0u;
   return w;
 }
 
@@ -2349,7 +2466,9 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
   for (int t = threadIdx.x; t < nsuper; t += kSThreads) s_cnt[t] = 0u;
   if (threadIdx.x == 0) s_qn = 0u;
   if (blockIdx.x == 0 && b == 0) {   // state of the resolve pass (this kernel runs first)
-    if (threadIdx.x < 16) sw.ctl[threadIdx.x] = 0u;
+    // (not ctl[1]: other workgroups of THIS launch exchange the epoch into it, see kPromiseEpochWord)
+    if (threadIdx.x < 16 && threadIdx.x != 1)
+      sw.ctl[threadIdx.x] = (int)threadIdx.x == kPromiseEpochWord ? sw.epoch : 0u;
     if ((int)threadIdx.x < kSinkSlots * C) sw.fpart2[threadIdx.x] = 0u;
   }
   __syncthreads();
@@ -2557,12 +2676,12 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
       sum += c[q];
     }
     uint32_t ex = block_excl_scan_u32<kSThreads / 64>(sum, s_w, &all);
-    uint32_t* R = sw.runs + ((int64_t)b * nsuper) * sw.chunks + blockIdx.x;
+    uint32_t* R = sw.runs + ((int64_t)b * nsuper) * sw.cstride + run_slot(blockIdx.x, sw.cstride);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (t0 + q < nsuper) {
         s_cnt[t0 + q] = ex;   // (in place: every count was read before the scan's barriers)
-        R[(int64_t)(t0 + q) * sw.chunks] = (ex << 16) | c[q];
+        R[(int64_t)(t0 + q) * sw.cstride] = (ex << 16) | c[q];
       }
       ex += c[q];
     }
@@ -2599,7 +2718,7 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
     if ((threadIdx.x & 63) == 0) s_red[1 + k][threadIdx.x >> 6] = v;
   }
   if ((threadIdx.x & 63) == 0 && bad != 0u) {
-    atomicOr(&sw.ctl[1], 1u);
+    atomicExch(&sw.ctl[1], sw.epoch);
     atomicOr(&ws.sink_z[kPromiseStickyWord], 1u);
   }
   __syncthreads();
@@ -2650,10 +2769,13 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
   // without a record here), with their exclusive record prefix; total records
   uint32_t total = 0, nnz = 0;
   {
-    const uint32_t* R = sw.runs + (int64_t)bs * chunks;
-    for (int c0 = 0; c0 < chunks; c0 += kRThreads) {
-      const int c = c0 + threadIdx.x;
-      const uint32_t d = c < chunks ? R[c] : 0u;
+    // (the row holds the chunks XCD by XCD, run_slot(): the order of the runs is irrelevant -- min /
+    // max do not depend on the record order -- only slot -> chunk must be undone for the addresses)
+    const uint32_t* R = sw.runs + (int64_t)bs * sw.cstride;
+    for (int c0 = 0; c0 < sw.cstride; c0 += kRThreads) {
+      const int slot = c0 + threadIdx.x;
+      const int c = slot < sw.cstride ? run_chunk(slot, sw.cstride) : chunks;
+      const uint32_t d = c < chunks ? R[slot] : 0u;
       const uint32_t cnt = d & 0xffffu;
       uint32_t all, alln;
       const uint32_t ex = block_excl_scan_u32<kRThreads / 64>(cnt, s_w, &all);
@@ -2984,6 +3106,7 @@ int launch_splat_sorted(const float* coords, const float* offset, const T* feats
   SplatWs ws = carve_ws(workspace, n, m);
   const size_t base = splat_hdr_bytes() + (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)m;
   SortWs sw = carve_sort_ws((char*)workspace + align16(base), n, g);
+  sw.epoch = next_splat_epoch();
 #define SE3DS_S(CC, PP)                                                                           \
   return launch_splat_sorted_c<T, EQUIRECT, CC, PP>(coords, offset, feats, n, m, ld, height, width, \
                                                     depth_scale, input_void, output_void, depth,  \
@@ -3597,6 +3720,27 @@ int se3ds_unproject_equirect_into(const void* feats, int feat_dtype, const float
   int64_t p = (int64_t)height * width;
   if (m_offset < 0 || m_offset + p > m_total) return SE3DS_E_BADSHAPE;
   dim3 grid((unsigned)grid_for(p, kBlock), (unsigned)n);
+  // four pixels per thread, 16-byte accesses (SE3DS_UNPROJECT_VEC=0: the scalar kernel, A/B and tests)
+  const char* e_vec = getenv("SE3DS_UNPROJECT_VEC");   // (read per call: the parity test switches it)
+  const bool no_vec = e_vec && atoi(e_vec) == 0;
+  const bool aligned = (width % 4) == 0 && (m_total % 4) == 0 && (m_offset % 4) == 0 &&
+      (((uintptr_t)feats | (uintptr_t)depth | (uintptr_t)xyz1 | (uintptr_t)feats_out |
+        (uintptr_t)sin_hd | (uintptr_t)cos_hd) & 15) == 0 && p < ((int64_t)1 << 31);
+  if (!no_vec && aligned && (feat_dtype == SE3DS_F32 || feat_dtype == SE3DS_I32) &&
+      (channels == 1 || channels == 3)) {
+    dim3 g4((unsigned)grid_for(p / 4, kBlock), (unsigned)n);
+#define SE3DS_U4(T, CC)                                                                          \
+    hipLaunchKernelGGL((unproject_equirect_vec4_kernel<T, CC>), g4, dim3(kBlock), 0, s,          \
+                       (const T*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position, height, \
+                       width, void_class, depth_scale, xyz1, (T*)feats_out, m_total, m_offset)
+    if (feat_dtype == SE3DS_F32) {
+      if (channels == 3) SE3DS_U4(float, 3); else SE3DS_U4(float, 1);
+    } else {
+      if (channels == 3) SE3DS_U4(int32_t, 3); else SE3DS_U4(int32_t, 1);
+    }
+#undef SE3DS_U4
+    return check_launch("unproject_equirect(vec4)");
+  }
   switch (feat_dtype) {
     case SE3DS_F32:
       hipLaunchKernelGGL(unproject_equirect_kernel<float>, grid, dim3(kBlock), 0, s,
@@ -3667,6 +3811,33 @@ int se3ds_project_equirect_memory(const float* xyz1, const float* offset, const 
   return dispatch_splat<true>(xyz1, offset, feats, feat_dtype, n, m, capacity, channels, height,
                               width, depth_scale, input_void, output_void, depth, feat, mask,
                               mask_void, workspace, workspace_bytes, stream);
+}
+
+int se3ds_warp_views_to_target(const void* const* view_feats, int feat_dtype,
+                               const float* const* view_depth, const float* const* view_position,
+                               int views, int n, int height, int width, int channels,
+                               float void_class, float depth_scale, const float* sin_el,
+                               const float* cos_el, const float* sin_hd, const float* cos_hd,
+                               float* mem_xyz1, void* mem_feats, int64_t capacity, int64_t m_offset,
+                               const float* target, int out_height, int out_width,
+                               float output_void, float* depth, float* feat, float* mask,
+                               float mask_void, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (views < 0 || n <= 0 || height <= 0 || width <= 0) return SE3DS_E_BADSHAPE;
+  const int64_t p = (int64_t)height * width;
+  if (m_offset < 0 || m_offset + (int64_t)views * p > capacity) return SE3DS_E_BADSHAPE;
+  const int dt = feat_dtype & ~SE3DS_FEAT_BYTE_RANGE;
+  for (int v = 0; v < views; ++v) {
+    const int rc = se3ds_unproject_equirect_into(
+        view_feats[v], dt, view_depth[v], sin_el, cos_el, sin_hd, cos_hd,
+        view_position ? view_position[v] : nullptr, n, height, width, channels, void_class,
+        depth_scale, mem_xyz1, mem_feats, capacity, m_offset + (int64_t)v * p, stream);
+    if (rc != SE3DS_OK) return rc;
+  }
+  return dispatch_splat<true>(mem_xyz1, target, mem_feats, feat_dtype, n, m_offset + (int64_t)views * p,
+                              capacity, channels, out_height, out_width, depth_scale, void_class,
+                              output_void, depth, feat, mask, mask_void, workspace, workspace_bytes,
+                              stream);
 }
 
 int se3ds_project_to_feat(const float* coords, const void* feats, int feat_dtype, int n, int64_t m,

@@ -45,7 +45,10 @@ __device__ __forceinline__ void unpack8(const uint4& v, float (&o)[8]) {
 // mode 0: sums of (x, x^2)                        [forward statistics / column sums]
 // mode 1: sums of (dpre, dpre * xhat), dpre = dy * act'(y)   [backward statistics]
 // Optional row_scale (rows of the [G*R] view) multiplies the first operand (x or dy).
-template <typename T, int VEC, int MODE, bool U2 = false, int ACT = 0>
+// CG (round 5, bf16 MODE 1 only): the launch uses the CHANNEL-GROUP layout -- cx = 8 lanes x 8
+// channels = 64 channels = one 128-byte line per row, ry = 32 rows -- and the 32 row partials of a
+// block are folded by all 256 threads (two LDS rounds) instead of 8 threads walking 32 rows each.
+template <typename T, int VEC, int MODE, bool U2 = false, int ACT = 0, bool CG = false>
 __global__ void __launch_bounds__(256)
 norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
                     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -204,6 +207,23 @@ norm_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* _
     red[1][threadIdx.x * VEC + e] = s1[e];
   }
   __syncthreads();
+  if constexpr (CG && VEC == 8) {
+    // red[k][ty][64 channels]: thread t sums rows q*16 .. q*16+15 of (k, channel), q = bit 6 of t
+    __shared__ ACC red2[2][2][64];
+    const int t = threadIdx.x, k = t >> 7, q = (t >> 6) & 1, ch = t & 63;
+    ACC v = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v += red[k][(q * 16 + i) * 64 + ch];
+    red2[k][q][ch] = v;
+    __syncthreads();
+    if (t < 128) {
+      const int kk = t >> 6;
+      const int c = blockIdx.y * 64 + ch;
+      if (c < C)
+        partial[(((int64_t)g * rblocks + blockIdx.x) * 2 + kk) * C + c] = (float)(red2[kk][0][ch] + red2[kk][1][ch]);
+    }
+    return;
+  }
   if (ty == 0 && cok) {
     for (int t = 1; t < ry; ++t) {
 #pragma unroll
@@ -552,7 +572,14 @@ norm_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T
 //   conv's weight / data gradients), computed from the bf16-rounded dx as that pass would;
 //   colpart[blockIdx.x][2][C] (second row zero: the layout of the statistics partials, so the
 //   same final reduction applies) = column sums of rounded dx * sum_row[row] -- the bias gradient.
-template <int ACT, int IN_ACT, bool ROWS = false>
+// PRO (round 5; channel-group layout cx = 8, ry = 32, one group, C % 64 == 0): `sums` is not the
+// reduced [2][C] array but the statistics kernel's PARTIAL rows [prows][2][C]; every workgroup folds
+// the columns of its own 64 channels in a prologue (prows x 512 bytes, L2-resident) -- the stand-
+// alone norm_final_reduce launch between the two passes (255 per step, 7 us alone / 17 us inside the
+// step, plus two dependent-launch boundaries each) is gone.  Every workgroup of a channel group adds
+// the same numbers in the same order: identical sums.  Row block 0 also writes the folded sums
+// (dbeta = sum dz, dgamma = sum dz * xhat: straight into the gradient arena) and sums_out[2][C].
+template <int ACT, int IN_ACT, bool ROWS = false, bool PRO = false>
 __global__ void __launch_bounds__(256)
 norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x,
                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -562,18 +589,62 @@ norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __re
                            const uint8_t* __restrict__ amask, float in_alpha,
                            const float* __restrict__ sum_row = nullptr,
                            const float* __restrict__ out_row = nullptr,
-                           float* __restrict__ colpart = nullptr) {
+                           float* __restrict__ colpart = nullptr, int prows = 0,
+                           float* __restrict__ dbeta = nullptr, float* __restrict__ dgamma = nullptr,
+                           float* __restrict__ sums_out = nullptr) {
   typedef uint16_t T;
   constexpr int VEC = 8;
   const int g = blockIdx.z;
   const int tx = threadIdx.x % cx, ty = threadIdx.x / cx;
   const int c0 = (blockIdx.y * cx + tx) * VEC;
-  if (!ROWS && c0 >= C) return;
+  if (!ROWS && !PRO && c0 >= C) return;
   const bool live = c0 < C;
   float bsum[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) bsum[e] = 0.f;
   float gr[VEC], k1[VEC], c0k[VEC];
+  __shared__ float pro_sums[PRO ? 2 : 1][PRO ? 64 : 1];
+  // one LDS buffer for the prologue's fold (PRO: 2 x 32 x 64 floats) and, after it, the bias
+  // partials of ROWS (256 x 8 floats)
+  __shared__ float lds_buf[PRO ? 4096 : (ROWS ? 256 * VEC : 1)];
+  if constexpr (PRO) {
+    // (cx == 8, ry == 32, C % 64 == 0: every thread is live)
+    float (*pro_red)[32][64] = reinterpret_cast<float (*)[32][64]>(lds_buf);
+    float a0[VEC], a1[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+    for (int b = ty; b < prows; b += 32) {
+      const float* P = sums + (int64_t)b * 2 * C + c0;
+      float v0[VEC], v1[VEC];
+      VT<float>::load(P, reinterpret_cast<float(&)[4]>(v0[0]));
+      VT<float>::load(P + 4, reinterpret_cast<float(&)[4]>(v0[4]));
+      VT<float>::load(P + C, reinterpret_cast<float(&)[4]>(v1[0]));
+      VT<float>::load(P + C + 4, reinterpret_cast<float(&)[4]>(v1[4]));
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { a0[e] += v0[e]; a1[e] += v1[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      pro_red[0][ty][tx * VEC + e] = a0[e];
+      pro_red[1][ty][tx * VEC + e] = a1[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int k = threadIdx.x >> 6, ch = threadIdx.x & 63;
+      double t = 0;   // (binary64 second stage, as norm_final_reduce_kernel)
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) t += pro_red[k][i][ch];
+      const float tf = (float)t;
+      pro_sums[k][ch] = tf;
+      if (blockIdx.x == 0) {
+        const int c = blockIdx.y * 64 + ch;
+        if (sums_out) sums_out[k * C + c] = tf;
+        if (k == 0 && dbeta) dbeta[c] = tf;
+        if (k == 1 && dgamma) dgamma[c] = tf;
+      }
+    }
+    __syncthreads();
+  }
   if (live) {
     const int64_t gc = (int64_t)g * C + c0;
     float mu[VEC], rs[VEC], gm[VEC], s0[VEC], s1[VEC];
@@ -583,10 +654,15 @@ norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __re
     VT<float>::load(rstd + gc + 4, reinterpret_cast<float(&)[4]>(rs[4]));
     VT<float>::load(gamma + c0, reinterpret_cast<float(&)[4]>(gm[0]));
     VT<float>::load(gamma + c0 + 4, reinterpret_cast<float(&)[4]>(gm[4]));
+    if constexpr (PRO) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { s0[e] = pro_sums[0][tx * VEC + e]; s1[e] = pro_sums[1][tx * VEC + e]; }
+    } else {
     VT<float>::load(sums + (int64_t)g * 2 * C + c0, reinterpret_cast<float(&)[4]>(s0[0]));
     VT<float>::load(sums + (int64_t)g * 2 * C + c0 + 4, reinterpret_cast<float(&)[4]>(s0[4]));
     VT<float>::load(sums + ((int64_t)g * 2 + 1) * C + c0, reinterpret_cast<float(&)[4]>(s1[0]));
     VT<float>::load(sums + ((int64_t)g * 2 + 1) * C + c0 + 4, reinterpret_cast<float(&)[4]>(s1[4]));
+    }
     const float inv_count = 1.0f / count;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
@@ -649,10 +725,21 @@ norm_bwd_apply_fast_kernel(const uint16_t* __restrict__ dy, const uint16_t* __re
     }
   }
   if (ROWS) {
-    __shared__ float red[256 * VEC];
+    float* red = lds_buf;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = bsum[e];
     __syncthreads();
+    if (PRO) {
+      // compact rows [gridDim.x][C] (the slab layout of se3ds_wgrad_reduce_multi: the bias sums of a
+      // module are folded with its weight-gradient slabs in ONE deferred launch); 64 threads fold
+      // the 32 row partials of one channel each
+      if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) t += red[q * 64 + threadIdx.x];
+        colpart[(int64_t)blockIdx.x * C + blockIdx.y * 64 + threadIdx.x] = t;
+      }
+    } else
     if (ty == 0 && live) {
       const int ny = 256 / cx;
       float* row = colpart + (int64_t)blockIdx.x * 2 * C + c0;
@@ -1015,6 +1102,100 @@ int se3ds_norm_bwd_apply_rows(const void* dy, const void* x, int dtype, int64_t 
 #undef LAUNCH_ROWS
   launch_final_reduce(s, part, (int)grid.x, c, 1, scratch_sums, colsum_dst, nullptr);
   return check_launch("norm_bwd_apply_rows");
+}
+
+// Round 5: batch-norm backward in TWO launches (statistics partials, apply) instead of three: the
+// channel-group layout (64 channels = one 128-byte line per row and workgroup) lets every apply
+// workgroup fold the partial rows of its own channels in a prologue.  One group, bf16, c % 64 == 0,
+// c >= kCgMinC (enough channel groups to fill the chip with <= kCgMaxRows partial rows).
+constexpr int kCgMaxRows = 64;
+static int cg_min_c() {   // SE3DS_NORM_CG_MINC (A/B): smallest channel count that takes this path
+  static const int v = [] {
+    const char* e = getenv("SE3DS_NORM_CG_MINC");
+    const int x = e ? atoi(e) : 0;
+    return x >= 64 ? x : 512;
+  }();
+  return v;
+}
+static int cg_stat_blocks(int64_t r, int c) {
+  static const int total = [] {
+    const char* e = getenv("SE3DS_NORM_CG_STAT_BLOCKS");
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? x : 768;
+  }();
+  int64_t rb = total / (c / 64);
+  const int64_t max_rb = ceil_div(r, (int64_t)32 * 4);   // >= 4 rows per thread
+  if (rb > max_rb) rb = max_rb;
+  if (rb > kCgMaxRows) rb = kCgMaxRows;
+  if (rb < 1) rb = 1;
+  return (int)rb;
+}
+static int cg_apply_blocks(int64_t r, int c) {
+  static const int total = [] {
+    const char* e = getenv("SE3DS_NORM_CG_APPLY_BLOCKS");
+    const int x = e ? atoi(e) : 0;
+    return x > 0 ? x : 2048;
+  }();
+  int64_t rb = total / (c / 64);
+  const int64_t max_rb = ceil_div(r, (int64_t)32);
+  if (rb > max_rb) rb = max_rb;
+  if (rb < 1) rb = 1;
+  return (int)rb;
+}
+
+int se3ds_norm_bwd_cg_supported(int dtype, int64_t r, int c, int act, int has_mask, int in_act) {
+  static const bool off = [] {
+    const char* e = getenv("SE3DS_NORM_CG");
+    return e && atoi(e) == 0;
+  }();
+  if (off || dtype != SE3DS_BF16 || r <= 0 || c < cg_min_c() || (c % 64) != 0) return 0;
+  if (act < 0 || act > 2 || (act != 0 && !has_mask) || !(in_act == 0 || in_act == 2)) return 0;
+  return 1;
+}
+
+size_t se3ds_norm_bwd_cg_workspace_bytes(int c) { return sizeof(float) * (size_t)kCgMaxRows * 2 * (size_t)c; }
+
+// rows of the [rows][c] bias partials se3ds_norm_bwd_cg writes when sum_row / out_row are given
+int se3ds_norm_bwd_cg_col_rows(int64_t r, int c) { return cg_apply_blocks(r, c); }
+
+int se3ds_norm_bwd_cg(const void* dy, const void* x, int dtype, int64_t r, int c, const float* mean,
+                      const float* rstd, const float* gamma, float count, int act, float alpha,
+                      void* dx, void* dres, const void* act_mask, int in_act, float in_alpha,
+                      float* dbeta_out, float* dgamma_out, float* sums_out, const float* sum_row,
+                      const float* out_row, float* colpart, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+  if (!se3ds_norm_bwd_cg_supported(dtype, r, c, act, act_mask != nullptr, in_act) || gamma == nullptr)
+    return SE3DS_E_UNSUPPORTED;
+  const bool rows = sum_row != nullptr;
+  if (rows && (out_row == nullptr || colpart == nullptr || in_act != 0)) return SE3DS_E_UNSUPPORTED;
+  if (workspace_bytes < se3ds_norm_bwd_cg_workspace_bytes(c)) return SE3DS_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  float* part = (float*)workspace;
+  const int rb = cg_stat_blocks(r, c);
+  const dim3 gs((unsigned)rb, (unsigned)(c / 64), 1);
+  const uint16_t* A = (const uint16_t*)dy;
+  const uint16_t* X = (const uint16_t*)x;
+#define LAUNCH_ST(AC)                                                                             \
+  hipLaunchKernelGGL((norm_partial_kernel<uint16_t, 8, 1, true, AC, true>), gs, dim3(256), 0, s, A,  \
+                     (const uint16_t*)nullptr, X, mean, rstd, (const float*)nullptr, r, c, 8, 32,    \
+                     act, alpha, rb, part, (const uint8_t*)act_mask)
+  if (act == 0) LAUNCH_ST(0); else if (act == 1) LAUNCH_ST(1); else LAUNCH_ST(2);
+#undef LAUNCH_ST
+  const dim3 ga((unsigned)cg_apply_blocks(r, c), (unsigned)(c / 64), 1);
+#define LAUNCH_AP(AC, IA, RW)                                                                     \
+  hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<AC, IA, RW, true>), ga, dim3(256), 0, s, A, X, mean, \
+                     rstd, gamma, part, count, r, c, 8, 32, alpha, (uint16_t*)dx, (uint16_t*)dres,     \
+                     (const uint8_t*)act_mask, in_alpha, sum_row, out_row, colpart, rb, dbeta_out,     \
+                     dgamma_out, sums_out)
+  if (rows) {
+    if (act == 0) LAUNCH_AP(0, 0, true); else if (act == 1) LAUNCH_AP(1, 0, true); else LAUNCH_AP(2, 0, true);
+  } else if (in_act == 0) {
+    if (act == 0) LAUNCH_AP(0, 0, false); else if (act == 1) LAUNCH_AP(1, 0, false); else LAUNCH_AP(2, 0, false);
+  } else {
+    if (act == 0) LAUNCH_AP(0, 2, false); else if (act == 1) LAUNCH_AP(1, 2, false); else LAUNCH_AP(2, 2, false);
+  }
+#undef LAUNCH_AP
+  return check_launch("norm_bwd_cg");
 }
 
 int se3ds_affine_bwd(const void* dy, const void* y, int dtype, int g, int64_t r, int c,

@@ -558,6 +558,10 @@ def _run_paired(ctx, fns):
   on_gpu = ctx.device.type == 'cuda'
   dev, stream = ctx.device, (torch.cuda.current_stream(ctx.device) if on_gpu else None)
 
+  keep = ctx.streams
+  if 'fwd' not in ctx.stream_phases:
+    ctx.streams = None   # (debugging switch: the forward pass on one stream, as run_branches does)
+
   def work(tag):
     try:
       if on_gpu:
@@ -580,6 +584,7 @@ def _run_paired(ctx, fns):
     th.join()
   finally:
     ctx.pair = None
+    ctx.streams = keep
   if err:
     real = [e for e in err if not isinstance(e, threading.BrokenBarrierError)]
     raise (real or err)[0]
@@ -1021,6 +1026,19 @@ def flush_wgrad_reduces(ctx):
   if not rows:
     return
   ctx.wgrad_defer = []   # (a fresh list: `rows` is this launch's, also if a caller still holds it)
+  _reduce_rows(ctx, rows)
+
+
+def reduce_or_defer(ctx, row):
+  """row = (slabs, splits, n / 4, destination): dst[i] = sum_s slabs[s][i] -- joins the module's
+  deferred reductions (ctx.wgrad_defer) or runs right away as a one-row launch."""
+  if ctx.wgrad_defer is not None:
+    ctx.wgrad_defer.append(row)
+  else:
+    _reduce_rows(ctx, [row])
+
+
+def _reduce_rows(ctx, rows):
   key = (str(ctx.device), tuple(rows))
   ent = _RED_TABLES.get(key)
   if ent is None:   # (pointers are stable: per-layer slabs, one gradient arena -- built once)
@@ -1031,8 +1049,11 @@ def flush_wgrad_reduces(ctx):
       first += (n4 + tile - 1) // tile
     ent = (torch.tensor(tab, dtype=torch.int64, device=ctx.device), first)
     _RED_TABLES[key] = ent
-  _chk(_L().se3ds_wgrad_reduce_multi(ent[0].data_ptr(), len(rows), ent[1], _lib.stream()),
-       'se3ds_wgrad_reduce_multi')
+  # (the bench's instrumented step charges the batched reduce to the weight gradients, as it
+  # charges every immediate reduce inside the timed se3ds_conv2d_wgrad call)
+  with _Timed('wgrad', 0.0, 'split reduce (batched)'):
+    _chk(_L().se3ds_wgrad_reduce_multi(ent[0].data_ptr(), len(rows), ent[1], _lib.stream()),
+         'se3ds_wgrad_reduce_multi')
 
 
 def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act=ACT_NONE,
@@ -1312,6 +1333,10 @@ _FUSED_BN_BWD = os.environ.get('SE3DS_FUSED_BN_BWD', '0') == '1'
 # default: the batch norm in front of it (in backward order) stores its dx pre-scaled and writes
 # the bias gradient from the same kernel (se3ds_norm_bwd_apply_rows)
 _FUSED_ROW_SCALE = os.environ.get('SE3DS_FUSED_ROW_SCALE', '1') != '0'
+# SE3DS_NORM_CG=0: batch-norm backward as statistics + column reduction + apply (three launches);
+# default: se3ds_norm_bwd_cg (two launches, the apply workgroups fold the partial rows) where the
+# shape allows (bf16, channels % 64 == 0, >= 512 channels, one replica)
+_NORM_CG = os.environ.get('SE3DS_NORM_CG', '1') != '0'
 
 
 def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: Var = None,
@@ -1439,6 +1464,47 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
                                 act, float(alpha), dx.data_ptr(), _lib.ptr(dres), _lib.ptr(amask),
                                 _lib.stream()), 'se3ds_affine_bwd')
       else:
+        in_a = in_act[0] if in_act else 0
+        if (_NORM_CG and not sync_bwd and g == 1 and fused is None and lim is None and
+            L.se3ds_norm_bwd_cg_supported(ctx.code, r, c, act, 1 if amask is not None else 0, in_a)):
+          # Round 5: statistics partials + apply in the channel-group layout, the apply workgroups
+          # fold the partial rows themselves -- no stand-alone column reduction between the passes
+          # (se3ds_norm_bwd_cg); beta / gamma gradients are written by the apply kernel
+          sink = x.row_sink
+          use_rows = (sink is not None and _FUSED_ROW_SCALE and ctx.param_grads and not in_act and
+                      x.grad is None)
+          cws = ctx.ws('norm_cg', L.se3ds_norm_bwd_cg_workspace_bytes(c))
+          colpart, nrows = None, 0
+          if use_rows:
+            # (the bias partials must outlive the module's deferred reduction: the layer's own)
+            nrows = int(L.se3ds_norm_bwd_cg_col_rows(r, c))
+            colpart = layer.__dict__.get('_cg_colpart')
+            if colpart is None or colpart.numel() < nrows * c:
+              colpart = torch.empty(nrows * c, dtype=torch.float32, device=ctx.device)
+              layer._cg_colpart = colpart
+          pg = ctx.param_grads
+          _chk(L.se3ds_norm_bwd_cg(
+              dy.data_ptr(), xd.data_ptr(), ctx.code, r, c, mean.data_ptr(), rstd.data_ptr(),
+              gamma.data_ptr(), count, act, float(alpha), dx.data_ptr(), _lib.ptr(dres),
+              _lib.ptr(amask), in_a, float(in_act[1]) if in_act else 0.0,
+              st.grad_views[layer.name + '/beta'].data_ptr() if pg else None,
+              st.grad_views[layer.name + '/gamma'].data_ptr() if pg else None, None,
+              sink[1].data_ptr() if use_rows else None, sink[0].data_ptr() if use_rows else None,
+              _lib.ptr(colpart), cws.data_ptr(), cws.numel(), _lib.stream()), 'se3ds_norm_bwd_cg')
+          if _NORM_DEBUG is not None:
+            k = ('cg-rows' if use_rows else 'cg', tuple(xd.shape), layer.kind)
+            _NORM_DEBUG[k] = _NORM_DEBUG.get(k, 0) + 1
+          if use_rows:
+            reduce_or_defer(ctx, (colpart.data_ptr(), nrows, c // 4,
+                                  sink[2].grad_views[sink[3]].data_ptr()))
+          if in_act:
+            x.grad_pre_act = True
+          accumulate(x, dx)
+          if use_rows:
+            x.grad_scaled = x.gver
+          if want_res:
+            accumulate(res, dres)
+          return
         bs = torch.empty((g, 2, c), dtype=torch.float32, device=ctx.device)
         direct = ctx.param_grads and g == 1
         # parameter gradients are the LOCAL sums (aggregated later with every other gradient);

@@ -346,8 +346,11 @@ class GAN(gan_manager.GANManager):
                              d_depth.data_ptr(), _lib.stream()), 'se3ds_add')
     # ---- generator backward
     ctx_g.param_grads = True
-    if ctx_g.streams is not None and WGRAD_STREAM:
-      # one replica: the conv layers' weight gradients leave the dgrad -> norm -> dgrad chain
+    if ctx_g.streams is not None and WGRAD_STREAM and sync is None:
+      # ONE replica only: the conv layers' weight gradients leave the dgrad -> norm -> dgrad chain.
+      # (With several replicas the segment hand-over below orders the optimiser's stream behind the
+      # module's backward stream only: a wgrad stream would let clip / all-reduce read slabs and
+      # gradients whose kernels are still running.)
       ctx_g.wgrad_stream = self._wgrad_stream(dev)
     push_rgb(d_rgb)
     push_depth(d_depth)
@@ -405,12 +408,21 @@ class GAN(gan_manager.GANManager):
       self.g_optimizer.end_step()
       g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
     elif sync is None:
+      # serial order (SE3DS_SEGMENT_OPTIMIZER=0, and the bench's instrumented step): the split
+      # reductions of ALL weight gradients go out as one table-driven launch behind the backward
+      # pass, the operand copies of a model as one launch behind its update (round 5: 295 + 290
+      # launches per step less on this path too)
+      if DEFER_WGRAD_REDUCE and ctx_g.wgrad_stream is None:
+        ctx_g.wgrad_defer = []
       ctx_g.backward()
+      ctx_g.wgrad_defer = None
       G.spectral.backward_fixup(dots_only=FUSED_SN_CLIP)
       self._update_all(self.g_optimizer, FUSED_SN_CLIP, ema_theta, ema_omd)
       g_norm = self.g_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
       self._update_all(self.d_optimizer, False, None, 0.0)
       d_norm = self.d_optimizer.mean_clipped_norm(GRAD_CLIP_NORM).clone()
+      self._operand_group(G, None, ctx_g.dtype).prep(G.store.version)
+      self._operand_group(D, None, ctx_d.dtype).prep(D.store.version)
     else:
       # Several replicas (round 4: the SAME stream schedule as the benchmarked one-replica step):
       # when the backward pass leaves a module -- on the main stream or on a decoder's branch
@@ -435,6 +447,7 @@ class GAN(gan_manager.GANManager):
           sync.reduce_range(G.store.grad, e0, e1)   # (its `ready` event lands on this stream)
       ctx_g.on_segment = segment_done
       ctx_g.after_collective = sync.pump
+      assert ctx_g.wgrad_stream is None   # (see above: one replica only)
       if DEFER_WGRAD_REDUCE:
         ctx_g.wgrad_defer = []
       ctx_g.backward()
@@ -518,6 +531,7 @@ class GAN(gan_manager.GANManager):
     sync = self._grad_sync()
     if sync is None:
       self._update_all(self.d_optimizer, False, None, 0.0)
+      self._operand_group(D, None, ctx_d.dtype).prep(D.store.version)
     else:
       self._sync_discriminator(sync)
       sync.finish()

@@ -345,6 +345,76 @@ class PointCloudMemory:
                                              position=position, out=(self._x, self._f, self.m))
     self.m += p
 
+  def clear(self):
+    """Forgets the points (the buffers stay)."""
+    self.m = 0
+    self.byte_range = True
+
+  def append_views_and_project(self, views, void_class: float, depth_scale: float,
+                               target: Optional[torch.Tensor], height: int, width: int,
+                               with_mask: bool = False,
+                               mask_void: float = constants.INVALID_RGB_VALUE,
+                               output_void_class: float = 0):
+    """One trajectory step in ONE library call (`se3ds_warp_views_to_target`): every view
+    (feats (N,H,W[,C]), depth (N,H,W), position (N,3) or None) is appended as append_equirect does
+    and the target at `target` (N,3) is rendered as project() does -- utils/eval_metric.py:153-166,
+    233-240; the launches are queued back to back instead of through four Python calls."""
+    if not views:
+      return self.project(height, width, void_class, depth_scale, position=target,
+                          with_mask=with_mask, mask_void=mask_void,
+                          output_void_class=output_void_class)
+    feats0 = views[0][0]
+    vh, vw = views[0][1].shape[1], views[0][1].shape[2]
+    if void_class < 0.0 and feats0.dtype == torch.uint8:
+      raise ValueError('feats datatype must be signed if the void class is negative')
+    p = vh * vw
+    self.reserve(self.m + len(views) * p)
+    fl, dl, pl, keep = [], [], [], []
+    any_pos = any(v[2] is not None for v in views)
+    for feats, depth, pos in views:
+      if feats.dim() == 3:
+        feats = feats[..., None]
+      _lib.require_cuda(feats, depth, pos)
+      if (feats.dtype != self.dtype or tuple(feats.shape) != (self.n, vh, vw, self.c) or
+          tuple(depth.shape) != (self.n, vh, vw)):
+        raise ValueError('views must share the memory\'s dtype, batch, channels and one size')
+      self.byte_range = self.byte_range and byte_range(feats, void_class)
+      feats, depth = feats.contiguous(), depth.to(torch.float32).contiguous()
+      if any_pos:
+        pos = (torch.zeros((self.n, 3), dtype=torch.float32, device=self.device) if pos is None
+               else pos.to(torch.float32).contiguous())
+        pl.append(pos.data_ptr())
+      keep += [feats, depth, pos]
+      fl.append(feats.data_ptr())
+      dl.append(depth.data_ptr())
+    import ctypes
+    nv = len(views)
+    arr = lambda xs: (ctypes.c_void_p * nv)(*xs)
+    dev, n, c = self.device, self.n, self.c
+    tab = _host_tables.equirect_tables(vh, vw, dev)
+    base = tab.data_ptr()
+    depth_o = torch.empty((n, height, width), dtype=torch.float32, device=dev)
+    out = torch.empty((n, height, width, c), dtype=torch.float32, device=dev)
+    mask = torch.empty((n, height, width), dtype=torch.float32, device=dev) if with_mask else None
+    L = _lib.lib()
+    m_new = self.m + nv * p
+    ws = _workspace(L.se3ds_splat_workspace_bytes(n, m_new, height, width, c), dev)
+    if target is not None:
+      _lib.require_cuda(target)
+      target = target.to(torch.float32).contiguous()
+    hint = FEAT_BYTE_RANGE if (self.dtype == torch.int32 and c <= 3 and self.byte_range) else 0
+    rc = L.se3ds_warp_views_to_target(
+        arr(fl), _lib.dtype_code(self._f) | hint, arr(dl), arr(pl) if any_pos else None, nv, n, vh, vw,
+        c, float(void_class), float(depth_scale), base, base + 4 * vh, base + 8 * vh,
+        base + 8 * vh + 4 * vw, _lib.ptr(self._x), _lib.ptr(self._f), self.capacity, self.m,
+        _lib.ptr(target), height, width, float(output_void_class), _lib.ptr(depth_o), _lib.ptr(out),
+        _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(), _lib.stream())
+    _lib.check(rc, 'se3ds_warp_views_to_target')
+    self.m = m_new
+    if hint:
+      _poll_promise(dev)
+    return (depth_o, out, mask) if with_mask else (depth_o, out)
+
   def project(self, height: int, width: int, void_class: float, depth_scale: float,
               position: Optional[torch.Tensor] = None, with_mask: bool = False,
               mask_void: float = constants.INVALID_RGB_VALUE, output_void_class: float = 0):

@@ -44,16 +44,17 @@ def test_two_replicas_share_one_gpu_over_gloo(own_comm):
 
 
 def test_two_replica_stream_schedule_is_bit_identical_to_one_stream():
-  """Round 4: with several replicas the decoders keep their two HIP streams (lockstep branch threads,
-  event-ordered paired SyncBN sums) and the per-module fix-up / clip / gradient hand-over runs on
-  the optimiser's side stream -- the schedule the one-GPU bench measures.  It only reorders
-  independent work: the two-replica worker's signature (parameter / Adam / EMA checksums after
+  """With several replicas the decoders can keep their two HIP streams (lockstep branch threads,
+  event-ordered paired SyncBN sums; opt-in SE3DS_DUAL_STREAM_DP=1 until it has run over RCCL on two
+  real GPUs -- gloo blocks the host and cannot show a stream-ordering mistake around NCCL's streams)
+  and the per-module fix-up / clip / gradient hand-over runs on the optimiser's side stream -- the
+  schedule the one-GPU bench measures.  It only reorders independent work: the two-replica worker's signature (parameter / Adam / EMA checksums after
   train_g_d, train_d, train_g_d) must equal the one-stream run's BIT FOR BIT, and the SyncBN
   collective count stays 2 x (all batch norms - those of one decoder branch)."""
   sigs = {}
   for dual in ('0', '1'):
-    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', SE3DS_DUAL_STREAM=dual,
-               SE3DS_GRAD_SYNC_OWN_COMM='0', **_LOOPBACK)
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0', SE3DS_DUAL_STREAM='1',
+               SE3DS_DUAL_STREAM_DP=dual, SE3DS_GRAD_SYNC_OWN_COMM='0', **_LOOPBACK)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
            '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
            os.path.join(ROOT, 'tests', '_dist_gpu_worker.py')]
@@ -118,8 +119,9 @@ def test_gan_step_on_two_gpus_over_rccl():
   import torch
   if torch.cuda.device_count() < 2:
     pytest.skip('needs two GPUs')
-  for own in ('0', '1'):
+  for own, dual in (('0', '0'), ('1', '0'), ('0', '1')):
     out = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '1', '--image-size',
-                      '128', '--no-cpu-baseline', '--no-warp'], dict(SE3DS_GRAD_SYNC_OWN_COMM=own))
+                      '128', '--no-cpu-baseline', '--no-warp'],
+                     dict(SE3DS_GRAD_SYNC_OWN_COMM=own, SE3DS_DUAL_STREAM_DP=dual))
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 2
     assert all(v == v for v in out['losses'].values())

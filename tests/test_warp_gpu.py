@@ -59,6 +59,82 @@ def test_unproject_bit_exact(n, h, dtype):
   np.testing.assert_array_equal(fs.cpu().numpy(), f_o[..., 0])
 
 
+@pytest.mark.parametrize('dtype,c', [(np.int32, 3), (np.float32, 3), (np.int32, 1)])
+def test_unproject_vec4_kernel_equals_scalar_kernel(dtype, c, monkeypatch):
+  """Round 5: four pixels per thread with 16-byte accesses (int32 / fp32 features, 1 or 3 channels,
+  aligned windows) against the one-pixel-per-lane kernel (SE3DS_UNPROJECT_VEC=0) and the oracle,
+  bit for bit -- also into an aligned window of a larger memory and with a position."""
+  rng = np.random.default_rng(21)
+  n, h = 2, 64
+  w = 2 * h
+  rgb, depth = synth_pano(rng, n, h, w)
+  feats = rgb[..., :c].astype(dtype)
+  pos = rng.standard_normal((n, 3)).astype(F32)
+  xyz_o, f_o = warp_np.equirectangular_to_pointcloud(feats, depth, -1, DEPTH_SCALE)
+  pos4 = np.concatenate([pos, np.zeros((n, 1), F32)], 1)[:, :, None]
+  res = {}
+  for vec in ('1', '0'):
+    monkeypatch.setenv('SE3DS_UNPROJECT_VEC', vec)
+    x, f = pano_utils.equirectangular_to_pointcloud(t(feats), t(depth), -1, DEPTH_SCALE, position=t(pos))
+    np.testing.assert_array_equal(x.cpu().numpy(), (xyz_o + pos4).astype(F32))
+    np.testing.assert_array_equal(f.cpu().numpy(), f_o)
+    # a window of a larger memory: offset 4 * 37 (aligned) and 4 * 37 + 1 (scalar fallback)
+    for off in (148, 149):
+      m = 3 * h * w
+      mem_x = torch.full((n, 4, m), 7.0, device=dev())
+      mem_f = torch.full((n, m, c), 5, dtype=t(feats).dtype, device=dev())
+      pano_utils.equirectangular_to_pointcloud(t(feats), t(depth), -1, DEPTH_SCALE, out=(mem_x, mem_f, off))
+      np.testing.assert_array_equal(mem_x[:, :, off:off + h * w].cpu().numpy(), xyz_o)
+      np.testing.assert_array_equal(mem_f[:, off:off + h * w].cpu().numpy(), f_o)
+      assert float(mem_x[:, :, :off].min()) == 7.0 and float(mem_x[:, :, off + h * w:].min()) == 7.0
+      assert int(mem_f[:, :off].min()) == 5 and int(mem_f[:, off + h * w:].min()) == 5
+    res[vec] = (x.cpu().numpy(), f.cpu().numpy())
+  np.testing.assert_array_equal(res['0'][0], res['1'][0])
+  np.testing.assert_array_equal(res['0'][1], res['1'][1])
+
+
+@pytest.mark.parametrize('n,h,views', [(1, 64, 2), (2, 32, 3), (1, 256, 2)])
+def test_trajectory_step_in_one_call_equals_the_separate_calls(n, h, views):
+  """PointCloudMemory.append_views_and_project (se3ds_warp_views_to_target: V unprojects + one
+  render queued by ONE library call) against append_equirect x V + project, and against the C
+  oracle: bit-exact depth / features / mask, identical memory."""
+  rng = np.random.default_rng(33)
+  w = 2 * h
+  vs = []
+  for _ in range(views):
+    rgb, depth = synth_pano(rng, n, h, w)
+    pos = (rng.standard_normal((n, 3)) * 0.4).astype(F32)
+    vs.append((rgb, depth, pos))
+  tgt = (rng.standard_normal((n, 3)) * 0.4).astype(F32)
+  g = [(t(r), t(d), t(p)) for r, d, p in vs]
+  a = point_cloud_utils.PointCloudMemory(n, 3, torch.int32, dev())
+  da, fa, ma = a.append_views_and_project(g, -1, DEPTH_SCALE, t(tgt), h, w, with_mask=True)
+  b = point_cloud_utils.PointCloudMemory(n, 3, torch.int32, dev())
+  for r, d, p in g:
+    b.append_equirect(r, d, -1, DEPTH_SCALE, position=p)
+  db, fb, mb = b.project(h, w, -1, DEPTH_SCALE, position=t(tgt), with_mask=True)
+  assert a.m == b.m == views * h * w
+  assert torch.equal(a.coords, b.coords) and torch.equal(a.feats, b.feats)
+  assert torch.equal(da, db) and torch.equal(fa, fb) and torch.equal(ma, mb)
+  # ... and the oracle (C twin of the kernels' arithmetic)
+  tabs = warp_np.equirect_angle_tables(h, w)
+  xs, fs = [], []
+  for r, d, p in vs:
+    x, f = warp_c.unproject_equirect(r, d, tabs, -1, DEPTH_SCALE, position=p)
+    xs.append(x)
+    fs.append(f)
+  d_o, f_o = warp_c.project_feats_to_equirectangular(np.concatenate(fs, 1), np.concatenate(xs, 2), h, w,
+                                                     -1, DEPTH_SCALE, offset=tgt)
+  np.testing.assert_array_equal(da.cpu().numpy(), d_o)
+  np.testing.assert_array_equal(fa.cpu().numpy(), f_o)
+  # a second step appends behind the first and renders everything
+  rgb, depth = synth_pano(rng, n, h, w)
+  d2, f2 = a.append_views_and_project([(t(rgb), t(depth), None)], -1, DEPTH_SCALE, t(tgt), h, w)
+  b.append_equirect(t(rgb), t(depth), -1, DEPTH_SCALE)
+  d3, f3 = b.project(h, w, -1, DEPTH_SCALE, position=t(tgt))
+  assert a.m == b.m and torch.equal(d2, d3) and torch.equal(f2, f3)
+
+
 def test_unproject_errors():
   d = dev()
   with pytest.raises(ValueError):

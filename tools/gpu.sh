@@ -62,6 +62,8 @@ task_prof_step() {
   ( for v in "$@"; do export "$v"; done
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o gan -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped > gpurun_out/prof_$tag.log 2>&1 )
   python tools/rocpd_summary.py gpurun_out/prof_tmp/gan_results.db gpurun_out/${tag}_kernel_stats.csv "$note"
+  python tools/step_trace.py gpurun_out/prof_tmp/gan_results.db gpurun_out/${tag}_per_step.csv 4 11 "$note"
+  grep '^#' gpurun_out/${tag}_per_step.csv | cut -c1-200
   tail -1 gpurun_out/prof_$tag.log | cut -c1-400
   head -24 gpurun_out/${tag}_kernel_stats.csv | cut -c1-160; tail -1 gpurun_out/${tag}_kernel_stats.csv
   rm -rf gpurun_out/prof_tmp
