@@ -87,6 +87,48 @@ def _launch_ranks(n):
 from se3ds_amd.bench_util import pmc_traffic as _pmc_traffic  # noqa: E402
 
 
+def _collective_preflight(rank, world, dev):
+  """Before the timed loop of a multi-rank run: which ranks the communicator really sees, the bus
+  bandwidth of one 256 MiB all-reduce (the gradient buckets' size class) and the latency of one
+  [2][1024] fp32 all-reduce (a SyncBatchNormalization statistics exchange, ~390 per step) -- so that
+  the first scaling curve explains itself: ring all-reduce over xGMI is per-link bound (7 links x
+  ~153 GB/s per GPU), small collectives are latency bound."""
+  out = {}
+  try:
+    ids = [None] * world
+    dist.all_gather_object(ids, (rank, torch.cuda.current_device() if dev.type == 'cuda' else -1))
+    out['rccl_ranks_seen'] = sorted(i[0] for i in ids)
+    out['devices'] = [i[1] for i in sorted(ids)]
+    # 256 MiB over RCCL (gloo -- the one-GPU plumbing tests -- goes through the host: 16 MiB)
+    nbig = (64 if dist.get_backend() == 'nccl' else 4) * 1024 * 1024
+    big = torch.ones(nbig, dtype=torch.float32, device=dev)
+    small = torch.ones((2, 1024), dtype=torch.float32, device=dev)
+    def timed(t, reps):
+      dist.all_reduce(t)
+      torch.cuda.synchronize()
+      dist.barrier()
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      for _ in range(reps):
+        dist.all_reduce(t)
+      torch.cuda.synchronize()
+      return (time.perf_counter() - t0) / reps
+    tb = _max_over_ranks(timed(big, 5), world, dev)
+    ts = _max_over_ranks(timed(small, 50), world, dev)
+    nbytes = big.numel() * 4
+    out['allreduce_big_bytes'] = nbytes
+    out['allreduce_big_ms'] = 1e3 * tb
+    out['allreduce_big_algbw_GBs'] = nbytes / tb / 1e9
+    out['allreduce_big_busbw_GBs'] = nbytes / tb / 1e9 * 2 * (world - 1) / world
+    out['allreduce_syncbn_2x1024_us'] = 1e6 * ts
+    out['sum_check'] = float(big[0].item())   # (world ** reps: the collective really summed)
+    del big, small
+    torch.cuda.empty_cache()
+  except Exception as e:   # noqa: BLE001  (a diagnostic must not take the bench down)
+    out['error'] = repr(e)[:300]
+  return out
+
+
 def _barrier(world):
   if world > 1:
     dist.barrier()
@@ -283,6 +325,8 @@ def main():
                   help='gan_step: skip the extra large-batch measurement (batch_max) on the default line')
   ap.add_argument('--no-shipped', action='store_true',
                   help='gan_step: skip the extra d_step_per_g_step = 2 cluster-step measurement')
+  ap.add_argument('--no-fp32', action='store_true',
+                  help='gan_step: skip the extra fp32 (reference arithmetic) step measurement')
   ap.add_argument('--no-warp', action='store_true',
                   help='gan_step: skip the extra cfg5 warp measurement on the default line')
   args = ap.parse_args()
@@ -293,6 +337,7 @@ def main():
     raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with '
                      f'--nproc-per-node {args.gpus} (or without torchrun: bench.py spawns the ranks)')
   dev = torch.device('cuda', local)
+  preflight = _collective_preflight(rank, world, dev) if world > 1 else None
   workload = args.workload
   if workload is None:
     workload = 'gan_step' if os.path.exists(os.path.join(ROOT, 'se3ds_amd', 'bench_step.py')) \
@@ -318,6 +363,8 @@ def main():
         'ms_per_launch': r5['ms_per_launch'], 'achieved': r5['achieved'], 'frac': r5['frac'],
         'unit': 'GB/s', 'algorithmic_bytes': r5['algorithmic_bytes'], 'unproject': r5['unproject'],
         'step_over_kernels': r5['step_over_kernels']}
+  if preflight is not None:
+    out['collectives'] = preflight
   out['backend'] = (dist.get_backend() if world > 1 else None)
   out['world_size'] = (dist.get_world_size() if world > 1 else 1)
   if rank == 0:

@@ -141,6 +141,8 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
   }
   if world == 1 and not getattr(args, 'no_shipped', False):
     out['shipped_schedule'] = shipped_schedule(gan, n, h, dev, rank)
+  if world == 1 and args.dtype == 'bf16' and not getattr(args, 'no_fp32', False):
+    out['fp32_step'] = fp32_step(gan, h, dev, rank)
   if world == 1 and args.batch <= 0 and h == 512 and not getattr(args, 'no_batch_max', False):
     # "N = B (largest that fits; report B)".  The headline stays at the named
     # per-GPU batch 8 (= cfg4's share of global batch 64); the large-batch rate rides along.
@@ -178,6 +180,57 @@ def shipped_schedule(gan, n, h, dev, rank, steps=3):
   return {'d_step_per_g_step': 2, 'value': 2 * n * steps / dt, 'unit': 'panoramas/sec',
           'ms_per_cluster_step': 1e3 * dt / steps, 'cluster_batch': 2 * n, 'steps': steps,
           'warmup': 1, 'what': 'train_d (chunk 0) + train_g_d (chunk 1) per cluster step'}
+
+
+def fp32_step(gan, h, dev, rank, nb=2, steps=2):
+  """The SAME step in the reference's own arithmetic: the reference trains in fp32 throughout
+  (trainers/gan_manager.py:175-183, no mixed-precision policy anywhere); BASELINE.json's cfg3 names
+  bf16, which the headline measures.  Here the models' compute dtype is switched to fp32 -- the path
+  that carries the 1e-3 parity (fp32-input MFMA, 157.3 TFLOP/s dense peak) -- for one warm-up and
+  `steps` timed train_g_d steps at per-GPU batch `nb`, then one instrumented step for the conv
+  family's fraction of that peak.  The bf16 operand copies are refreshed lazily afterwards."""
+  models = (gan.generator, gan.discriminator, gan.ema_generator)
+  keep = [m.dtype for m in models]
+  import gc
+  gc.collect()
+  torch.cuda.empty_cache()
+  try:
+    for m in models:
+      m.dtype = torch.float32
+    batch = synth_batch(nb, h, 777 + rank, dev)
+    def step():
+      gan.train_g_d(batch)
+      gan.global_step += gan.num_batched_steps
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = nn.ConvProfiler()
+    nn.set_conv_profiler(prof)
+    step()
+    torch.cuda.synchronize()
+    nn.set_conv_profiler(None)
+    summ = prof.summary()
+    ach = summ['flops'] / (summ['ms'] * 1e-3) / 1e12 if summ['ms'] > 0 else 0.0
+    return {'dtype': 'f32', 'per_gpu_batch': nb, 'value': nb * steps / dt, 'unit': 'panoramas/sec',
+            'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': 1,
+            'roofline': {'bound': 'mfma', 'achieved': ach, 'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach / F32_PEAK_TFLOPS, 'conv_ms_per_step': summ['ms'],
+                         'conv_tflop_per_step': summ['flops'] / 1e12,
+                         'frac_in_step': summ['flops'] / (1e-3 * (1e3 * dt / steps)) / 1e12 / F32_PEAK_TFLOPS},
+            'what': 'the reference trains in fp32 (gan_manager.py:175-183): same model, same step, '
+                    'compute dtype fp32 (v_mfma_f32_32x32x2_f32, the 1e-3 parity path)'}
+  except (torch.OutOfMemoryError, RuntimeError) as e:
+    nn.set_conv_profiler(None)
+    return {'dtype': 'f32', 'value': None, 'error': repr(e)[:200]}
+  finally:
+    for m, d in zip(models, keep):
+      m.dtype = d
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
 def batch_max(gan, h, dev, rank, candidates=(24, 16), steps=3):

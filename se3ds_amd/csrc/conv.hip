@@ -1785,258 +1785,10 @@ igemm_halo_kernel(const IgemmParams p) {
   }
 }
 
-// ------------------------------------------- halo-resident 3x3 tiles, 128 output channels (round 4)
-// The 128-channel layers (3x3 128->128 at 256x512 and 512x1024: 29 ms of the batch-8 step) ran the
-// kernel above as 2 channel halves x 4 pixel blocks: a wave tile of 64 channels x 64 pixels reads
-// one 1 KiB fragment per MFMA, and the PMC pass showed the LDS pipe -- not the matrix pipe -- full
-// (MFMA-busy 0.40; 64 KiB of fragment reads + 21 KiB of LDS-DMA per 64 MFMAs).  Here a wave owns ALL
-// 128 output channels of its 64 pixels (the 256-channel kernel's wave tile: 0.75 KiB per MFMA), a
-// workgroup is the four pixel blocks of one 8 x 32 patch (4 waves), and TWO workgroups share a CU:
-// K steps of 32 channels (64-byte LDS rows) keep a workgroup at 2 x 22 KiB of patch + WST x 8 KiB of
-// weights, and the second workgroup's K loop runs under the first one's barriers and epilogue.
-// OPT-IN (SE3DS_HALO_4W=3|4): faster alone, slower inside the power-limited step -- see
-// halo_4w_stages() below.
-// Schedule (as wgrad_taps3_kernel): software-pipelined inside the wave, ONE barrier per K step --
-//   wait(q0 fragments) -> read q1 -> 8 MFMAs (q0) -> vmcnt -> BARRIER (weights of step k+1 landed
-//   everywhere, stage of step k-1 free) -> LDS-DMA of step k+WST-1's weights (+ one piece of the
-//   next slab's patch) -> wait(q1) -> read q0 of step k+1 -> 8 MFMAs (q1).
-// Item geometry, epilogue and statistics rows are those of igemm_halo_kernel<., 128, .>.
-//   patch row r = pr * 34 + pc (64 B = 32 channels); 16-byte chunk index ^= (r >> 2) & 3: any 16
-//   consecutive rows cover the sixteen 16-byte slots of the 256-byte bank line (swz() above).
-template <int MODE, int WST, bool BNB = false>
-__global__ void __launch_bounds__(256, 2)
-igemm_halo4w_kernel(const IgemmParams p) {
-  typedef uint16_t T;
-  constexpr int EPC = 8, ROW = 64, SLABC = 32, TH = 8, TW = 32, PC = TW + 2, XROWS = (TH + 2) * PC;
-  constexpr int XPIECES = (XROWS + 15) / 16;        // 22 LDS-DMA pieces of 16 rows
-  constexpr int XS = (XPIECES + 3) / 4;             // patch pieces per wave: up to 6
-  constexpr int XBUF = XPIECES * 16 * ROW;          // 22 KiB
-  constexpr int CO = 128, NI = 4;
-  constexpr int WT = CO * ROW;                      // 8 KiB
-  constexpr int AHEAD = WST - 1;                    // weights of step k + AHEAD are issued in step k
-  static_assert(WST == 3 || WST == 4, "weight stages");
-  static_assert(XS <= 6, "one patch piece per K step, all landed by the barrier of tap 8");
-  static_assert(4 * kEpiScratch<2> <= XBUF, "epilogue scratch lives in a patch buffer");
-  __shared__ __attribute__((aligned(16))) unsigned char wst0[WT];
-  __shared__ __attribute__((aligned(16))) unsigned char wst1[WT];
-  __shared__ __attribute__((aligned(16))) unsigned char wst2[WT];
-  __shared__ __attribute__((aligned(16))) unsigned char wst3[WST == 4 ? WT : 16];
-  __shared__ __attribute__((aligned(16))) unsigned char sink[1024];
-  __shared__ __attribute__((aligned(16))) unsigned char xb0[XBUF];
-  __shared__ __attribute__((aligned(16))) unsigned char xb1[XBUF];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l32 = lane & 31;
-
-  const int Cr = p.sC;
-  const int nslabs = Cr / SLABC;
-  const T* __restrict__ src = (const T*)p.src;
-  const T* zero = reinterpret_cast<const T*>(g_zero_page);
-  const int lrow = lane >> 2;                                 // row of a 16-row DMA piece
-  const int wch = (lane & 3) ^ ((lane >> 4) & 3);             // global chunk of this lane's weight slot
-  const int64_t wjs = 64 * p.w_n;                             // pieces j and j+1 of a wave: 64 rows apart
-  const int nco = p.oC / CO;
-  const int nitems = p.N * p.halo_ty * p.halo_tx * nco;
-
-  struct ItemPos { int img, y0, x0, n0, tile; };
-  ItemPos cur = {0, 0, 0, 0, 0};
-  const T* xptr[XS];    // patch pieces of this wave: piece sl*4 + wave, rows 16*piece + lane/4
-  int xmk[XS];
-  const T* wbase = nullptr;
-  auto setup_item = [&](int item, ItemPos& pos, const T* (&xp)[XS], int (&xm)[XS], const T*& wb) {
-    pos.n0 = (item % nco) * CO;
-    int bt = item / nco;
-    pos.tile = bt;
-    const int tx = bt % p.halo_tx; bt /= p.halo_tx;
-    const int ty = bt % p.halo_ty;
-    pos.img = bt / p.halo_ty;
-    pos.y0 = ty * TH; pos.x0 = tx * TW;
-    const int oy0 = pos.y0 - (MODE == MODE_FWD ? p.pad_t : 2 - p.pad_t);
-    const int ox0 = pos.x0 - (MODE == MODE_FWD ? p.pad_l : 2 - p.pad_l);
-#pragma unroll
-    for (int sl = 0; sl < XS; ++sl) {
-      const int r = (sl * 4 + wave) * 16 + lrow;
-      const int ch = (lane & 3) ^ ((r >> 2) & 3);
-      const int pr = r / PC, pc = r - pr * PC;
-      const int sy = oy0 + pr;
-      int sx = ox0 + pc;
-      if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
-      bool ok = r < XROWS && (unsigned)sy < (unsigned)p.sH && (unsigned)sx < (unsigned)p.sW;
-      const int pix = (pos.img * p.sH + (ok ? sy : 0)) * p.sW + (ok ? sx : 0);
-      if (ok && p.src_mask) ok = p.src_mask[pix] != 0.0f;
-      xp[sl] = ok ? src + (int64_t)pix * Cr + ch * EPC : zero + ch * EPC;
-      xm[sl] = ok ? -1 : 0;
-    }
-    wb = (const T*)p.w + (int64_t)(pos.n0 + wave * 16 + lrow) * p.w_n + wch * EPC;
-  };
-
-  const T* zlane = zero + (lane & 3) * EPC;
-  auto issue_x = [&](unsigned char* xb, int sl, const T* xp, int xm, int slab, bool real) {
-    const bool live = real && sl * 4 + wave < XPIECES;   // wave-uniform
-    if (live)
-      glds16(xp + ((slab * SLABC) & xm), xb + (sl * 4 + wave) * 16 * ROW);
-    else
-      glds16(zlane, sink);
-  };
-  // the two weight pieces of this wave for (tap, slab): rows (j*4 + wave)*16 + lane/4
-  auto issue_w = [&](unsigned char* wt, const T* wb0, int tap, int slab, bool real) {
-    const T* wb = wb0;
-    asm volatile("" : "+v"(wb));   // (recomputed from scalars, not hoisted and spilled)
-    const int64_t soff = (int64_t)tap * p.w_tap + slab * SLABC;   // wave-uniform
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (real)
-        glds16(wb + soff + j * wjs, wt + (j * 4 + wave) * 16 * ROW);
-      else
-        glds16(zlane, sink);
-    }
-  };
-  auto wsel = [&](int i) -> unsigned char* {
-    return i == 0 ? wst0 : (i == 1 ? wst1 : (i == 2 ? wst2 : wst3));
-  };
-
-  f32x16_t acc[NI][2];
-  // first patch slab and the first AHEAD weight tiles of the current item (K steps 0 .. AHEAD-1
-  // are taps 0 .. AHEAD-1 of slab 0: AHEAD <= 3)
-  auto issue_prologue = [&]() {
-#pragma unroll
-    for (int sl = 0; sl < XS; ++sl) issue_x(xb0, sl, xptr[sl], xmk[sl], 0, true);
-#pragma unroll
-    for (int t = 0; t < AHEAD; ++t) issue_w(wsel(t), wbase, t, 0, true);
-  };
-  int item = blockIdx.x;
-  setup_item(item, cur, xptr, xmk, wbase);
-  issue_prologue();
-
-  const int wsw = (l32 >> 2) & 3;
-  int rb[2];   // patch row of this lane's pixel (tap offset 0) for the two 32-pixel fragments
-#pragma unroll
-  for (int j = 0; j < 2; ++j) rb[j] = (wave * 2 + j) * PC + l32;
-
-  uint4 wfA[NI], xfA[2], wfB[NI], xfB[2];
-  // fragments of one half K step (q: 16 channels) of tap `toff` from weight stage wt / patch xb
-  auto read_frag = [&](const unsigned char* wt, const unsigned char* xb, int toff, int q,
-                       uint4 (&wf)[NI], uint4 (&xf)[2]) {
-    const int c = q * 2 + half;
-    const unsigned char* wrow = wt + l32 * ROW + ((c ^ wsw) * 16);
-#pragma unroll
-    for (int i = 0; i < NI; ++i) wf[i] = *reinterpret_cast<const uint4*>(wrow + i * 32 * ROW);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = rb[j] + toff;
-      xf[j] = *reinterpret_cast<const uint4*>(xb + r * ROW + ((c ^ ((r >> 2) & 3)) * 16));
-    }
-  };
-  auto mfma8 = [&](const uint4 (&wf)[NI], const uint4 (&xf)[2]) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            __builtin_bit_cast(bf16x8_t, wf[i]), __builtin_bit_cast(bf16x8_t, xf[j]), acc[i][j], 0, 0, 0);
-  };
-#define H4_WAIT_LDS() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xC07F); \
-                           __builtin_amdgcn_sched_barrier(0); } while (0)
-  constexpr int tap_off[9] = {
-      MODE == MODE_FWD ? 0 * PC + 0 : 2 * PC + 2, MODE == MODE_FWD ? 0 * PC + 1 : 2 * PC + 1,
-      MODE == MODE_FWD ? 0 * PC + 2 : 2 * PC + 0, MODE == MODE_FWD ? 1 * PC + 0 : 1 * PC + 2,
-      MODE == MODE_FWD ? 1 * PC + 1 : 1 * PC + 1, MODE == MODE_FWD ? 1 * PC + 2 : 1 * PC + 0,
-      MODE == MODE_FWD ? 2 * PC + 0 : 0 * PC + 2, MODE == MODE_FWD ? 2 * PC + 1 : 0 * PC + 1,
-      MODE == MODE_FWD ? 2 * PC + 2 : 0 * PC + 0};
-
-  for (;;) {
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): prologue landed, older stores retired
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" : "+v"(rb[0]), "+v"(rb[1]));
-  read_frag(wst0, xb0, tap_off[0], 0, wfA, xfA);
-  // One K step = one tap of one 32-channel slab.  P = slab & 3 fixes the weight stage of every tap
-  // at compile time ((9 * slab + tap) % WST: tap % 3 with three stages, (P + tap) % 4 with four) and
-  // the patch buffer (P & 1).
-  auto k_step = [&](auto tap_c, auto par_c, int slab, bool next_slab) {
-    constexpr int tap = decltype(tap_c)::value, P = decltype(par_c)::value;
-    constexpr int sidx = WST == 3 ? tap % 3 : (P + tap) % 4;
-    constexpr int ntap = (tap + 1) % 9;
-    constexpr int ftap = (tap + AHEAD) % 9;
-    unsigned char* wcur = wsel(sidx);
-    unsigned char* wnxt = wsel((sidx + 1) % WST);
-    unsigned char* wfar = wsel((sidx + AHEAD) % WST);     // == the stage of step k-1
-    unsigned char* xcur = (P & 1) ? xb1 : xb0;
-    unsigned char* xoth = (P & 1) ? xb0 : xb1;
-    const bool has_next = tap < 8 || next_slab;
-    const bool has_far = tap + AHEAD < 9 || next_slab;
-    const int fslab = tap + AHEAD >= 9 ? slab + 1 : slab;
-    const bool x_piece = tap < XS && next_slab;
-    constexpr int xsl = tap < XS ? tap : 0;
-    // (opaque to the optimiser: otherwise the per-tap fragment addresses are hoisted and spilled)
-    asm volatile("" : "+v"(rb[0]), "+v"(rb[1]));
-    H4_WAIT_LDS();
-    read_frag(wcur, xcur, tap_off[tap], 1, wfB, xfB);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(wfA, xfA);
-    __builtin_amdgcn_sched_barrier(0);
-    // the weight tile of step k+1 (issued AHEAD-1 steps ago) must have landed; younger LDS-DMA
-    // stays in flight: per step 2 weight pieces + 1 patch piece (or its idle copy)
-    if (WST == 3) __builtin_amdgcn_s_waitcnt(0x0F71);   // vmcnt(1)
-    else __builtin_amdgcn_s_waitcnt(0x0F74);            // vmcnt(4)
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    issue_w(wfar, wbase, ftap, fslab, has_far);
-    issue_x(xoth, xsl, xptr[xsl], xmk[xsl], slab + 1, x_piece);
-    H4_WAIT_LDS();
-    if (has_next) read_frag(wnxt, tap == 8 ? xoth : xcur, tap_off[ntap], 0, wfA, xfA);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma8(wfB, xfB);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto slab_body = [&](auto par_c, int slab, bool next_slab) {
-#define SE3DS_TAP(T_) k_step(std::integral_constant<int, T_>(), par_c, slab, next_slab)
-    SE3DS_TAP(0); SE3DS_TAP(1); SE3DS_TAP(2); SE3DS_TAP(3); SE3DS_TAP(4);
-    SE3DS_TAP(5); SE3DS_TAP(6); SE3DS_TAP(7); SE3DS_TAP(8);
-#undef SE3DS_TAP
-  };
-  for (int slab = 0; slab < nslabs; slab += 4) {
-    slab_body(std::integral_constant<int, 0>(), slab, slab + 1 < nslabs);
-    if (slab + 1 < nslabs) slab_body(std::integral_constant<int, 1>(), slab + 1, slab + 2 < nslabs);
-    if (slab + 2 < nslabs) slab_body(std::integral_constant<int, 2>(), slab + 2, slab + 3 < nslabs);
-    if (slab + 3 < nslabs) slab_body(std::integral_constant<int, 3>(), slab + 3, slab + 4 < nslabs);
-  }
-  // every wave must be past its last fragment read before the stages are reused: xb1 becomes the
-  // epilogue scratch, xb0 and the first weight stages take the next item's prologue
-  __builtin_amdgcn_s_waitcnt(0xC07F);
-  __builtin_amdgcn_s_barrier();
-
-  int64_t opix[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int y = cur.y0 + wave * 2 + j, x = cur.x0 + l32;
-    opix[j] = (y < p.oH && x < p.oW) ? ((int64_t)cur.img * p.oH + y) * p.oW + x : -1;
-  }
-  const int co_base = cur.n0;
-  float* stats_row = ((MODE == MODE_FWD || BNB) && p.stats)
-                         ? p.stats + ((int64_t)(cur.tile * 4 + wave) * 2) * p.oC : nullptr;
-  item += gridDim.x;
-  const bool have = item < nitems;
-  if (have) {
-    setup_item(item, cur, xptr, xmk, wbase);
-    issue_prologue();
-  }
-  unsigned char* scratch = xb1 + wave * kEpiScratch<2>;
-  store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[0]), opix, co_base, lane,
-                         scratch, stats_row);
-  store_wave_lds<2, BNB>(p, *reinterpret_cast<f32x16_t(*)[2][2]>(&acc[2]), opix, co_base + 64,
-                         lane, scratch, stats_row);
-  if (!have) break;
-  }
-#undef H4_WAIT_LDS
-}
+// (Round 4's 4-wave variant for the 128-output-channel layers -- igemm_halo4w_kernel: a wave owns
+// all 128 channels of its 64 pixels, two workgroups per CU; 13-43 % faster alone, 2-3 ms SLOWER in
+// the power-limited step, DESIGN.md section 3.1 -- was removed from the library in round 5; it is
+// in the history at commit 07a2034.)
 
 // ------------------------------------------------------------------------------- wgrad
 // dW[(tap,ci), co] = sum_l xg[l,(tap,ci)] * dy[l, co].  Tile: 128 (ci of one tap) x 128 (co),
@@ -4291,19 +4043,6 @@ static int halo_tile_channels(const IgemmParams& p) {
   return eff256 >= eff128 ? 256 : 128;
 }
 
-// SE3DS_HALO_4W: 3 / 4 = igemm_halo4w_kernel with that many weight stages for the 128-channel halo
-// layers; default 0 = the 8-wave igemm_halo_kernel<., 128, 3>.  Read per call (tests switch it).
-// Measured (round 4): alone the 4-wave kernel is 13-43 % faster (tools/conv_bench.py)
-// and 6-8 % faster inside the serial instrumented step (128->128 layers 31.0 -> 29.0 ms), but the
-// other conv kernels of that same step then take 1.5 ms LONGER and the overlapped step is 2-3 ms
-// SLOWER (202.9 -> 205.4 ms): higher MFMA occupancy, lower shader clock (2.02 -> 1.93 GHz in the
-// PMC pass) -- the step is power-limited, and this kernel saves time, not energy.
-static int halo_4w_stages() {
-  const char* e = getenv("SE3DS_HALO_4W");
-  const int v = e ? atoi(e) : 0;
-  return v == 3 || v == 4 ? v : 0;
-}
-
 // SE3DS_HALO_M16: the LDS-DMA forward / data-gradient kernels (halo, 256-pixel macro tile, 128 x 128)
 // and the tap-fused weight gradient with v_mfma_f32_16x16x32_bf16 (default; 0 = 32x32x16; read per call).  Step A/B on one box, 256-channel tile only: 204.3 / 202.6 -> 200.2 / 200.0 ms.
 static bool halo_m16() {
@@ -4464,15 +4203,6 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
         if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 256, 2>), grid, dim3(512), 0, s, p);
         else if (p.bn_x) hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2, true>), grid, dim3(512), 0, s, p);
         else hipLaunchKernelGGL((igemm_halo_kernel<MODE_DGRAD, 256, 2>), grid, dim3(512), 0, s, p);
-      } else if (const int w4 = halo_4w_stages()) {
-        // round 4: 4-wave workgroups, a wave owns all 128 channels, two workgroups per CU
-        dim3 grid2((unsigned)(items < 512 ? items : 512));
-#define SE3DS_H4(WST_)                                                                             \
-        if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo4w_kernel<MODE_FWD, WST_>), grid2, dim3(256), 0, s, p); \
-        else if (p.bn_x) hipLaunchKernelGGL((igemm_halo4w_kernel<MODE_DGRAD, WST_, true>), grid2, dim3(256), 0, s, p); \
-        else hipLaunchKernelGGL((igemm_halo4w_kernel<MODE_DGRAD, WST_>), grid2, dim3(256), 0, s, p)
-        if (w4 == 3) { SE3DS_H4(3); } else { SE3DS_H4(4); }
-#undef SE3DS_H4
       } else {
         if (halo_m16()) {
           if (mode == MODE_FWD) hipLaunchKernelGGL((igemm_halo_kernel<MODE_FWD, 128, 3, false, true>), grid, dim3(512), 0, s, p);

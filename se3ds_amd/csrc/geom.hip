@@ -546,15 +546,10 @@ inline uint32_t slice_records() {
 }
 
 struct BinWs {
-  uint32_t* tile_count;   // [nb]  (single-pass layout: the tiles' record cursors = totals)
+  uint32_t* tile_count;   // [nb]
   uint32_t* hist;         // [n][chunks][ntiles]: counts, then exclusive prefix over the chunks
   uint32_t* fpart2;       // [items][C] sink partials of the occluded points, per resolve item
   uint32_t* rec;          // [N*M][2 + C]: pixel inside the tile, z bits, feature bits
-  // single-pass layout (splat_bin_fused_kernel): tile t owns records [t*cap, t*cap + min(count,
-  // cap)); records that do not fit go to the overflow list (tile, pixel, z, features)
-  uint32_t cap;           // 0: three-pass layout above
-  uint32_t* ovf_count;    // [1]
-  uint32_t* ovf;          // [N*M][3 + C]
 };
 __host__ __device__ inline size_t align16(size_t v) { return (v + 15) / 16 * 16; }
 inline size_t bin_ws_bytes(int n, int64_t m, int height, int width, int channels) {
@@ -578,52 +573,6 @@ inline BinWs carve_bin_ws(void* base, int n, int64_t m, int height, int width, i
   w.hist = (uint32_t*)p; p += align16(4 * nb * chunks);
   w.fpart2 = (uint32_t*)p; p += align16(4 * items * channels);
   w.rec = (uint32_t*)p;
-  w.cap = 0;
-  w.ovf_count = nullptr;
-  w.ovf = nullptr;
-  return w;
-}
-
-// Single-pass binning: records per tile = 8x the mean (a smooth depth map puts ~14x the mean
-// into its heaviest tile; whatever does not fit takes the overflow list), at least 2048.
-// SE3DS_SPLAT_CAP overrides (the parity tests force overflows with tiny capacities).
-inline uint32_t fused_cap(int n, int64_t m, size_t nb) {
-  static const long forced = [] {
-    const char* e = getenv("SE3DS_SPLAT_CAP");
-    return e ? atol(e) : 0L;
-  }();
-  if (forced > 0) return (uint32_t)forced;
-  const size_t pts = (size_t)n * (size_t)(m > 0 ? m : 0);
-  size_t cap = 8 * ((pts + nb - 1) / (nb ? nb : 1));
-  cap = (cap + 1023) / 1024 * 1024;
-  if (cap < 2048) cap = 2048;
-  if (cap > pts + 1024) cap = (pts + 1024) / 1024 * 1024;
-  return (uint32_t)cap;
-}
-inline size_t fused_ws_bytes(int n, int64_t m, int height, int width, int channels) {
-  const size_t ntiles = (size_t)ceil_div(height, kTileY) * ceil_div(width, kTileX);
-  const size_t nb = (size_t)n * ntiles;
-  const size_t pts = (size_t)n * (size_t)(m > 0 ? m : 0);
-  const size_t items = (size_t)resolve_items_max((int64_t)nb, (int64_t)pts, slice_records());
-  return align16(4 * (nb + 4)) + align16(4 * items * channels) +
-         align16(4 * nb * (size_t)fused_cap(n, m, nb) * (2 + channels)) +
-         align16(4 * pts * (3 + channels));
-}
-inline BinWs carve_fused_ws(void* base, int n, int64_t m, int height, int width, int channels) {
-  const size_t ntiles = (size_t)ceil_div(height, kTileY) * ceil_div(width, kTileX);
-  const size_t nb = (size_t)n * ntiles;
-  const size_t pts = (size_t)n * (size_t)(m > 0 ? m : 0);
-  const size_t items = (size_t)resolve_items_max((int64_t)nb, (int64_t)pts, slice_records());
-  char* p = (char*)base;
-  BinWs w;
-  w.hist = nullptr;
-  w.cap = fused_cap(n, m, nb);
-  w.tile_count = (uint32_t*)p;
-  w.ovf_count = w.tile_count + nb;
-  p += align16(4 * (nb + 4));
-  w.fpart2 = (uint32_t*)p; p += align16(4 * items * channels);
-  w.rec = (uint32_t*)p; p += align16(4 * nb * (size_t)w.cap * (2 + channels));
-  w.ovf = (uint32_t*)p;
   return w;
 }
 
@@ -775,228 +724,6 @@ splat_bin_count_kernel(const float* __restrict__ coords, const float* __restrict
   }
   uint32_t* row = bw.hist + ((int64_t)b * gridDim.x + blockIdx.x) * ntiles;
   for (int t = threadIdx.x; t < ntiles; t += kChunkThreads) row[t] = s_hist[t];
-}
-
-// A' (single pass): count, reserve and scatter in ONE kernel.  A chunk is processed in batches of
-// kFusedPts points per thread that stay in registers: (1) pixel index per point (fp32 screen, the
-// undecided ~2.5 % densely through the binary64 chain afterwards) and an LDS histogram whose
-// atomicAdd return value IS the point's rank inside (batch, tile); (2) one global atomicAdd per
-// touched tile reserves the batch's run in that tile's fixed-capacity bin (<= ntiles atomics per
-// 8192 points instead of one per point); (3) the records go out at bin + reserved base + rank.
-// Against the three-pass version this drops the (idx, z) round trip (16 B per point), the second
-// read of the coordinates' validity and the column scan.
-template <typename T, bool EQUIRECT, bool DEBUG, int kFusedPts>
-__global__ void __launch_bounds__(kChunkThreads, kFusedPts <= 8 ? 4 : 2)
-splat_bin_fused_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
-                       const T* __restrict__ feats, int64_t m, int64_t ld, int64_t per, int channels,
-                       int height, int width, uint64_t wmagic, float input_void, int ntiles,
-                       int tiles_x, uint32_t slice_records, SplatWs ws, BinWs bw) {
-  extern __shared__ uint32_t s_dyn[];   // hist[ntiles], base[ntiles]
-  uint32_t* s_hist = s_dyn;
-  uint32_t* s_base = s_dyn + ntiles;
-  __shared__ uint32_t s_queue[kExactQueue];
-  __shared__ int32_t s_qpk[kExactQueue];
-  __shared__ uint32_t s_qrank[kExactQueue];
-  __shared__ uint32_t s_qn;
-  const int b = blockIdx.y;
-  const float* X = coords + (int64_t)b * 4 * ld;
-  const T* F = feats + (int64_t)b * ld * channels;
-  float ox = 0.f, oy = 0.f, oz = 0.f;
-  if (EQUIRECT && offset) {
-    ox = offset[b * 3 + 0];
-    oy = offset[b * 3 + 1];
-    oz = offset[b * 3 + 2];
-  }
-  constexpr int kMaxC = kMaxBinChannels;
-  uint32_t sink = 0xffffffffu;
-  uint32_t smax[kMaxC];
-#pragma unroll
-  for (int k = 0; k < kMaxC; ++k) smax[k] = 0u;
-  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < m ? lo + per : m;
-  const int stride = 2 + channels;
-  auto load = [&](int64_t i, float* x, float* y, float* z, int* fv) {
-    *x = X[i];
-    *y = X[ld + i];
-    *z = X[2 * ld + i];
-    if (EQUIRECT && offset) {
-      *x = *x - ox;
-      *y = *y - oy;
-      *z = *z - oz;
-    }
-    const T* f = F + i * channels;
-    int v = 1;
-    for (int k = 0; k < channels; ++k) v &= (FeatIO<T>::load(f + k) != input_void);
-    *fv = v;
-  };
-  auto exact_index = [&](float x, float y, float z, int fv, float* pz_out) {
-    float px, py, pz;
-    if (EQUIRECT) {
-      se3ds_equirect_project(x, y, z, &px, &py, &pz);
-    } else {
-      px = x;
-      py = y;
-      pz = z;
-    }
-    *pz_out = pz;
-    return se3ds_splat_index(px, py, pz, width, height, fv);
-  };
-  for (int64_t base = lo; base < hi; base += (int64_t)kFusedPts * kChunkThreads) {
-    for (int t = threadIdx.x; t < ntiles; t += kChunkThreads) s_hist[t] = 0u;
-    if (threadIdx.x == 0) s_qn = 0u;
-    __syncthreads();
-    // tgt: >= 0 packed (tile << 11 | pixel); -1 invalid (sink); <= -2: queue slot -2 - tgt
-    int32_t tgt[kFusedPts];
-    uint32_t rank[kFusedPts];
-    float zz[kFusedPts];
-#pragma unroll
-    for (int u = 0; u < kFusedPts; ++u) {
-      const int64_t i = base + (int64_t)u * kChunkThreads + threadIdx.x;
-      tgt[u] = -1;
-      rank[u] = 0u;
-      zz[u] = __builtin_nanf("");
-      if (i >= hi) continue;
-      float x, y, z;
-      int fv;
-      load(i, &x, &y, &z, &fv);
-      int32_t idx = -1;
-      float pz = 0.f;
-      bool decided = false;
-      if (EQUIRECT) {
-        decided = se3ds_equirect_index_fast(x, y, z, width, height, fv, &idx, &pz) != 0;
-        if (!decided) {
-          const uint32_t slot = atomicAdd(&s_qn, 1u);
-          if (slot < (uint32_t)kExactQueue) {
-            s_queue[slot] = (uint32_t)(u * kChunkThreads + threadIdx.x);
-            tgt[u] = -2 - (int32_t)slot;
-            zz[u] = pz;   // rad: the same IEEE operation in both chains
-            continue;
-          }
-        }
-      }
-      if (!decided) idx = exact_index(x, y, z, fv, &pz);
-      zz[u] = pz;
-      if (idx >= 0) {
-        const int32_t pk = pack_tile(idx, width, wmagic, tiles_x);
-        tgt[u] = pk;
-        rank[u] = atomicAdd(&s_hist[pk >> 11], 1u);
-      }
-    }
-    __syncthreads();
-    if (EQUIRECT) {
-      const uint32_t qn = s_qn < (uint32_t)kExactQueue ? s_qn : (uint32_t)kExactQueue;
-      for (uint32_t q = threadIdx.x; q < qn; q += kChunkThreads) {
-        const int64_t i = base + s_queue[q];
-        float x, y, z, pz;
-        int fv;
-        load(i, &x, &y, &z, &fv);
-        const int32_t idx = exact_index(x, y, z, fv, &pz);
-        int32_t pk = -1;
-        uint32_t r = 0u;
-        if (idx >= 0) {
-          pk = pack_tile(idx, width, wmagic, tiles_x);
-          r = atomicAdd(&s_hist[pk >> 11], 1u);
-        }
-        s_qpk[q] = pk;
-        s_qrank[q] = r;
-      }
-      __syncthreads();
-    }
-    // reserve this batch's run in every touched tile
-    for (int t = threadIdx.x; t < ntiles; t += kChunkThreads) {
-      const uint32_t c = s_hist[t];
-      uint32_t old = 0u;
-      if (c) {
-        old = atomicAdd(&bw.tile_count[(int64_t)b * ntiles + t], c);
-        // a tile that grows past one slice will be resolved in bands: tell the resolve kernel
-        // that item != tile (it then scans the tile counts for its (tile, band))
-        if (old + c > slice_records && old <= slice_records) atomicOr(&bw.ovf_count[1], 1u);
-      }
-      s_base[t] = old;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kFusedPts; ++u) {
-      const int64_t i = base + (int64_t)u * kChunkThreads + threadIdx.x;
-      if (i >= hi) continue;
-      int32_t pk = tgt[u];
-      uint32_t r = rank[u];
-      if (pk <= -2) {
-        const int slot = -2 - pk;
-        pk = s_qpk[slot];
-        r = s_qrank[slot];
-      }
-      if (DEBUG) {
-        int32_t idx = -1;
-        if (pk >= 0) {
-          const int t = pk >> 11, li = pk & (kTilePx - 1);
-          const int ty = t / tiles_x, tx = t - ty * tiles_x;
-          idx = (ty * kTileY + li / kTileX) * width + tx * kTileX + (li % kTileX);
-        }
-        ws.idx[(int64_t)b * m + i] = idx;
-        ws.z[(int64_t)b * m + i] = zz[u];
-      }
-      float f[kMaxC];
-#pragma unroll
-      for (int k = 0; k < kMaxC; ++k)
-        if (k < channels) f[k] = FeatIO<T>::load(F + i * channels + k);
-      if (pk >= 0) {
-        const int t = pk >> 11;
-        const uint32_t pos = s_base[t] + r;
-        const int64_t bt = (int64_t)b * ntiles + t;
-        uint32_t* rec;
-        if (pos < bw.cap) {
-          rec = bw.rec + (bt * bw.cap + pos) * stride;
-        } else {
-          const uint32_t o = atomicAdd(bw.ovf_count, 1u);
-          rec = bw.ovf + (int64_t)o * (stride + 1);
-          *rec++ = (uint32_t)bt;
-        }
-        rec[0] = (uint32_t)(pk & (kTilePx - 1));
-        rec[1] = __float_as_uint(zz[u]);
-#pragma unroll
-        for (int k = 0; k < kMaxC; ++k)
-          if (k < channels) rec[2 + k] = __float_as_uint(f[k]);
-      } else {
-        const float pz = zz[u];
-        if (pz == pz) {
-          const uint32_t o = se3ds_f32_to_ordered(pz);
-          sink = o < sink ? o : sink;
-        }
-#pragma unroll
-        for (int k = 0; k < kMaxC; ++k)
-          if (k < channels) {
-            const float v = f[k];
-            if (v == v) {
-              const uint32_t o = se3ds_f32_to_ordered(v);
-              smax[k] = o > smax[k] ? o : smax[k];
-            }
-          }
-      }
-    }
-    __syncthreads();   // s_hist / s_base / queue are reused by the next batch
-  }
-  __shared__ uint32_t s_sink[kChunkThreads / 64];
-  __shared__ uint32_t s_f[kMaxC][kChunkThreads / 64];
-  sink = wave_min_u32(sink);
-  if ((threadIdx.x & 63) == 0) s_sink[threadIdx.x >> 6] = sink;
-#pragma unroll
-  for (int k = 0; k < kMaxC; ++k) {
-    uint32_t v = wave_max_u32(smax[k]);
-    if ((threadIdx.x & 63) == 0) s_f[k][threadIdx.x >> 6] = v;
-  }
-  __syncthreads();
-  const int part = blockIdx.y * gridDim.x + blockIdx.x;
-  if (threadIdx.x == 0) {
-    uint32_t v = s_sink[0];
-    for (int i = 1; i < kChunkThreads / 64; ++i) v = s_sink[i] < v ? s_sink[i] : v;
-    ws.zpart[part] = v;
-  }
-  if ((int)threadIdx.x < channels) {
-    uint32_t v = 0u;
-    for (int i = 0; i < kChunkThreads / 64; ++i)
-      v = s_f[threadIdx.x][i] > v ? s_f[threadIdx.x][i] : v;
-    ws.fpart[(int64_t)part * channels + threadIdx.x] = v;
-  }
 }
 
 // B1: per tile, exclusive prefix of the chunk rows (in place) and the tile total.  One workgroup
@@ -1156,16 +883,7 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
   // so bands never exchange anything.  item -> (tile, band) by a scan of the bands per tile.
   const uint32_t item = blockIdx.x;
   if (threadIdx.x == 0) s_item[0] = -1;
-  // single-pass layout without a banded tile (the usual case): item == tile, no scan needed
-  const bool direct = bw.cap != 0 && bw.ovf_count[1] == 0u;
-  if (direct) {
-    if (threadIdx.x == 0 && item < (uint32_t)nb) {
-      s_item[0] = (int)item;
-      s_item[1] = 0;
-      s_item[2] = 0;
-      s_r0 = 0u;
-    }
-  } else {
+  {
     const int per = ceil_div(nb, kResolveThreads);
     const int t0 = threadIdx.x * per, t1 = t0 + per < nb ? t0 + per : nb;
     uint32_t sum_s = 0, sum_c = 0;
@@ -1202,11 +920,9 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
   const int band = s_item[1], band_shift = 4 - s_item[2];   // rows per band = 16 >> log2(bands)
   const bool banded = s_item[2] != 0;
   const uint32_t tcount = bw.tile_count[bt];
-  // three-pass layout: records are packed tile after tile; single-pass layout: fixed-capacity bins
-  // (records beyond the capacity sit in the overflow list, tagged with their tile)
-  const uint32_t r0 = bw.cap ? (uint32_t)bt * bw.cap : s_r0;
-  const uint32_t r1 = r0 + (bw.cap && tcount > bw.cap ? bw.cap : tcount);
-  const uint32_t ovf_n = (bw.cap && tcount > bw.cap) ? *bw.ovf_count : 0u;
+  // records are packed tile after tile
+  const uint32_t r0 = s_r0;
+  const uint32_t r1 = r0 + tcount;
   const int b = bt / ntiles, t = bt - b * ntiles;
   const int ty = t / tiles_x, tx = t - ty * tiles_x;
   const uint32_t fvoid = se3ds_f32_to_ordered(output_void);
@@ -1267,10 +983,6 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
     for (int u = 0; u < kU; ++u)
       if (q0 + u * kResolveThreads < r1 && mine(li[u])) atomicMin(&s_z[li[u]], zb[u]);   // valid => z > 0
   }
-  for (uint32_t q = threadIdx.x; q < ovf_n; q += kResolveThreads) {
-    const uint32_t* r = bw.ovf + (int64_t)q * (stride + 1);
-    if (r[0] == (uint32_t)bt && mine(r[1])) atomicMin(&s_z[r[1]], r[2]);
-  }
   __syncthreads();
   constexpr int kMaxC = kMaxBinChannels;
   uint32_t smax[kMaxC];
@@ -1329,24 +1041,6 @@ splat_tile_resolve_kernel(int channels, int height, int width, int ntiles, int t
             smax[k] = o > smax[k] ? o : smax[k];
           }
         }
-    }
-  }
-  for (uint32_t q = threadIdx.x; q < ovf_n; q += kResolveThreads) {
-    const uint32_t* r = bw.ovf + (int64_t)q * (stride + 1);
-    if (r[0] != (uint32_t)bt || !mine(r[1])) continue;
-    const uint32_t li = r[1];
-    const float z = __uint_as_float(r[2]);
-    float zm = __uint_as_float(s_z[li]);
-    if (first && li == 0 && have_sink_z) zm = sink_z < zm ? sink_z : zm;
-    const bool keep = z < zm + 0.1f;
-    for (int k = 0; k < channels; ++k) {
-      const float v = __uint_as_float(r[3 + k]);
-      if (keep) {
-        if (ORDERED || v > 0.0f) atomicMax(&s_fe[k * kTilePx + li], se3ds_f32_to_ordered(v));
-      } else if (v == v) {
-        const uint32_t o = se3ds_f32_to_ordered(v);
-        smax[k] = o > smax[k] ? o : smax[k];
-      }
     }
   }
   __shared__ uint32_t s_f[kMaxC][kResolveThreads / 64];
@@ -1440,30 +1134,10 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
   const uint64_t wmagic = ((uint64_t)1 << 40) / (uint64_t)width + 1;
   const dim3 g_pt((unsigned)cg.chunks, (unsigned)n);
   const int nparts = cg.chunks * n;
-  // Default: the three-pass version (count, column scan, scatter).  SE3DS_SPLAT_FUSED=8 | 16
-  // selects the single-pass binning kernel with that many points per thread and batch -- measured
-  // (profiles/r02_warp_*): equal on a random depth map (151 us per render either way: the kernel
-  // moves 16 B per point less but is bound by its phase barriers and the reservation atomics'
-  // latency), slower on a smooth one (hot tile cursors, overflow list), so it is not the default.
-  // SE3DS_SPLAT_DEBUG=1: the single-pass kernel also writes the (idx, z) parity tap.
-  const char* e_fused = getenv("SE3DS_SPLAT_FUSED");
-  const bool fused = e_fused && atoi(e_fused) > 0 &&
-                     (uint64_t)nb * fused_cap(n, m, (size_t)nb) < ((uint64_t)1 << 32);
-  if (fused) {
-    bw = carve_fused_ws((char*)workspace + align16(base), n, m, height, width, channels);
-    if (hipMemsetAsync(bw.tile_count, 0, 4 * ((size_t)nb + 4), stream) != hipSuccess)
-      return SE3DS_E_LAUNCH;
-    const char* e_dbg = getenv("SE3DS_SPLAT_DEBUG");
-    const bool dbg = e_dbg && atoi(e_dbg) != 0;
-    const int pts = atoi(e_fused);   // points per thread and batch: 8 or 16
-#define SE3DS_FUSED(DBG, PTS)                                                                    \
-  hipLaunchKernelGGL((splat_bin_fused_kernel<T, EQUIRECT, DBG, PTS>), g_pt, dim3(kChunkThreads), \
-                     8 * ntiles, stream, coords, offset, feats, m, ld, cg.per, channels, height, \
-                     width, wmagic, input_void, ntiles, tiles_x, slice_records(), ws, bw)
-    if (pts == 16) { if (dbg) SE3DS_FUSED(true, 16); else SE3DS_FUSED(false, 16); }
-    else { if (dbg) SE3DS_FUSED(true, 8); else SE3DS_FUSED(false, 8); }
-#undef SE3DS_FUSED
-  } else {
+  // three passes: count, column scan, scatter.  (Round 2's single-pass binning kernel --
+  // splat_bin_fused_kernel, SE3DS_SPLAT_FUSED: count, reservation and scatter in one launch, equal on
+  // a random depth map and slower on a smooth one, DESIGN.md section 3.3 -- left the library in round 5.)
+  {
     hipLaunchKernelGGL((splat_bin_count_kernel<T, EQUIRECT>), g_pt, dim3(kChunkThreads), 4 * ntiles,
                        stream, coords, offset, feats, m, ld, cg.per, channels, height, width, wmagic,
                        input_void, ntiles, tiles_x, ws, bw);
@@ -3783,10 +3457,9 @@ size_t se3ds_splat_workspace_bytes(int n, int64_t m, int height, int width, int 
                       (sizeof(int32_t) + sizeof(float)) * (size_t)n * (size_t)(m > 0 ? m : 0);
   const int c = channels > 0 ? channels : 1;
   const size_t three_pass = bin_ws_bytes(n, m, height, width, c);
-  const size_t single_pass = fused_ws_bytes(n, m, height, width, c);
   const size_t packed = pack_ws_bytes(n, m, height, width);
   const size_t sorted = sort_ws_bytes(n, m, height, width);
-  size_t bins = three_pass > single_pass ? three_pass : single_pass;
+  size_t bins = three_pass;
   if (packed > bins) bins = packed;
   if (sorted > bins) bins = sorted;
   return align16(base) + bins + 16;

@@ -1012,6 +1012,7 @@ def _wgrad(ctx, layer, args, wsz):
   if ws is None or ws.numel() < wsz:
     ws = torch.empty((int(wsz),), dtype=torch.uint8, device=ctx.device)
     layer._wgrad_slab = ws
+    _RED_TABLES.clear()   # (tables are keyed by slab pointers: the old ones can never match again)
   row = (_lib.c_i64 * 5)()
   _chk(L.se3ds_conv2d_wgrad_partial(*args, ws.data_ptr(), ws.numel(), row, _lib.stream()),
        'se3ds_conv2d_wgrad_partial')
@@ -1048,6 +1049,8 @@ def _reduce_rows(ctx, rows):
       tab.append([part, splits, n4, dst, first])
       first += (n4 + tile - 1) // tile
     ent = (torch.tensor(tab, dtype=torch.int64, device=ctx.device), first)
+    if len(_RED_TABLES) >= 256:   # (varying shapes / batch sizes: bounded, rebuilt on demand)
+      _RED_TABLES.clear()
     _RED_TABLES[key] = ent
   # (the bench's instrumented step charges the batched reduce to the weight gradients, as it
   # charges every immediate reduce inside the timed se3ds_conv2d_wgrad call)
@@ -1272,7 +1275,8 @@ def conv_transpose2d(ctx: Ctx, x: Var, layer: ConvLayer):
   y = ctx.empty((n, H, W, layer.cout))
   bias = layer.bias
   flops = 2.0 * n * hi * wi * cin_t * layer.cout * k * k
-  with _Timed('convT_fwd', flops):
+  tag = f'convT {k}x{k}s2 {cin_t}->{layer.cout} @{hi}x{wi}->{H}x{W} n{n}'
+  with _Timed('convT_fwd', flops, tag):
     _chk(L.se3ds_conv2d_dgrad(xd.data_ptr(), wn.data_ptr(), y.data_ptr(), ctx.code, n, H, W,
                               layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None,
                               _lib.ptr(bias), None, ACT_NONE, 0.0, _lib.stream()),
@@ -1291,12 +1295,12 @@ def conv_transpose2d(ctx: Ctx, x: Var, layer: ConvLayer):
                   out=st.grad_views[layer.name + '/bias'])
         wsz = L.se3ds_conv2d_wgrad_workspace_bytes(n, hi, wi, layer.cout, cin_t, k, k)
         gk = st.grad_views[layer.name + '/kernel']
-        with _Timed('convT_wgrad', flops):
+        with _Timed('convT_wgrad', flops, tag):
           _wgrad(ctx, layer, (dy.data_ptr(), xd.data_ptr(), gk.data_ptr(), ctx.code, n, H, W,
                               layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, 0, None), wsz)
       if x.requires_grad:
         dx = ctx.empty(xd.shape)
-        with _Timed('convT_dgrad', flops):
+        with _Timed('convT_dgrad', flops, tag):
           _chk(L.se3ds_conv2d_fwd(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), ctx.code, n, H, W,
                                   layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, 0, None, None,
                                   None, None, ACT_NONE, 0.0, _lib.stream()), 'se3ds_conv2d_fwd')
@@ -1492,8 +1496,9 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
               sink[1].data_ptr() if use_rows else None, sink[0].data_ptr() if use_rows else None,
               _lib.ptr(colpart), cws.data_ptr(), cws.numel(), _lib.stream()), 'se3ds_norm_bwd_cg')
           if _NORM_DEBUG is not None:
-            k = ('cg-rows' if use_rows else 'cg', tuple(xd.shape), layer.kind)
-            _NORM_DEBUG[k] = _NORM_DEBUG.get(k, 0) + 1
+            for k in (('cg', tuple(xd.shape), layer.kind),) + (
+                (('fused-rows', tuple(xd.shape), layer.kind),) if use_rows else ()):
+              _NORM_DEBUG[k] = _NORM_DEBUG.get(k, 0) + 1
           if use_rows:
             reduce_or_defer(ctx, (colpart.data_ptr(), nrows, c // 4,
                                   sink[2].grad_views[sink[3]].data_ptr()))

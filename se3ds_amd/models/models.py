@@ -146,6 +146,7 @@ class SE3DSModel(object):
   def write_memory_as_pointcloud(self, filename):
     """Writes memory at batch position 0 to an ASCII .ply file (reference :154-178)."""
     state = self.get_memory_state()
+    point_cloud_utils.check_promise(state.rgb_coords.device)   # (a host synchronisation anyway)
     xyz = state.rgb_coords[0, 0:3].cpu().numpy().T
     rgb = state.rgb[0].cpu().numpy()
     with open(filename, 'w') as fp:
@@ -239,6 +240,8 @@ class SE3DSModel(object):
       self.prev_rgb_frame = generated_pred_rgb
       self.add_to_memory(pred_rgb_mem, pred_semantic_mem[..., None], pred_depth_mem, position)
     pred_rgb = _quantize(pred_rgb, torch.uint8, lo=0, hi=255)   # in [0, 255] already: a cast
+    # (byte-range promise of the packed splats above: poll without waiting)
+    point_cloud_utils.check_promise(pred_rgb.device, wait=False)
     return OutputData(proj_semantic=proj_semantic, pred_semantic=pred_semantic,
                       proj_rgb=_quantize(proj_rgb, torch.uint8, mul=255.0, lo=0, hi=255),
                       pred_rgb=pred_rgb,

@@ -13,6 +13,7 @@ from se3ds_amd import _lib
 from se3ds_amd import constants
 from se3ds_amd.models.models import _quantize
 from se3ds_amd.utils import pano_utils
+from se3ds_amd.utils import point_cloud_utils
 from se3ds_amd.utils.point_cloud_utils import PointCloudMemory
 
 
@@ -102,4 +103,5 @@ def generated_rollout(generator_fn: Callable, inputs: Dict[str, torch.Tensor], e
     out.projected.append(pred_rgb)
     out.proj_mask.append(pred_mask[..., None])
     out.proj_depth.append(pred_depth[..., None])
+  point_cloud_utils.check_promise(memory.device)   # (the roll-out's results are read next)
   return out

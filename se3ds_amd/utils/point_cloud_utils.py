@@ -64,10 +64,13 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 FEAT_BYTE_RANGE = 0x100   # include/se3ds_hip.h SE3DS_FEAT_BYTE_RANGE
 # A broken byte-range promise makes the packed splat pack f & 255: silently wrong features.  The
-# kernels raise a sticky flag in the workspace; it is read back ASYNCHRONOUSLY every
-# _PROMISE_POLL_EVERY-th promised splat (a 1-thread kernel + a 4-byte copy into pinned memory,
-# examined at a later call without waiting), so a violation is reported a few calls late but never
-# missed.  SE3DS_CHECK_PROMISE=1: checked synchronously after every promised splat (debugging).
+# kernels raise a sticky flag in the workspace; it is read back ASYNCHRONOUSLY after the FIRST
+# promised splat of a process and after every _PROMISE_POLL_EVERY-th (a 1-thread kernel + a 4-byte
+# copy into pinned memory, examined at a later call without waiting).  Between polls a violation is
+# only PENDING: check_promise(device) forces the read-back and raises -- the library's own sync
+# points call it (SE3DSModel.__call__ on return, write_memory_as_pointcloud, generated_rollout's
+# end) and an atexit hook reports a violation nobody polled for.  SE3DS_CHECK_PROMISE=1: checked
+# synchronously after every promised splat (debugging).
 _PROMISE_POLL_EVERY = 64
 _CHECK_PROMISE_SYNC = os.environ.get('SE3DS_CHECK_PROMISE') == '1'
 _promise_state = {}   # device -> dict(calls, pending=[(event, pinned flag)])
@@ -78,8 +81,9 @@ class PromiseBroken(RuntimeError):
   SE3DS_FEAT_BYTE_RANGE: the features it rendered are wrong."""
 
 
-def _poll_promise(device, force=False):
-  """Bookkeeping of the sticky flag (see above).  force: launch the read-back now and wait."""
+def _poll_promise(device, force=False, launch=False):
+  """Bookkeeping of the sticky flag (see above).  force: launch the read-back now and wait;
+  launch: launch it now, examine it at a later call."""
   key = str(device)
   st = _promise_state.setdefault(key, dict(calls=0, pending=[]))
   ws = _workspaces.get(key)
@@ -99,7 +103,8 @@ def _poll_promise(device, force=False):
   if ws is None:
     return
   st['calls'] += 1
-  if force or _CHECK_PROMISE_SYNC or st['calls'] % _PROMISE_POLL_EVERY == 0:
+  if (force or launch or _CHECK_PROMISE_SYNC or st['calls'] == 1 or
+      st['calls'] % _PROMISE_POLL_EVERY == 0):
     dflag = torch.empty(1, dtype=torch.int32, device=ws.device)
     _lib.check(_lib.lib().se3ds_splat_promise_sticky(_lib.ptr(ws), _lib.ptr(dflag), 1, _lib.stream()),
                'se3ds_splat_promise_sticky')
@@ -110,6 +115,35 @@ def _poll_promise(device, force=False):
     st['pending'].append((ev, hflag))
     if force or _CHECK_PROMISE_SYNC:
       _poll_promise_wait(st)
+
+
+def check_promise(device=None, wait=True):
+  """Poll of the sticky byte-range flag on `device` (default: every device that has a splat
+  workspace): launches the read-back (one 1-thread kernel + a 4-byte copy) and, with wait=True,
+  WAITS for it and raises PromiseBroken if an int32 feature outside [0, 255] reached a promised
+  splat since the last check; wait=False examines the read-backs that have completed and leaves the
+  new one for the next call (no host synchronisation: SE3DSModel.__call__ does this on every
+  return, so a short inference trajectory that never reaches the 64th promised splat is covered
+  one call late at most, and by the atexit hook for its last call)."""
+  keys = [str(device)] if device is not None else list(_workspaces)
+  for key in keys:
+    if key in _workspaces:
+      _poll_promise(_workspaces[key].device, force=wait, launch=not wait)
+
+
+def _check_promise_at_exit():
+  try:
+    if torch.cuda.is_available():
+      check_promise()
+  except PromiseBroken as e:   # (an exception out of atexit is only printed: say it clearly)
+    import sys
+    sys.stderr.write(f'se3ds_amd: {e}\n')
+  except Exception:   # noqa: BLE001  (interpreter teardown: the runtime may be gone)
+    pass
+
+
+import atexit   # noqa: E402
+atexit.register(_check_promise_at_exit)
 
 
 def _poll_promise_wait(st):

@@ -140,6 +140,21 @@ def _judge_against_fp64(tag, direct_ok, pairs, bad_hip, bad_orc):
   assert len(bad_hip) <= 2 * len(bad_orc) + 0.02 * (len(pairs) + direct_ok), (tag, len(bad_hip), len(bad_orc))
 
 
+# bf16 whole-arena gradient gates of test_cfg1_lowres_train_g_d_fp32_and_bf16 (measured values in
+# the test's printout; set in round 5 from runs on MI355X with ~2x margin)
+# measured (round 5, MI355X): G cosine 0.793 / ||diff|| / ||ref|| 0.645 = 32 x max(o32, 0.02) with the
+# fp32 oracle 0.0055 from fp64; D cosine 0.964 / 0.267 = 13 x (fp32 oracle 0.0009 from fp64).
+# Round 2 measured the same cosines (0.79 / 0.96): the figures are stable properties of the arithmetic.
+BF16_CFG1_COS_MIN = {'g': 0.65, 'd': 0.90}
+BF16_CFG1_K_REL = {'g': 50.0, 'd': 25.0}
+# ... and of test_cfg1_generator_gradients_vs_fp64_yardstick (moving statistics, random init, 200+
+# layers): measured whole-arena cosine 0.346, per-tensor cosine median 0.410 (10th percentile 0.295)
+# over 888 tensors -- what 8 mantissa bits leave of that gradient ("chaotic
+# amplification"); a sign or scale error in any bf16 backward kernel drives them to ~0
+BF16_YARD_COS_MIN = 0.20
+BF16_YARD_MEDIAN_TENSOR_COS_MIN = 0.25
+
+
 def _grad_view(store, arena, name):
   o, n, shape = store._off_tr[name]
   return arena[o:o + n].view(shape)
@@ -183,6 +198,7 @@ def test_cfg1_lowres_train_g_d_fp32_and_bf16():
     print(f'cfg1 oracle fp64: {time.time() - t0:.1f} s')
   finally:
     torch.set_default_dtype(torch.float32)
+  arena_dist = {}
   for tag, model, key in (('g', gan.generator, 'g_grads'), ('d', gan.discriminator, 'd_grads')):
     st = model.store
     assert set(ref[key]) == set(st.trainable_names)
@@ -207,6 +223,15 @@ def test_cfg1_lowres_train_g_d_fp32_and_bf16():
       if e_o32 > 5.0 * e_hip + 1e-3:
         bad_orc.append(name)
     _judge_against_fp64(f'cfg1 fp32 {tag}', direct_ok, pairs, bad_hip, bad_orc)
+    # whole-arena distances against the fp64 run: the yardstick of the bf16 gate below
+    a64 = torch.cat([ref64[key][nm].reshape(-1).double() for nm in st.trainable_names])
+    a32 = torch.cat([ref[key][nm].reshape(-1).double() for nm in st.trainable_names])
+    ah = torch.cat([_grad_view(st, cap[tag + '_grad'], nm).reshape(-1).double() for nm in st.trainable_names])
+    arena_dist[tag] = dict(o32=float((a32 - a64).norm() / a64.norm()), hip32=float((ah - a64).norm() / a64.norm()),
+                           cos_o32=float((a32 @ a64) / (a32.norm() * a64.norm())))
+    print(f'cfg1 {tag}: ||g - g64|| / ||g64||: fp32 oracle {arena_dist[tag]["o32"]:.4f}, HIP fp32 '
+          f'{arena_dist[tag]["hip32"]:.4f}; cosine(fp32 oracle, fp64) {arena_dist[tag]["cos_o32"]:.4f}')
+    del a64, a32, ah
 
   # ---- Adam at t = 1 on ALL parameters (Keras form, gan_manager.py:175-183)
   for tag, opt, lr in (('g', gan.g_optimizer, gan.g_lr), ('d', gan.d_optimizer, gan.d_lr)):
@@ -267,12 +292,20 @@ def test_cfg1_lowres_train_g_d_fp32_and_bf16():
       b[o:o + cnt] = ref[key][name].reshape(-1).double()
     cos = float((a @ b) / (a.norm() * b.norm()))
     rel = float((a - b).norm() / b.norm())
-    # Reported, not gated: at random initialisation with batch statistics over 64 samples the
-    # backward pass is so ill-conditioned that fp32 itself sits 20-30 % from fp64 (above); with 8
-    # mantissa bits the direction is noise.  The bf16 kernels are gated layer by layer
-    # (tests/test_prod_shapes_gpu.py: one rounding step) and on the well-conditioned network
-    # (test_cfg1_generator_gradients_vs_fp64_yardstick).
-    print(f'cfg1 bf16 {tag}: gradient cosine vs fp32 oracle {cos:.4f}, ||diff||/||ref|| {rel:.3f}')
+    # Round 5: GATED against this test's own yardstick.  At random initialisation with batch
+    # statistics over 64 samples the backward pass is ill-conditioned: the fp32 oracle's whole-arena
+    # gradient sits `o32` from an fp64 run of itself (printed above).  bf16 rounds every activation
+    # to 8 mantissa bits (2^-9 relative against fp32's 2^-24), so its distance from the fp32
+    # oracle may exceed that fp32 noise floor by a bounded factor, and the direction must hold:
+    #   ||g_bf16 - g_o32|| / ||g_o32||  <=  K_REL x max(o32, 0.02)      cosine >= COS_MIN
+    # (measured round 5 on MI355X: see the printed line; K_REL and COS_MIN leave ~2x margin).  The
+    # bf16 kernels are additionally gated layer by layer (tests/test_prod_shapes_gpu.py), block by
+    # block (tests/test_blocks_gpu.py) and as a training signal (the trajectory test below).
+    o32 = arena_dist[tag]['o32']
+    print(f'cfg1 bf16 {tag}: gradient cosine vs fp32 oracle {cos:.4f}, ||diff||/||ref|| {rel:.3f} '
+          f'= {rel / max(o32, 0.02):.1f} x the fp32 oracle\'s distance from fp64 ({o32:.4f})')
+    assert cos >= BF16_CFG1_COS_MIN[tag], (tag, cos)
+    assert rel <= BF16_CFG1_K_REL[tag] * max(o32, 0.02), (tag, rel, o32)
     assert bool(torch.isfinite(cap16[tag + '_grad']).all())
   assert bool(torch.isfinite(gan.generator.store.theta).all())
 
@@ -365,9 +398,21 @@ def test_cfg1_generator_gradients_vs_fp64_yardstick():
     o, cnt, _ = Gb.store._off_tr[k]
     bref[o:o + cnt] = g32[k].reshape(-1).double()
   cos = float((a @ bref) / (a.norm() * bref.norm()))
+  # per-tensor cosines (tensors whose reference gradient is numerically zero are skipped)
+  tcos = []
+  for k in names:
+    o, cnt, _ = Gb.store._off_tr[k]
+    x, y = a[o:o + cnt], bref[o:o + cnt]
+    if float(y.norm()) > 1e-6 * float(bref.norm()) / max(len(names), 1) ** 0.5:
+      tcos.append(float((x @ y) / (x.norm() * y.norm() + 1e-300)))
+  tmed, t10 = float(np.median(tcos)), float(np.percentile(tcos, 10))
   print(f'bf16 path: gradient cosine vs fp32 oracle {cos:.4f}, ||diff||/||ref|| '
-        f'{float((a - bref).norm() / bref.norm()):.3f}; rgb max err {rel_err(outs[6].cpu().numpy(), outs_o[6].detach().numpy()):.2e}')
-  assert cos > 0.0, cos   # reported (what 8 mantissa bits leave of a 200-layer gradient)
+        f'{float((a - bref).norm() / bref.norm()):.3f}; per-tensor cosine median {tmed:.4f}, 10th percentile '
+        f'{t10:.4f} over {len(tcos)} tensors; rgb max err {rel_err(outs[6].cpu().numpy(), outs_o[6].detach().numpy()):.2e}')
+  # Round 5: gated (was `cos > 0`): the measured values minus a margin -- what 8 mantissa bits leave
+  # of a 200-layer gradient on the well-conditioned (moving-statistics) network
+  assert cos >= BF16_YARD_COS_MIN, cos
+  assert tmed >= BF16_YARD_MEDIAN_TENSOR_COS_MIN, tmed
 
 
 def test_cfg1_bf16_training_trajectory_tracks_fp32():

@@ -98,6 +98,11 @@ def test_bench_gpus_2_launches_two_ranks_on_one_gpu():
                     '--warmup', '1', '--no-cpu-baseline'], dict(SE3DS_BENCH_BACKEND='gloo'))
   assert out['n_gpus'] == 2 and out['steps'] == 3 and out['value'] > 0
   assert out['scaling'] == 'weak' and out['config']['workload'].startswith('warp')
+  # the pre-flight block of a multi-rank run: both ranks seen, the all-reduce really summed
+  # (ones all-reduced 1 + 5 times over 2 ranks = 64), bandwidth / latency figures present
+  pre = out['collectives']
+  assert pre['rccl_ranks_seen'] == [0, 1] and pre['sum_check'] == 64.0, pre
+  assert pre['allreduce_big_busbw_GBs'] > 0 and pre['allreduce_syncbn_2x1024_us'] > 0, pre
 
 
 def test_bench_gan_step_two_gloo_ranks_on_one_gpu():

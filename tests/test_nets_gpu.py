@@ -136,18 +136,6 @@ def test_conv_lds_dma_kernels_mfma_32x32x16(case, big, monkeypatch):
   _run_conv_case(case, torch.bfloat16)
 
 
-@pytest.mark.parametrize('stages', ['0', '3', '4'])
-@pytest.mark.parametrize('case', [c for c in BIG_TILE_CASES if c[2] == 128 and c[3] == 3 and c[4] == 1])
-def test_conv_halo_128_channel_variants(case, stages, monkeypatch):
-  """The 128-output-channel halo layers: 4-wave workgroups with 32-channel K steps and three / four
-  weight stages (round 4, opt-in: faster alone, slower inside the power-limited step) and the
-  default 8-wave kernel (stages=0)."""
-  monkeypatch.setenv('SE3DS_BIG_TILE', '1')
-  monkeypatch.setenv('SE3DS_HALO_TILE', '1')
-  monkeypatch.setenv('SE3DS_HALO_4W', stages)
-  _run_conv_case(case, torch.bfloat16)
-
-
 @pytest.mark.parametrize('case', [c for c in BIG_TILE_CASES if c[2] % 128 == 0 and c[3] == 3 and c[4] == 1] + [
     ('partial_spectral', 128, 256, 3, 1, 'VALID', 1, False, True, True, 2, 24, 40),   # gather mask, ragged tiles
     ('plain', 256, 512, 3, 1, 'VALID', 1, True, False, False, 1, 16, 64),            # circular width, 2 channel tiles
@@ -160,7 +148,6 @@ def test_conv_halo_mfma_shapes(case, m16, monkeypatch):
   monkeypatch.setenv('SE3DS_BIG_TILE', '1')
   monkeypatch.setenv('SE3DS_HALO_TILE', '1')
   monkeypatch.setenv('SE3DS_HALO_M16', m16)
-  monkeypatch.setenv('SE3DS_HALO_4W', '0')
   _run_conv_case(case, torch.bfloat16)
 
 

@@ -151,7 +151,7 @@ def test_unproject_errors():
 
 @pytest.mark.parametrize('n,h,views', [(1, 16, 1), (2, 32, 2), (1, 128, 2), (1, 256, 1)])
 def test_project_equirect_bit_exact(n, h, views, monkeypatch):
-  monkeypatch.setenv('SE3DS_SPLAT_DEBUG', '1')   # (the opt-in single-pass binning kernel writes the (idx, z) tap on request)
+  monkeypatch.setenv('SE3DS_SPLAT_DEBUG', '1')   # (the packed / sorted kernels write the (idx, z) parity tap on request)
   rng = np.random.default_rng(11 + h)
   w = 2 * h
   coords, feats = [], []
@@ -379,20 +379,17 @@ _SORT = dict(SE3DS_SPLAT_SORT='2')    # round 4: sorted chunks + gathering resol
 @pytest.mark.parametrize('env_extra', [
     dict(SE3DS_SPLAT_SLICE='48'),                          # packed records, every tile banded
     dict(_OLD, SE3DS_SPLAT_SLICE='48'),                    # three-pass, 20-byte records, every tile banded
-    dict(_OLD, SE3DS_SPLAT_FUSED='16'),                    # single-pass binning kernel, 16 points / thread
-    dict(_OLD, SE3DS_SPLAT_FUSED='8', SE3DS_SPLAT_CAP='64', SE3DS_SPLAT_SLICE='48'),   # overflow + bands
     dict(_SORT),                                           # sorted chunks (16 points / thread) + gathering resolve
     dict(_SORT, SE3DS_SPLAT_PTS='8'),                      # ... 8 points / thread (4096-point chunks)
-], ids=['packed-banded', 'three-pass-banded', 'single-pass', 'single-pass-overflow-banded', 'sorted',
-        'sorted-8pt'])
+], ids=['packed-banded', 'three-pass-banded', 'sorted', 'sorted-8pt'])
 def test_splat_banded_tiles_bit_exact(env_extra):
   """The splat parity tests re-run in a child process under switches that are read once per
   process: tiny slices (every tile of the small parity images is cut into bands of rows, in the
   packed and in the 20-byte-record resolve kernels), the 20-byte-record three-pass path that the
   8-byte packed path replaced as the default (SE3DS_SPLAT_PACKED=0; still what float features
-  and more than 3 channels take), and the opt-in single-pass binning kernel (SE3DS_SPLAT_FUSED)
-  with tiny bin capacities (records spill into its overflow list); and the round-4 sorted-chunk
-  path (SE3DS_SPLAT_SORT=2 takes it on images of any size) in its template variants."""
+  and more than 3 channels take); and the round-4 sorted-chunk path (SE3DS_SPLAT_SORT=2 takes it on
+  images of any size) in its template variants.  (Round 2's opt-in single-pass binning kernel left
+  the library in round 5.)"""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -482,6 +479,22 @@ def test_packed_splat_variants_and_byte_range_promise():
   import se3ds_amd.hipops  # noqa: F401  (registers se3ds_fill's signature)
   assert L.se3ds_fill(good.data_ptr() + 4 * 40, _lib.F32, 1, 3.0e9, _lib.stream()) == 0
   assert point_cloud_utils.byte_range(good, -1)   # the stale cached verdict
+  # a FORCED poll (check_promise: the sync points of SE3DSModel / the roll-out, atexit) reports the
+  # violation of a single promised splat -- a short trajectory never reaches the 64th
+  try:
+    point_cloud_utils.check_promise(dev())   # (drains whatever earlier tests left pending)
+  except point_cloud_utils.PromiseBroken:
+    pass
+  pano_utils.project_feats_to_equirectangular(good, t(xyz_np), h, w, -1, DEPTH_SCALE)
+  with pytest.raises(point_cloud_utils.PromiseBroken):
+    point_cloud_utils.check_promise(dev())
+  point_cloud_utils.check_promise(dev())   # (the flag was cleared by the read that raised)
+  # ... and the non-blocking form raises one call late at most
+  pano_utils.project_feats_to_equirectangular(good, t(xyz_np), h, w, -1, DEPTH_SCALE)
+  with pytest.raises(point_cloud_utils.PromiseBroken):
+    for _ in range(3):
+      point_cloud_utils.check_promise(dev(), wait=False)
+      torch.cuda.synchronize()
   old_every, point_cloud_utils._PROMISE_POLL_EVERY = point_cloud_utils._PROMISE_POLL_EVERY, 1
   try:
     with pytest.raises(point_cloud_utils.PromiseBroken):
