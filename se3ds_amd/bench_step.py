@@ -139,6 +139,15 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
           'gen/gen_gan_loss', 'dis/disc_loss', 'gen/depth_loss', 'gen/wc_loss')},
       'hbm_gib_peak': torch.cuda.max_memory_allocated(dev) / 2**30,
   }
+  if world > 1:
+    # one more step with the collective log on: what a rank sends per step (the scaling curve's
+    # explanation: ~390 latency-bound SyncBN sums + 4.46 GB of gradient buckets per step)
+    from se3ds_amd.trainers import dist_utils
+    dist_utils.COLLECTIVE_LOG = []
+    step()
+    torch.cuda.synchronize()
+    out['collectives_per_step'] = dist_utils.summarize_collectives(dist_utils.COLLECTIVE_LOG)
+    dist_utils.COLLECTIVE_LOG = None
   if world == 1 and not getattr(args, 'no_shipped', False):
     out['shipped_schedule'] = shipped_schedule(gan, n, h, dev, rank)
   if world == 1 and args.dtype == 'bf16' and not getattr(args, 'no_fp32', False):

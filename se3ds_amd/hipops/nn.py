@@ -27,6 +27,11 @@ def _L():
   return _lib.lib()
 
 
+def _log_collective(kind, numel):
+  from se3ds_amd.trainers import dist_utils   # (late: dist_utils does not import this module)
+  dist_utils.log_collective(kind, numel)
+
+
 def _chk(rc, what):
   _lib.check(rc, what)
 
@@ -418,6 +423,7 @@ class Ctx:
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
     a.copy_(buf[:a.numel()].view_as(a))
     b.copy_(buf[a.numel():].view_as(b))
+    _log_collective('syncbn_pair', buf.numel())
     self._after_collective()
 
   def _after_collective(self):
@@ -433,6 +439,7 @@ class Ctx:
         pair.allreduce(t, self.branch_tag)   # forward of two branches in lockstep threads
         return
       dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+      _log_collective('syncbn', t.numel())
       self._after_collective()
 
   def allreduce_then(self, t, cont):
@@ -1084,7 +1091,23 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
       _chk(L.se3ds_fill(m.data_ptr(), _lib.F32, m.numel(), 1.0, _lib.stream()), 'se3ds_fill')
     else:
       in_mask = m
-    ratio, um, ru, bu = mask_window(ctx, m, n, h, w, ho, wo, k, s, pt, pl, wrap, recording)
+    # The window sums depend on the mask and the geometry only: layers that see the SAME mask tensor
+    # with the same geometry share one launch (round 5).  In a ResNet stack the 1x1 convs pass a
+    # binary mask through unchanged (update_mask = clip(mask, 0, 1) = mask), so with the alias below
+    # conv3 of a block, the next block's conv1 and its downsample conv hit the same entry: 115 ->
+    # ~50 launches of 5 us (+ a dependent-launch boundary each) on the encoder's serial path.
+    cache = ctx.__dict__.setdefault('_mask_cache', {}) if mask is not None else None
+    key = (m.data_ptr(), tuple(m.shape), k, s, pt, pl, wrap, ho, wo, bool(recording))
+    ent = cache.get(key) if cache is not None and _MASK_CACHE else None
+    if ent is None:
+      ratio, um, ru, bu = mask_window(ctx, m, n, h, w, ho, wo, k, s, pt, pl, wrap, recording)
+      if (cache is not None and _MASK_CACHE and ctx.binary_masks and k == 1 and s == 1 and pt == 0 and
+          pl == 0):
+        um = m   # (exactly the kernel's output for a {0, 1} mask: the chain keeps ONE tensor)
+      if cache is not None:
+        cache[key] = (ratio, um, ru, bu, m)   # (m: keeps the keyed storage alive)
+    else:
+      ratio, um, ru, bu = ent[:4]
   # SpectralConv convolves with W/(sigma+eps); PartialSpectralConv with the raw kernel.
   scale = layer.sn['sig'][1:] if layer.kind == 'spectral' else None
   bias = layer.bias
@@ -1341,6 +1364,8 @@ _FUSED_ROW_SCALE = os.environ.get('SE3DS_FUSED_ROW_SCALE', '1') != '0'
 # default: se3ds_norm_bwd_cg (two launches, the apply workgroups fold the partial rows) where the
 # shape allows (bf16, channels % 64 == 0, >= 512 channels, one replica)
 _NORM_CG = os.environ.get('SE3DS_NORM_CG', '1') != '0'
+# SE3DS_MASK_CACHE=0: every partial conv launches its own mask-window kernel
+_MASK_CACHE = os.environ.get('SE3DS_MASK_CACHE', '1') != '0'
 
 
 def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: Var = None,

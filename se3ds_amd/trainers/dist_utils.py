@@ -11,6 +11,33 @@ GRAD_BUCKET_ELEMS = 64 * 1024 * 1024   # 256 MiB fp32 per all-reduce: large mess
 DRIP_BUCKET_ELEMS = 16 * 1024 * 1024   # 64 MiB: drip-fed behind SyncBN collectives (GradSync)
 
 
+# Per-step record of the collectives a rank issues (bench.py --gpus N carries its summary on the
+# line; tests read it): None = off, else a list of (kind, elements, host time).  Kinds: 'syncbn'
+# (one [2][C] statistics sum), 'syncbn_pair' (the two decoders' k-th sums in one all-reduce),
+# 'grad_bucket' (a slice of the clipped gradient arena on the side stream), 'grad_arena'.
+COLLECTIVE_LOG = None
+
+
+def log_collective(kind, numel):
+  if COLLECTIVE_LOG is not None:
+    import time
+    COLLECTIVE_LOG.append((kind, int(numel), time.perf_counter()))
+
+
+def summarize_collectives(log):
+  """{kind: count, elements, bytes}, totals and the median host-side spacing of the SyncBN sums."""
+  out = {}
+  for kind, n, _ in log:
+    e = out.setdefault(kind, {'count': 0, 'bytes': 0})
+    e['count'] += 1
+    e['bytes'] += 4 * n
+  ts = sorted(t for k, _, t in log if k.startswith('syncbn'))
+  gaps = sorted(b - a for a, b in zip(ts, ts[1:]))
+  out['total'] = {'count': len(log), 'bytes': sum(4 * n for _, n, _ in log)}
+  out['syncbn_host_gap_us_median'] = 1e6 * gaps[len(gaps) // 2] if gaps else None
+  return out
+
+
 def world_size(group=None):
   return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
 
@@ -21,6 +48,7 @@ def allreduce_arena_sum(arena: torch.Tensor, group=None, bucket_elems: int = GRA
     return arena
   for o in range(0, arena.numel(), bucket_elems):
     dist.all_reduce(arena[o:o + bucket_elems], op=dist.ReduceOp.SUM, group=group)
+    log_collective('grad_arena', min(bucket_elems, arena.numel() - o))
   return arena
 
 
@@ -78,6 +106,7 @@ class GradSync:
       self.side.wait_event(ready)
       if world_size(self.group) > 1:
         dist.all_reduce(arena[o:o + n], op=dist.ReduceOp.SUM, group=self.group)
+        log_collective('grad_bucket', n)
 
   def reduce_range(self, arena: torch.Tensor, e0: int, e1: int):
     ready = torch.cuda.Event()

@@ -400,10 +400,11 @@ def test_cfg1_generator_gradients_vs_fp64_yardstick():
   cos = float((a @ bref) / (a.norm() * bref.norm()))
   # per-tensor cosines (tensors whose reference gradient is numerically zero are skipped)
   tcos = []
+  floor = 1e-6 * float(bref.norm()) / max(len(names), 1) ** 0.5
   for k in names:
     o, cnt, _ = Gb.store._off_tr[k]
     x, y = a[o:o + cnt], bref[o:o + cnt]
-    if float(y.norm()) > 1e-6 * float(bref.norm()) / max(len(names), 1) ** 0.5:
+    if float(y.norm()) > floor:
       tcos.append(float((x @ y) / (x.norm() * y.norm() + 1e-300)))
   tmed, t10 = float(np.median(tcos)), float(np.percentile(tcos, 10))
   print(f'bf16 path: gradient cosine vs fp32 oracle {cos:.4f}, ||diff||/||ref|| '

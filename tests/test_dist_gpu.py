@@ -115,6 +115,15 @@ def test_bench_gan_step_two_gloo_ranks_on_one_gpu():
                    dict(SE3DS_BENCH_BACKEND='gloo'), timeout=900)
   assert out['n_gpus'] == 2 and out['config']['global_batch'] == 2 and out['backend'] == 'gloo'
   assert all(v == v for v in out['losses'].values()) and out['value'] > 0
+  # what one rank sends per step at the REAL model dimensions (ResNet-101, gen_dims 128): the SyncBN
+  # sums of the encoder / context one by one, the two decoders' in pairs, and the whole clipped
+  # gradient arena (1.114 B generator + 30.5 M discriminator parameters, fp32) in buckets
+  cps = out['collectives_per_step']
+  print('collectives per step:', cps)
+  n_sync = cps.get('syncbn', {'count': 0})['count'] + cps.get('syncbn_pair', {'count': 0})['count']
+  assert n_sync == 2 * (279 - 84), cps
+  grad_bytes = sum(cps.get(k, {'bytes': 0})['bytes'] for k in ('grad_bucket', 'grad_arena'))
+  assert 4.4e9 < grad_bytes < 4.8e9, cps
 
 
 def test_gan_step_on_two_gpus_over_rccl():
