@@ -505,6 +505,13 @@ __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (
             vw[q] = pack2_bf16(lo, hi);
           }
         }
+#ifdef SE3DS_PROBE
+        if (p.probe == 3) {   // (timing probe: non-temporal output stores)
+          typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+          __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v),
+                                      reinterpret_cast<u32x4_t*>(out + po * p.oC + co_base + c8 * 8));
+        } else
+#endif
         *reinterpret_cast<uint4*>(out + po * p.oC + co_base + c8 * 8) = v;
         if (BNB && bnb) {
           const int64_t e0 = po * p.oC + co_base + c8 * 8;

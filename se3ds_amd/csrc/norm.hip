@@ -879,6 +879,16 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
 
 using namespace se3ds;
 
+constexpr int kCgMaxRows = 64;
+static int cg_min_c() {   // SE3DS_NORM_CG_MINC (A/B): smallest channel count that takes this path
+  static const int v = [] {
+    const char* e = getenv("SE3DS_NORM_CG_MINC");
+    const int x = e ? atoi(e) : 0;
+    return x >= 64 ? x : 512;
+  }();
+  return v;
+}
+
 extern "C" {
 
 size_t se3ds_norm_workspace_bytes(int g, int c) {
@@ -991,6 +1001,18 @@ int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const fl
   } else if (dtype == SE3DS_BF16) {
     Layout2D l = make_layout(c, 8);
     static const bool no_fast = getenv("SE3DS_NORM_BWD_GENERIC") != nullptr;
+    // SE3DS_NORM_APPLY_CG=1 (A/B): the channel-group layout of se3ds_norm_bwd_cg -- 8 lanes x 8
+    // channels = one 128-byte line per row and workgroup, 32 rows per pass -- for the forward apply
+    // too.  Measured round 5, same box: 198.2 / 197.1 ms per step with, 196.8 / 196.9 without: off.
+    static const int apply_cg = [] {
+      const char* e = getenv("SE3DS_NORM_APPLY_CG");
+      return e ? atoi(e) : 0;
+    }();
+    if (apply_cg && l.vec > 1 && (c % 64) == 0 && c >= cg_min_c()) {
+      l.cx = 8;
+      l.ry = 32;
+      l.ctiles = c / 64;
+    }
     if (l.vec > 1 && post == nullptr && act >= 0 && act <= 2 && !no_fast) {
 #define LAUNCH_FAST(A, RES)                                                                      \
   hipLaunchKernelGGL((norm_apply_fast_kernel<A, RES>), ew_grid(l, r, g), dim3(256), 0, s,        \
@@ -1108,15 +1130,6 @@ int se3ds_norm_bwd_apply_rows(const void* dy, const void* x, int dtype, int64_t 
 // channel-group layout (64 channels = one 128-byte line per row and workgroup) lets every apply
 // workgroup fold the partial rows of its own channels in a prologue.  One group, bf16, c % 64 == 0,
 // c >= kCgMinC (enough channel groups to fill the chip with <= kCgMaxRows partial rows).
-constexpr int kCgMaxRows = 64;
-static int cg_min_c() {   // SE3DS_NORM_CG_MINC (A/B): smallest channel count that takes this path
-  static const int v = [] {
-    const char* e = getenv("SE3DS_NORM_CG_MINC");
-    const int x = e ? atoi(e) : 0;
-    return x >= 64 ? x : 512;
-  }();
-  return v;
-}
 static int cg_stat_blocks(int64_t r, int c) {
   static const int total = [] {
     const char* e = getenv("SE3DS_NORM_CG_STAT_BLOCKS");

@@ -1,6 +1,7 @@
 """Where a conv kernel's time goes: the same launch with its epilogue or its K loop compiled out
 (a -DSE3DS_PROBE build of conv.hip, tools/probes/conv_phases.sh; never the shipped library).
-  SE3DS_PROBE_MODE=0 whole kernel, 1 no epilogue (prologue + K loop), 2 no K loop (prologue + epilogue)
+  SE3DS_PROBE_MODE=0 whole kernel, 1 no epilogue (prologue + K loop), 2 no K loop (prologue + epilogue),
+  3 whole kernel with non-temporal output stores
 Shapes: the 1x1 family of the encoder at batch 8 and, for scale, the dominant 3x3."""
 import os
 import sys
@@ -34,39 +35,54 @@ def timed(fn, reps=20):
   return e0.elapsed_time(e1) / reps * 1e3
 
 
+from se3ds_amd import _lib
+L = _lib.lib()
 for name, cin, cout, k, h, w, pad, kind in shapes:
   store = nn.ParamStore()
-  layer = nn.ConvLayer(store, 'c', cin, cout, k, 1, 'VALID', kind.startswith('partial'), kind)
+  partial = kind.startswith('partial')
+  layer = nn.ConvLayer(store, 'c', cin, cout, k, 1, 'VALID', partial, kind)
   store.finalize(DEV, torch.Generator(device=DEV).manual_seed(1))
   sg = nn.SpectralGroup([layer], torch.device(DEV))
   sg.power_iteration(True)
-  x = nn.Var(torch.randn((N, h, w, cin), device=DEV).to(dtype))
-  mask = (torch.rand((N, h, w), device=DEV) < 0.9).float() if kind.startswith('partial') else None
+  ctx = nn.Ctx(DEV, dtype, training=True, record=True)
+  x = torch.randn((N, h, w, cin), device=DEV).to(dtype)
+  mask = (torch.rand((N, h, w), device=DEV) < 0.9).float() if partial else None
+  wt, wn = layer.operands(ctx)
+  ho, wo = h + 2 * pad - k + 1, w + 2 * pad - k + 1
+  ratio = um = None
+  if partial:
+    ratio, um, ru, bu = nn.mask_window(ctx, mask, N, h, w, ho, wo, k, 1, pad, pad, False, True)
+  scale = layer.sn['sig'][1:] if kind == 'spectral' else None
+  y = torch.empty((N, ho, wo, cout), device=DEV, dtype=dtype)
+  dx = torch.empty_like(x)
+  dy = torch.randn((N, ho, wo, cout), device=DEV).to(dtype)
+  rows = int(L.se3ds_conv2d_fwd_stats_rows(3, N, cin, ho, wo, cout, k, k, 1, 1 if partial else 0, 1))
+  stats = torch.empty((max(rows, 1), 2, cout), device=DEV)
+  s_ = _lib.stream()
+  def fwd():   # the C entry points directly: ~3 us of host time per call, far below the kernels
+    if rows > 0:
+      L.se3ds_conv2d_fwd_stats(x.data_ptr(), wt.data_ptr(), y.data_ptr(), 3, N, h, w, cin, ho, wo, cout,
+                               k, k, 1, pad, pad, 0, _lib.ptr(mask), 1, _lib.ptr(scale), _lib.ptr(layer.bias),
+                               _lib.ptr(ratio), _lib.ptr(um if partial else None), 0, 0.0, stats.data_ptr(), s_)
+    else:
+      L.se3ds_conv2d_fwd(x.data_ptr(), wt.data_ptr(), y.data_ptr(), 3, N, h, w, cin, ho, wo, cout, k, k, 1,
+                         pad, pad, 0, _lib.ptr(mask), 1, _lib.ptr(scale), _lib.ptr(layer.bias),
+                         _lib.ptr(ratio), _lib.ptr(um if partial else None), 0, 0.0, s_)
+  def dgrad():   # (a partial conv's dy is pre-scaled: no row scale in the data gradient)
+    L.se3ds_conv2d_dgrad(dy.data_ptr(), wn.data_ptr(), dx.data_ptr(), 3, N, h, w, cin, ho, wo, cout, k, k,
+                         1, pad, pad, 0, None, _lib.ptr(scale), None, _lib.ptr(mask), 0, 0.0, s_)
+  def dgrad_acc():   # ... added into an existing gradient (the residual stream's)
+    L.se3ds_conv2d_dgrad_acc(dy.data_ptr(), wn.data_ptr(), dx.data_ptr(), 3, N, h, w, cin, ho, wo, cout, k,
+                             k, 1, pad, pad, 0, None, _lib.ptr(scale), None, _lib.ptr(mask), 0, 0.0,
+                             dx.data_ptr(), s_)
   flops = 2.0 * N * h * w * cin * cout * k * k
-  res = {}
-  for what in ('fwd', 'dgrad'):
-    for mode in ('0', '1', '2'):
-      os.environ['SE3DS_PROBE_MODE'] = '0'
-      ctx = nn.Ctx(DEV, dtype, training=True, record=True)
-      out = nn.conv2d(ctx, x, layer, pad=pad, mask=mask)
-      y = out[0] if isinstance(out, tuple) else out
-      if what == 'fwd':
-        def run():
-          c2 = nn.Ctx(DEV, dtype, training=True, record=True)
-          nn.conv2d(c2, x, layer, pad=pad, mask=mask)
-      else:
-        ctx.param_grads = False
-        g = torch.randn(y.data.shape, device=DEV).to(dtype)
-        tape = list(ctx.tape)
-        def run():
-          y.grad = g
-          x.grad = None
-          for fn, _, _ in reversed(tape):
-            fn()
+  parts = []
+  for what, fn in (('fwd', fwd), ('dgrad', dgrad), ('dgrad_acc', dgrad_acc)):
+    t = {}
+    for mode in ('0', '1', '2', '3'):
       os.environ['SE3DS_PROBE_MODE'] = mode
-      res[(what, mode)] = timed(run)
+      t[mode] = timed(fn, 50)
+    parts.append('%s: all %6.1f us (%4.0f TF/s) no-epilogue %6.1f no-K-loop %6.1f nt-stores %6.1f' % (
+        what, t['0'], flops / t['0'] / 1e6, t['1'], t['2'], t['3']))
   os.environ['SE3DS_PROBE_MODE'] = '0'
-  print('%-42s ' % name + '  '.join(
-      '%s: all %6.1f us (%4.0f TF/s)  no-epilogue %6.1f  no-K-loop %6.1f' % (
-          wh, res[(wh, '0')], flops / res[(wh, '0')] / 1e6, res[(wh, '1')], res[(wh, '2')])
-      for wh in ('fwd', 'dgrad')))
+  print('%-40s ' % name + ' | '.join(parts))

@@ -11,6 +11,7 @@
 #   prof_warp TAG [ENV=v ...]   kernel stats of the warp bench, random + room depth
 #   pmc_conv TAG "SHAPE"        MFMA-busy / FETCH / WRITE counters of tools/one_conv.py SHAPE (3 passes)
 #   pmc_warp TAG                FETCH / WRITE counters of the warp kernels (2 passes)
+#   pmc_warp_valu TAG           VALU / LDS counters of the warp kernels (1 pass) -> gpurun_out/TAG_warp_valu_pmc.json
 #   pmc_step TAG [ENV=v ...]    MFMA-busy + shader clock of every kernel inside the step (1 pass, tools/pmc_step.py)
 #   py <file.py> [args]         any python tool
 cd /tmp && export TMPDIR=/tmp
@@ -96,6 +97,14 @@ task_pmc_warp() {
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_tmp_w -o pmc -- python bench.py --workload warp --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
   python tools/pmc_summary.py gpurun_out/${tag}_warp_pmc.json --source=se3ds_amd/csrc/geom.hip "gpurun_out/pmc_tmp_f/*.db" "gpurun_out/pmc_tmp_w/*.db" 'splat|unproject'
   rm -rf gpurun_out/pmc_tmp_*
+}
+task_pmc_warp_valu() {
+  # VALU / LDS counters of the warp kernels (one pass): is the splat VALU-bound?
+  local tag=$1
+  rm -rf gpurun_out/pmc_tmp_v
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmc_tmp_v -o pmc -- python bench.py --workload warp --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+  python tools/pmc_summary.py gpurun_out/${tag}_warp_valu_pmc.json --source=se3ds_amd/csrc/geom.hip "gpurun_out/pmc_tmp_v/*.db" 'splat|unproject'
+  rm -rf gpurun_out/pmc_tmp_v
 }
 task_pmc_step() {
   local tag=$1; shift

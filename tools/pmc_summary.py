@@ -41,7 +41,27 @@ for k, d in res.items():
   if 'SQ_VALU_MFMA_BUSY_CYCLES' in d and 'GRBM_GUI_ACTIVE' in d and d['GRBM_GUI_ACTIVE']['avg'] > 0:
     # MFMA_BUSY sums over the 4 SIMDs of 256 CUs; GUI_ACTIVE is wall cycles of the dispatch
     d['mfma_util_of_1024_simds'] = d['SQ_VALU_MFMA_BUSY_CYCLES']['avg'] / (1024.0 * d['GRBM_GUI_ACTIVE']['avg'])
+  # VALU / LDS side.  On this pool rocprofv3 reports the SQ counters PER SHADER ENGINE (SQ_WAVES of a
+  # dispatch = its waves / 32): one engine = 8 CUs = 32 SIMDs.  SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES
+  # count quad-cycles, SQ_BUSY_CYCLES the engine's busy cycles of the dispatch.
+  busy = d.get('SQ_BUSY_CYCLES', {}).get('avg', 0)
+  if 'SQ_ACTIVE_INST_VALU' in d and busy > 0:
+    d['valu_busy_frac'] = 4.0 * d['SQ_ACTIVE_INST_VALU']['avg'] / (32.0 * busy)   # of the SIMDs' cycles
+  if 'SQ_INSTS_VALU' in d and 'SQ_WAVES' in d and d['SQ_WAVES']['avg'] > 0:
+    d['valu_insts_per_wave'] = d['SQ_INSTS_VALU']['avg'] / d['SQ_WAVES']['avg']
+  if 'SQ_INSTS_LDS' in d and 'SQ_WAVES' in d and d['SQ_WAVES']['avg'] > 0:
+    d['lds_insts_per_wave'] = d['SQ_INSTS_LDS']['avg'] / d['SQ_WAVES']['avg']
+  if 'SQ_LDS_IDX_ACTIVE' in d and busy > 0:
+    d['lds_active_frac'] = d['SQ_LDS_IDX_ACTIVE']['avg'] / (8.0 * busy)   # of the 8 CUs' LDS cycles
+  if 'SQ_LDS_BANK_CONFLICT' in d and 'SQ_LDS_IDX_ACTIVE' in d and d['SQ_LDS_IDX_ACTIVE']['avg'] > 0:
+    d['lds_conflict_over_active'] = d['SQ_LDS_BANK_CONFLICT']['avg'] / d['SQ_LDS_IDX_ACTIVE']['avg']
+  if 'SQ_WAVE_CYCLES' in d and 'SQ_ACTIVE_INST_VALU' in d and d['SQ_WAVE_CYCLES']['avg'] > 0:
+    # share of a wave's resident cycles in which one of its VALU instructions executes
+    d['valu_active_over_wave_cycles'] = d['SQ_ACTIVE_INST_VALU']['avg'] / d['SQ_WAVE_CYCLES']['avg']
+  if 'SQ_WAVE_CYCLES' in d and busy > 0:
+    d['waves_per_simd_resident'] = 4.0 * d['SQ_WAVE_CYCLES']['avg'] / (32.0 * busy)
 out = dict(res)
+out['kernels'] = {k: {kk: vv for kk, vv in d.items() if not isinstance(vv, dict)} for k, d in res.items()}
 if source:
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   out['_meta'] = {'source_file': source,
