@@ -193,6 +193,9 @@ def bench_warp(args, rank, world, dev):
   M = views * P
   # the point-cloud memory of the trajectory loops (eval_metric.py:144-239), preallocated
   mem = point_cloud_utils.PointCloudMemory(1, 3, torch.int32, dev, capacity=M)
+  frame = (torch.empty((1, h, w), dtype=torch.float32, device=dev),
+           torch.empty((1, h, w, 3), dtype=torch.float32, device=dev),
+           torch.empty((1, h, w), dtype=torch.float32, device=dev))
 
   def step():
     # ONE library call per trajectory step (se3ds_warp_views_to_target, round 5): every view is
@@ -204,7 +207,8 @@ def bench_warp(args, rank, world, dev):
       for rgb, depth, pos in g:
         mem.append_equirect(rgb, depth, -1, 20.0, position=pos)
       return mem.project(h, w, -1, 20.0, position=tgt, with_mask=True)
-    return mem.append_views_and_project(g, -1, 20.0, tgt, h, w, with_mask=True)
+    # (the frame buffers are reused, as a trajectory loop does)
+    return mem.append_views_and_project(g, -1, 20.0, tgt, h, w, with_mask=True, out=frame)
 
   for _ in range(args.warmup):
     step()
@@ -226,15 +230,38 @@ def bench_warp(args, rank, world, dev):
     ev1.record()
     torch.cuda.synchronize()
     return ev0.elapsed_time(ev1) / reps
-  reps = max(10, args.steps)
-  proj_ms = timed(lambda: mem.project(h, w, -1, 20.0, position=tgt, with_mask=True), reps)
+  # The kernels are timed through the C ABI with preallocated outputs (a ctypes call costs ~3-5 us of
+  # host time; the Python wrappers -- output allocation, workspace and byte-range bookkeeping -- cost
+  # 15-40 us per call, more than the 512 x 1024 kernels take, and would be what is measured).
+  from se3ds_amd import _lib as lib_mod
+  from se3ds_amd.utils import _host_tables
+  L = lib_mod.lib()
+  reps = max(20, args.steps)
+  d_o = torch.empty((1, h, w), dtype=torch.float32, device=dev)
+  f_o = torch.empty((1, h, w, 3), dtype=torch.float32, device=dev)
+  m_o = torch.empty((1, h, w), dtype=torch.float32, device=dev)
+  ws = point_cloud_utils._workspace(L.se3ds_splat_workspace_bytes(1, M, h, w, 3), dev)
+  hint = point_cloud_utils.FEAT_BYTE_RANGE if mem.byte_range else 0
+  st = lib_mod.stream()
+  def project_c():
+    lib_mod.check(L.se3ds_project_equirect_memory(
+        mem._x.data_ptr(), tgt.data_ptr(), mem._f.data_ptr(), lib_mod.I32 | hint, 1, M, mem.capacity, 3,
+        h, w, 20.0, -1.0, 0.0, d_o.data_ptr(), f_o.data_ptr(), m_o.data_ptr(), -1.0, ws.data_ptr(),
+        ws.numel(), st), 'se3ds_project_equirect_memory')
+  proj_ms = timed(project_c, reps)
   algo_bytes = 28 * M + 20 * P  # 28 B/point in, 16 B/px out + 4 B/px mask
   achieved = algo_bytes / (proj_ms * 1e-3) / 1e9
   # the other kernel of the step: one view's unproject (44 B per pixel: 4 depth + 12 features in,
   # 16 coordinates + 12 features out), into its window of the memory
   rgb0, depth0, pos0 = g[0]
-  unp_ms = timed(lambda: pano_utils.equirectangular_to_pointcloud(
-      rgb0, depth0, -1, 20.0, position=pos0, out=(mem._x, mem._f, 0)), reps)
+  tab = _host_tables.equirect_tables(h, w, dev)
+  tb = tab.data_ptr()
+  def unproject_c():
+    lib_mod.check(L.se3ds_unproject_equirect_into(
+        rgb0.data_ptr(), lib_mod.I32, depth0.data_ptr(), tb, tb + 4 * h, tb + 8 * h, tb + 8 * h + 4 * w,
+        pos0.data_ptr(), 1, h, w, 3, -1.0, 20.0, mem._x.data_ptr(), mem._f.data_ptr(), mem.capacity, 0,
+        st), 'se3ds_unproject_equirect_into')
+  unp_ms = timed(unproject_c, reps)
   unp_bytes = 44 * P
   kernels_ms = views * unp_ms + proj_ms
 

@@ -150,13 +150,14 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
     dist_utils.COLLECTIVE_LOG = None
   if world == 1 and not getattr(args, 'no_shipped', False):
     out['shipped_schedule'] = shipped_schedule(gan, n, h, dev, rank)
-  if world == 1 and args.dtype == 'bf16' and not getattr(args, 'no_fp32', False):
-    out['fp32_step'] = fp32_step(gan, h, dev, rank)
   if world == 1 and args.batch <= 0 and h == 512 and not getattr(args, 'no_batch_max', False):
     # "N = B (largest that fits; report B)".  The headline stays at the named
     # per-GPU batch 8 (= cfg4's share of global batch 64); the large-batch rate rides along.
     del batch
     out['batch_max'] = batch_max(gan, h, dev, rank)
+  if world == 1 and args.dtype == 'bf16' and not getattr(args, 'no_fp32', False):
+    # (after batch_max: the fp32 path leaves its operand copies and larger wgrad slabs allocated)
+    out['fp32_step'] = fp32_step(gan, h, dev, rank)
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out['cpu_baseline'] = cpu_baseline(args, gan, summ['flops'] / 1e12 / n)
   return out

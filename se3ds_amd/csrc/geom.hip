@@ -2022,7 +2022,8 @@ int launch_splat_packed(const float* coords, const float* offset, const T* feats
 // Traffic per cfg5 render: 100 MB in + 38 MB of records out, 38 MB in + 42 MB out = 218 MB for 159 MB
 // algorithmic (the packed path: ~310 nominal, 382 measured).  min / max do not depend on the record
 // order: bit-identical to every other path.
-constexpr int kSMaxPx = 2048;            // pixels per supertile (LDS tile of the resolve; 11-bit pixel)
+constexpr int kSMaxPx = 4096;            // pixels per supertile, upper bound (LDS tile of the resolve: 2 words per pixel)
+constexpr int kSDefaultPx = 2048;        // ... default: one full row of a 1024 x 2048 target
 constexpr int kSThreads = 512;           // S1 workgroup
 constexpr int kSQueue = 1024;            // S1: points waiting for the binary64 path (2 per thread)
 constexpr int kSMaxSuper = 2048;         // supertiles per image (S1 LDS histogram, 11-bit field)
@@ -2068,12 +2069,18 @@ inline int sort_env(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 inline SortGeom sort_geom(int64_t m, int height, int width, int pts_forced = 0) {
-  static const int pts_env = sort_env("SE3DS_SPLAT_PTS", 16) == 8 ? 8 : 16;
+  // points per thread: 16 (8192-point chunks) when that still gives the chip two workgroups per CU,
+  // else 8 (4096-point chunks) -- at 512 x 1024 with two views (1 M points) 16 left half the CUs
+  // without a chunk (S1 + S2 41 us for a quarter of the 1024 x 2048 work).  SE3DS_SPLAT_PTS forces.
+  static const int pts_forced_env = sort_env("SE3DS_SPLAT_PTS", 0);
+  const int pts_env = pts_forced_env == 8 || pts_forced_env == 16
+                          ? pts_forced_env
+                          : (ceil_div(m > 0 ? m : 1, (int64_t)kSThreads * 16) >= 512 ? 16 : 8);
   // SE3DS_SPLAT_SUPERPX (A/B): pixels per supertile, 256 .. 2048 (default 2048 = one full row of
   // a 1024 x 2048 target; smaller supertiles = more, lighter resolve workgroups)
   static const int super_px = [] {
-    const int v = sort_env("SE3DS_SPLAT_SUPERPX", kSMaxPx);
-    return v >= 256 && v <= kSMaxPx ? v : kSMaxPx;
+    const int v = sort_env("SE3DS_SPLAT_SUPERPX", kSDefaultPx);
+    return v >= 256 && v <= kSMaxPx ? v : kSDefaultPx;
   }();
   SortGeom g;
   g.pts = pts_forced ? pts_forced : pts_env;

@@ -46,6 +46,7 @@ def get_filtered_coords_and_feats(feats: torch.Tensor, depth: torch.Tensor, dept
 
 
 _workspaces = {}
+_WS_BYTES = {}   # (n, m, height, width, channels) -> se3ds_splat_workspace_bytes
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
@@ -388,11 +389,13 @@ class PointCloudMemory:
                                target: Optional[torch.Tensor], height: int, width: int,
                                with_mask: bool = False,
                                mask_void: float = constants.INVALID_RGB_VALUE,
-                               output_void_class: float = 0):
+                               output_void_class: float = 0, out=None):
     """One trajectory step in ONE library call (`se3ds_warp_views_to_target`): every view
     (feats (N,H,W[,C]), depth (N,H,W), position (N,3) or None) is appended as append_equirect does
     and the target at `target` (N,3) is rendered as project() does -- utils/eval_metric.py:153-166,
-    233-240; the launches are queued back to back instead of through four Python calls."""
+    233-240; the launches are queued back to back instead of through four Python calls.
+    out = (depth (N,H,W), feats (N,H,W,C), mask (N,H,W) or None) fp32: render into these tensors
+    instead of new ones (a trajectory loop reuses its frame buffers)."""
     if not views:
       return self.project(height, width, void_class, depth_scale, position=target,
                           with_mask=with_mask, mask_void=mask_void,
@@ -427,12 +430,26 @@ class PointCloudMemory:
     dev, n, c = self.device, self.n, self.c
     tab = _host_tables.equirect_tables(vh, vw, dev)
     base = tab.data_ptr()
-    depth_o = torch.empty((n, height, width), dtype=torch.float32, device=dev)
-    out = torch.empty((n, height, width, c), dtype=torch.float32, device=dev)
-    mask = torch.empty((n, height, width), dtype=torch.float32, device=dev) if with_mask else None
+    if out is not None:
+      depth_o, out, mask = out
+      if (tuple(depth_o.shape) != (n, height, width) or tuple(out.shape) != (n, height, width, c) or
+          depth_o.dtype != torch.float32 or out.dtype != torch.float32 or
+          not (depth_o.is_contiguous() and out.is_contiguous()) or
+          (with_mask and (mask is None or tuple(mask.shape) != (n, height, width)))):
+        raise ValueError('out = (depth (N,H,W), feats (N,H,W,C), mask (N,H,W) or None), fp32, contiguous')
+      if not with_mask:
+        mask = None
+    else:
+      depth_o = torch.empty((n, height, width), dtype=torch.float32, device=dev)
+      out = torch.empty((n, height, width, c), dtype=torch.float32, device=dev)
+      mask = torch.empty((n, height, width), dtype=torch.float32, device=dev) if with_mask else None
     L = _lib.lib()
     m_new = self.m + nv * p
-    ws = _workspace(L.se3ds_splat_workspace_bytes(n, m_new, height, width, c), dev)
+    key = (n, m_new, height, width, c)
+    nbytes = _WS_BYTES.get(key)
+    if nbytes is None:   # (a ctypes call per step otherwise; the answer only depends on the key)
+      nbytes = _WS_BYTES[key] = L.se3ds_splat_workspace_bytes(n, m_new, height, width, c)
+    ws = _workspace(nbytes, dev)
     if target is not None:
       _lib.require_cuda(target)
       target = target.to(torch.float32).contiguous()

@@ -133,6 +133,14 @@ def test_trajectory_step_in_one_call_equals_the_separate_calls(n, h, views):
   b.append_equirect(t(rgb), t(depth), -1, DEPTH_SCALE)
   d3, f3 = b.project(h, w, -1, DEPTH_SCALE, position=t(tgt))
   assert a.m == b.m and torch.equal(d2, d3) and torch.equal(f2, f3)
+  # rendering into caller-owned frame buffers (out=): the same values, the same tensors back
+  frame = (torch.empty_like(da), torch.empty_like(fa), torch.empty_like(ma))
+  c = point_cloud_utils.PointCloudMemory(n, 3, torch.int32, dev())
+  dc, fc, mc = c.append_views_and_project(g, -1, DEPTH_SCALE, t(tgt), h, w, with_mask=True, out=frame)
+  assert dc is frame[0] and fc is frame[1] and mc is frame[2]
+  assert torch.equal(dc, da) and torch.equal(fc, fa) and torch.equal(mc, ma)
+  with pytest.raises(ValueError):
+    c.append_views_and_project(g, -1, DEPTH_SCALE, t(tgt), h, w, out=(frame[0][:, :1], frame[1], None))
 
 
 def test_unproject_errors():
@@ -379,9 +387,10 @@ _SORT = dict(SE3DS_SPLAT_SORT='2')    # round 4: sorted chunks + gathering resol
 @pytest.mark.parametrize('env_extra', [
     dict(SE3DS_SPLAT_SLICE='48'),                          # packed records, every tile banded
     dict(_OLD, SE3DS_SPLAT_SLICE='48'),                    # three-pass, 20-byte records, every tile banded
-    dict(_SORT),                                           # sorted chunks (16 points / thread) + gathering resolve
+    dict(_SORT, SE3DS_SPLAT_PTS='16'),                     # sorted chunks (16 points / thread) + gathering resolve
     dict(_SORT, SE3DS_SPLAT_PTS='8'),                      # ... 8 points / thread (4096-point chunks)
-], ids=['packed-banded', 'three-pass-banded', 'sorted', 'sorted-8pt'])
+    dict(_SORT, SE3DS_SPLAT_SUPERPX='4096'),               # ... supertiles of 4096 pixels (two rows at 1024 x 2048)
+], ids=['packed-banded', 'three-pass-banded', 'sorted-16pt', 'sorted-8pt', 'sorted-4096px'])
 def test_splat_banded_tiles_bit_exact(env_extra):
   """The splat parity tests re-run in a child process under switches that are read once per
   process: tiny slices (every tile of the small parity images is cut into bands of rows, in the

@@ -40,7 +40,7 @@ task_ab() {
   for rep in 1 2; do
     for v in "SE3DS_NOP=1" "$@"; do
       echo "== $v"
-      env $v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch-max --no-warp --no-shipped 2>gpurun_out/ab.err | line || tail -5 gpurun_out/ab.err
+      env $v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch-max --no-warp --no-shipped --no-fp32 2>gpurun_out/ab.err | line || tail -5 gpurun_out/ab.err
     done
   done
 }
@@ -59,9 +59,9 @@ print('us/render %.1f frac %.4f step_ms %.4f' % (1e3*r['ms_per_launch'], r['frac
 task_prof_step() {
   local tag=$1; shift
   rm -rf gpurun_out/prof_tmp
-  local note="$* rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped   (3 warm-up + 10 timed + 2 instrumented train_g_d steps = 15 steps; model build kernels included)"
+  local note="$* rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped --no-fp32   (3 warm-up + 10 timed + 2 instrumented train_g_d steps = 15 steps; model build kernels included)"
   ( for v in "$@"; do export "$v"; done
-    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o gan -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped > gpurun_out/prof_$tag.log 2>&1 )
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o gan -- python bench.py --no-cpu-baseline --no-batch-max --no-warp --no-shipped --no-fp32 > gpurun_out/prof_$tag.log 2>&1 )
   python tools/rocpd_summary.py gpurun_out/prof_tmp/gan_results.db gpurun_out/${tag}_kernel_stats.csv "$note"
   python tools/step_trace.py gpurun_out/prof_tmp/gan_results.db gpurun_out/${tag}_per_step.csv 4 11 "$note"
   grep '^#' gpurun_out/${tag}_per_step.csv | cut -c1-200
@@ -110,7 +110,7 @@ task_pmc_step() {
   local tag=$1; shift
   rm -rf gpurun_out/pmc_tmp_s
   ( for v in "$@"; do export "$v"; done
-    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmc_tmp_s -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batch-max --no-warp --no-shipped > gpurun_out/pmc_step_$tag.log 2>&1 )
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmc_tmp_s -o pmc -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-batch-max --no-warp --no-shipped --no-fp32 > gpurun_out/pmc_step_$tag.log 2>&1 )
   tail -1 gpurun_out/pmc_step_$tag.log | cut -c1-300
   python tools/pmc_step.py "gpurun_out/pmc_tmp_s/*.db" gpurun_out/${tag}_step_pmc.json 40
   rm -rf gpurun_out/pmc_tmp_s

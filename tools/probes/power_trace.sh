@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 rocm-smi --showpower --showclocks --showmaxpower 2>&1 | grep -v "^$\|====" | head -20
 ( for v in "$@"; do export "$v"; done
-  timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-batch-max --no-warp --no-shipped > gpurun_out/power_bench.log 2>/dev/null ) &
+  timeout 600 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-batch-max --no-warp --no-shipped --no-fp32 > gpurun_out/power_bench.log 2>/dev/null ) &
 pid=$!
 : > gpurun_out/power_trace.txt
 while kill -0 $pid 2>/dev/null; do

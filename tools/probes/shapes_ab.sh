@@ -7,7 +7,7 @@ tag=$1; shift
 for rep in 1 2; do
   i=0
   for v in "$@"; do
-    env $v SE3DS_BENCH_SHAPES=all timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-batch-max --no-warp --no-shipped 2>/dev/null > gpurun_out/shapes_${tag}_${i}_${rep}.log
+    env $v SE3DS_BENCH_SHAPES=all timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-batch-max --no-warp --no-shipped --no-fp32 2>/dev/null > gpurun_out/shapes_${tag}_${i}_${rep}.log
     python - gpurun_out/shapes_${tag}_${i}_${rep}.log "$v rep$rep" <<'PY'
 import sys, json
 lines = open(sys.argv[1]).read().splitlines()
