@@ -275,6 +275,17 @@ int se3ds_conv2d_fwd(const void* x, const void* wt, void* y, int dtype, int n, i
                      const float* scale, const float* bias, const float* row_a,
                      const float* row_b, int act, float act_alpha, void* stream);
 
+/* Keras Conv2DTranspose, 2x2 kernel, stride 2 (layers.py:475-480 residual upsampling;
+ * image_models.py:440-441 final_deconv): y (n, 2 hi, 2 wi, cout) from x (n, hi, wi, cin).  `wn` is
+ * the compute-dtype copy of the kernel in its own layout (ky, kx, cout, cin) -- se3ds_weight_prep's
+ * second output for the layer.  Each output pixel sees exactly one tap, so the layer is two 1x1
+ * forward convolutions (one per output row parity) with 2 * cout "channels" (kx, co) whose results
+ * are contiguous in y: round 5 replaces the four parity-class passes of se3ds_conv2d_dgrad (K = cin:
+ * two K steps per 128 x 128 tile, 256-byte output pieces) by 256-wide tiles writing 512-byte runs.
+ * bias (cout floats) or NULL. */
+int se3ds_conv_transpose2x2_fwd(const void* x, const void* wn, void* y, int dtype, int n, int hi, int wi,
+                                int cin, int cout, const float* bias, void* stream);
+
 /* Forward conv that also emits the batch-norm statistics of its (rounded) output, so that
  * SyncBatchNormalization (models/layers.py BN after conv) needs no separate pass over y:
  * stats[row][2][cout] = per-row-block (sum, sum of squares) over the stored outputs, with

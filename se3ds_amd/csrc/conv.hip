@@ -89,6 +89,14 @@ struct IgemmParams {
   // would read back.  bn_x == nullptr: off.
   const uint16_t* bn_x; const uint8_t* bn_mask; const float* bn_mean; const float* bn_rstd;
   int bn_act; float bn_alpha;
+  // Output pixel of (image n, row a, column b) = (n * oH + a) * o_pitch + o_off + b (store_tile /
+  // store_tile16; default o_pitch = oW, o_off = 0) and bias index = channel % bias_mod (0: plain).
+  // A 2x2 stride-2 Conv2DTranspose is two 1x1 convolutions with 2 * Cout "channels" (px, co), one
+  // per output row parity py: the (px, co) pairs of input pixel (i, j) are the 2 * Cout CONTIGUOUS
+  // elements of output pixels (2i + py, 2j) and (2i + py, 2j + 1) -- virtual pixels of 2 * Cout
+  // channels with o_pitch = 2 * W and o_off = py * W (se3ds_conv_transpose2x2_fwd).
+  int64_t o_pitch, o_off;
+  int bias_mod;
 #ifdef SE3DS_PROBE
   // timing-only builds (tools/probes/conv_phases.sh; never the shipped library): 1 = return in front
   // of the epilogue, 2 = skip the K loop -- what the phases of a kernel cost on their own
@@ -184,7 +192,7 @@ __device__ __forceinline__ void store_pixel(const IgemmParams& p, f32x16_t (&acc
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float t = acc[i][j][g * 4 + e] * scale;
-        const float bv = (p.bias && co + e < p.oC) ? p.bias[co + e] : 0.0f;
+        const float bv = (p.bias && co + e < p.oC) ? p.bias[p.bias_mod ? (co + e) % p.bias_mod : co + e] : 0.0f;
         if (p.row_a) {
           if (p.bias) t = ((t - bv) * ra + bv) * rb;
           else t = t * ra;
@@ -402,7 +410,18 @@ __device__ __forceinline__ void store_wave_lds_impl(const IgemmParams& p, f32x16
 // store_wave_lds_impl<2, 32>: scratch layout, statistics and write-back are shared.
 // opix[j]: output pixel of (block j, lane % 16) or -1.
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-template <bool BNB = false>
+// HOIST (the 128 x 128 and 256-pixel macro tiles; not the halo kernels, which are at their register
+// limit): the per-pixel renormalisation factors of a partial conv (row_a / row_b, two global loads per
+// 16-pixel block) are requested for all four blocks up front -- in the loop each pair was an exposed
+// memory round trip in front of the block's arithmetic (the epilogue is ~50 % of a 1x1 layer).
+// BATCH (round 5; not the 256-channel halo kernel, which has no registers to spare): the write-back
+// of a 32-pixel pass issues ALL of its LDS reads (four 16-byte pieces + their pixel offsets), then
+// the addend loads, then the four stores.  The loop form compiled to a strictly serial chain per
+// piece -- ds_read offs, wait, branch, ds_read_b96 + ds_read_b32 (the compiler did not know the
+// 16-byte alignment), wait, store: eight exposed LDS round trips per pass, 32 per 128-channel wave
+// tile -- and the epilogue IS the kernel for the layers with few K steps (1x1, 2x2 transposed, the
+// 128-channel 3x3 layers: tools/conv_phases.py).
+template <bool BNB = false, bool HOIST = false, bool BATCH = false>
 __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (&acc)[4][4],
                                                  const int64_t (&opix)[4], int co_base, int lane,
                                                  unsigned char* scratch, float* stats_row = nullptr) {
@@ -422,9 +441,19 @@ __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (
   float4 bv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    bv[i] = p.bias ? *reinterpret_cast<const float4*>(p.bias + co_base + i * 16 + g * 4)
+    bv[i] = p.bias ? *reinterpret_cast<const float4*>(
+                         p.bias + (p.bias_mod ? (co_base + i * 16 + g * 4) % p.bias_mod : co_base + i * 16 + g * 4))
                    : make_float4(0.f, 0.f, 0.f, 0.f);
   const int form = p.row_a ? (p.bias ? 3 : 2) : (p.bias ? 1 : 0);
+  float ra4[4], rb4[4];
+  if (HOIST) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t oc = opix[j] < 0 ? 0 : opix[j];
+      ra4[j] = p.row_a ? p.row_a[oc] : 1.0f;
+      rb4[j] = p.row_b ? p.row_b[oc] : 1.0f;
+    }
+  }
   float cs1 = 0.f, cs2 = 0.f;
   const bool bnb = BNB && stats_row != nullptr && p.bn_x != nullptr;
   float bs1[8], bs2[8], bmu[8];
@@ -445,8 +474,8 @@ __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (
       const int j = J * 2 + jj;
       const int64_t o = opix[j];
       const int64_t oc = o < 0 ? 0 : o;
-      const float ra = p.row_a ? p.row_a[oc] : 1.0f;
-      const float rb = p.row_b ? p.row_b[oc] : 1.0f;
+      const float ra = HOIST ? ra4[j] : (p.row_a ? p.row_a[oc] : 1.0f);
+      const float rb = HOIST ? rb4[j] : (p.row_b ? p.row_b[oc] : 1.0f);
       const int lp = jj * 16 + c16;
       if (g == 0) offs[lp] = o;
       auto emit = [&](auto form_c) {
@@ -487,6 +516,48 @@ __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (
         cs2 += v * v;
       }
     }
+#ifdef SE3DS_PROBE
+    const bool batch_rt = p.probe != 4;   // (timing probe: 4 = the serial write-back loop)
+#else
+    constexpr bool batch_rt = true;
+#endif
+    if (BATCH && !BNB && batch_rt) {
+      constexpr int NK = PXC / PPI;   // 4
+      const int c8 = lane % LPP, pxl = lane / LPP;
+      const unsigned char* sbase =
+          static_cast<const unsigned char*>(__builtin_assume_aligned(scratch, 16));
+      int64_t po[NK];
+      uint4 vv[NK];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) po[k] = offs[k * PPI + pxl];
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const int px = k * PPI + pxl;
+        vv[k] = *reinterpret_cast<const uint4*>(sbase + px * RB + ((c8 ^ (px & 7)) << 4));
+      }
+      if (p.addend) {   // (wave-uniform)
+        uint4 av[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const int64_t pk = po[k] < 0 ? 0 : po[k];
+          av[k] = *reinterpret_cast<const uint4*>((const uint16_t*)p.addend + pk * p.oC + co_base + c8 * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          uint32_t* vw = reinterpret_cast<uint32_t*>(&vv[k]);
+          const uint32_t* aw = reinterpret_cast<const uint32_t*>(&av[k]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(vw[q] << 16) + __uint_as_float(aw[q] << 16);
+            const float hi = __uint_as_float(vw[q] & 0xffff0000u) + __uint_as_float(aw[q] & 0xffff0000u);
+            vw[q] = pack2_bf16(lo, hi);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NK; ++k)
+        if (po[k] >= 0) *reinterpret_cast<uint4*>(out + po[k] * p.oC + co_base + c8 * 8) = vv[k];
+    } else {
 #pragma unroll
     for (int k = 0; k < PXC / PPI; ++k) {
       const int px = k * PPI + lane / LPP, c8 = lane % LPP;
@@ -534,6 +605,7 @@ __device__ __forceinline__ void store_wave_lds16(const IgemmParams& p, f32x4_t (
         }
       }
     }
+    }
     __builtin_amdgcn_wave_barrier();
   }
   if (BNB && bnb) {
@@ -571,7 +643,8 @@ __device__ __forceinline__ void store_wave_lds(const IgemmParams& p, f32x16_t (&
   // vector loads up front (element-wise loads each paid a full vmcnt(0) round trip behind the
   // prefetch DMA)
   auto bias4 = [&](int cl) {
-    return p.bias ? *reinterpret_cast<const float4*>(p.bias + co_base + cl)
+    return p.bias ? *reinterpret_cast<const float4*>(
+                        p.bias + (p.bias_mod ? (co_base + cl) % p.bias_mod : co_base + cl))
                   : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   store_wave_lds_impl<NI, 32, BNB>(p, acc, opix, co_base, lane, scratch, scale, bias4, stats_row);
@@ -597,7 +670,7 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)
     int rem = (int)(m - (int64_t)n * cH * cW);
     int a = rem / cW, b = rem - a * cW;
     if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
-    opix[j] = ((int64_t)n * p.oH + a) * p.oW + b;
+    opix[j] = ((int64_t)n * p.oH + a) * p.o_pitch + p.o_off + b;
   }
   if (sizeof(T) == 2 && scratch != nullptr && (p.oC & 7) == 0 && co_base + NI * 32 <= p.oC) {
     if (NI == 4 && stats_row != nullptr) {
@@ -633,13 +706,13 @@ __device__ __forceinline__ void store_tile16(const IgemmParams& p, f32x4_t (&acc
     const int rem = (int)(m - (int64_t)n * cH * cW);
     int a = rem / cW, b = rem - a * cW;
     if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
-    opix[j] = ((int64_t)n * p.oH + a) * p.oW + b;
+    opix[j] = ((int64_t)n * p.oH + a) * p.o_pitch + p.o_off + b;
   }
-  store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[0]), opix, co_base, lane, scratch,
-                        stats_row);
+  store_wave_lds16<BNB, true, true>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[0]), opix, co_base, lane,
+                                    scratch, stats_row);
   if (CB == 8)
-    store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[CB - 4]), opix, co_base + 64, lane,
-                          scratch, stats_row);
+    store_wave_lds16<BNB, true, true>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc[CB - 4]), opix, co_base + 64,
+                                      lane, scratch, stats_row);
 }
 
 template <typename T, int MODE>
@@ -1800,8 +1873,9 @@ igemm_halo_kernel(const IgemmParams p) {
       const int y = opy0 + wn * 2 + (j >> 1), x = opx0 + (j & 1) * 16 + (lane_e & 15);
       opix16[j] = (y < p.oH && x < p.oW) ? ((int64_t)opimg * p.oH + y) * p.oW + x : -1;
     }
-    store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[0]), opix16, co_base, lane_e,
-                          scratch, stats_row);
+    // (batched write-back for the 128-channel tile: 181 VGPRs; the 256-channel tile is at 256 and spills)
+    store_wave_lds16<BNB, false, CO == 128>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[0]), opix16, co_base,
+                                            lane_e, scratch, stats_row);
     if (CO == 256)
       store_wave_lds16<BNB>(p, *reinterpret_cast<f32x4_t(*)[4][4]>(&acc16[CB16 - 4]), opix16,
                             co_base + 64, lane_e, scratch, stats_row);
@@ -4131,7 +4205,8 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
                        float* stats = nullptr, const void* addend = nullptr,
                        const void* bn_x = nullptr, const uint8_t* bn_mask = nullptr,
                        const float* bn_mean = nullptr, const float* bn_rstd = nullptr,
-                       int bn_act = 0, float bn_alpha = 0.f) {
+                       int bn_act = 0, float bn_alpha = 0.f, int64_t o_pitch = 0, int64_t o_off = 0,
+                       int bias_mod = 0) {
   if (n <= 0 || h <= 0 || wdt <= 0 || cin <= 0 || ho <= 0 || wo <= 0 || cout <= 0 || kh <= 0 ||
       kw <= 0 || stride <= 0 || stride > 2)
     return SE3DS_E_BADSHAPE;
@@ -4155,6 +4230,11 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
     p.w_tap = (int64_t)cin * cout; p.w_n = cout;    // wn [K][Cout]
   }
   p.vec = (p.sC % bk) == 0;
+  p.o_pitch = o_pitch > 0 ? o_pitch : p.oW;
+  p.o_off = o_off;
+  p.bias_mod = bias_mod;
+  // (the thin / halo kernels compute their own output pixels: the pitched form takes the generic ones)
+  const bool pitched = o_pitch > 0 || bias_mod > 0;
 #ifdef SE3DS_PROBE
   { const char* e = getenv("SE3DS_PROBE_MODE"); p.probe = e ? atoi(e) : 0; }
 #endif
@@ -4183,7 +4263,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   }
   if (mode == MODE_FWD && dtype == SE3DS_BF16 && cin <= kThinCinMax && (cout % 128) == 0 &&
       kh * kw * cin <= kThinKMax && kh <= 7 && kw <= 7 && stats == nullptr && addend == nullptr &&
-      !getenv("SE3DS_NO_THIN_CIN")) {
+      !pitched && !getenv("SE3DS_NO_THIN_CIN")) {
     const ThinCinLds L = thin_cin_lds(kh, kw, cin, stride);
     static size_t lds_set = 0;
     if (L.bytes > lds_set) {
@@ -4329,6 +4409,24 @@ int64_t se3ds_conv2d_fwd_stats_rows(int dtype, int n, int cin, int ho, int wo, i
   p.N = n; p.oH = ho; p.oW = wo; p.oC = cout; p.stride = stride;
   if (lvl == 1 && !(stride == 1 && kh == 3 && kw == 3 && halo_tile_channels(p))) return 0;
   return fwd_stats_rows(p, dtype, stride, kh, kw, true);
+}
+
+int se3ds_conv_transpose2x2_fwd(const void* x, const void* wn, void* y, int dtype, int n, int hi, int wi,
+                                int cin, int cout, const float* bias, void* stream) {
+  // y (n, 2 hi, 2 wi, cout) = Conv2DTranspose(k 2, stride 2)(x (n, hi, wi, cin)); wn = the operand copy
+  // in the Keras kernel's own layout (ky, kx, cout, cin).  Two 1x1 forward convolutions, one per
+  // output row parity, with the 2 * cout "channels" (kx, co): see IgemmParams::o_pitch.
+  if (cout % 4 != 0) return SE3DS_E_UNSUPPORTED;
+  const size_t esz = dtype == SE3DS_F32 ? 4 : 2;
+  for (int py = 0; py < 2; ++py) {
+    const char* wpy = (const char*)wn + (size_t)py * 2 * cout * cin * esz;
+    const int rc = conv_common(MODE_FWD, x, wpy, y, dtype, n, hi, wi, cin, hi, wi, 2 * cout, 1, 1, 1, 0, 0,
+                               0, nullptr, 0, nullptr, bias, nullptr, nullptr, 0, 0.f, stream, nullptr,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 2 * (int64_t)wi,
+                               (int64_t)py * wi, cout);
+    if (rc != SE3DS_OK) return rc;
+  }
+  return SE3DS_OK;
 }
 
 int se3ds_conv2d_fwd_stats(const void* x, const void* wt, void* y, int dtype, int n, int h, int w,

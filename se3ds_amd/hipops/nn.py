@@ -1300,10 +1300,17 @@ def conv_transpose2d(ctx: Ctx, x: Var, layer: ConvLayer):
   flops = 2.0 * n * hi * wi * cin_t * layer.cout * k * k
   tag = f'convT {k}x{k}s2 {cin_t}->{layer.cout} @{hi}x{wi}->{H}x{W} n{n}'
   with _Timed('convT_fwd', flops, tag):
-    _chk(L.se3ds_conv2d_dgrad(xd.data_ptr(), wn.data_ptr(), y.data_ptr(), ctx.code, n, H, W,
-                              layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None,
-                              _lib.ptr(bias), None, ACT_NONE, 0.0, _lib.stream()),
-         'se3ds_conv2d_dgrad')
+    if k == 2 and layer.cout % 4 == 0 and _CONVT_2X2:
+      # every output pixel sees one tap: two 1x1 convolutions with (kx, co) as channels, 512-byte
+      # output runs (se3ds_conv_transpose2x2_fwd) instead of four parity-class passes
+      _chk(L.se3ds_conv_transpose2x2_fwd(xd.data_ptr(), wn.data_ptr(), y.data_ptr(), ctx.code, n, hi,
+                                         wi, cin_t, layer.cout, _lib.ptr(bias), _lib.stream()),
+           'se3ds_conv_transpose2x2_fwd')
+    else:
+      _chk(L.se3ds_conv2d_dgrad(xd.data_ptr(), wn.data_ptr(), y.data_ptr(), ctx.code, n, H, W,
+                                layer.cout, hi, wi, cin_t, k, k, 2, 0, 0, 0, None, None,
+                                _lib.ptr(bias), None, ACT_NONE, 0.0, _lib.stream()),
+           'se3ds_conv2d_dgrad')
   out = Var(y)
   if ctx.tape is not None:
     def bwd():
@@ -1364,6 +1371,8 @@ _FUSED_ROW_SCALE = os.environ.get('SE3DS_FUSED_ROW_SCALE', '1') != '0'
 # default: se3ds_norm_bwd_cg (two launches, the apply workgroups fold the partial rows) where the
 # shape allows (bf16, channels % 64 == 0, >= 512 channels, one replica)
 _NORM_CG = os.environ.get('SE3DS_NORM_CG', '1') != '0'
+# SE3DS_CONVT_2X2=0: 2x2 stride-2 transposed convs through the parity-class data-gradient kernel
+_CONVT_2X2 = os.environ.get('SE3DS_CONVT_2X2', '1') != '0'
 # SE3DS_MASK_CACHE=0: every partial conv launches its own mask-window kernel
 _MASK_CACHE = os.environ.get('SE3DS_MASK_CACHE', '1') != '0'
 
