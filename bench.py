@@ -267,7 +267,7 @@ def bench_warp(args, rank, world, dev):
 
   traffic, traffic_detail = (None, None)
   if (h, views, args.warp_depth) == (1024, 2, 'random'):
-    traffic, traffic_detail = _pmc_traffic('r04_warp_pmc.json', ('splat_sort',))
+    traffic, traffic_detail = _pmc_traffic('r05_warp_pmc.json', ('splat_sort',))
   out = {
       'metric': 'panoramas/sec (2-view unproject + 1 target render, 1024x2048 equirect)',
       'value': world * args.steps / dt, 'unit': 'panoramas/sec', 'n_gpus': world,
