@@ -200,13 +200,9 @@ def bench_warp(args, rank, world, dev):
   def step():
     # ONE library call per trajectory step (se3ds_warp_views_to_target, round 5): every view is
     # unprojected straight into its window of the memory (the concat of eval_metric.py:238-239 /
-    # models.py:239-245 without a copy), then one target is rendered.  SE3DS_WARP_SEPARATE=1: the
-    # four separate calls of round 4 (A/B).
+    # models.py:239-245 without a copy), then one target is rendered (the four separate calls of round 4
+    # took 154.5 us per step against 117).
     mem.clear()
-    if os.environ.get('SE3DS_WARP_SEPARATE') == '1':
-      for rgb, depth, pos in g:
-        mem.append_equirect(rgb, depth, -1, 20.0, position=pos)
-      return mem.project(h, w, -1, 20.0, position=tgt, with_mask=True)
     # (the frame buffers are reused, as a trajectory loop does)
     return mem.append_views_and_project(g, -1, 20.0, tgt, h, w, with_mask=True, out=frame)
 

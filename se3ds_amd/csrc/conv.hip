@@ -4076,8 +4076,7 @@ static void launch_wgrad_reduce(const float* part, int splits, int64_t n, int ac
     t_defer_row = nullptr;
     return;
   }
-  static const bool scalar_only = getenv("SE3DS_WGRAD_REDUCE_SCALAR") != nullptr;   // (A/B switch)
-  if (!scalar_only && (n % 4) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0)
+  if ((n % 4) == 0 && (((uintptr_t)part | (uintptr_t)out) & 15) == 0)
     hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, part,
                        splits, n / 4, accumulate, out_scale, out);
   else
@@ -4117,7 +4116,12 @@ int fill_classes(IgemmParams& p, int mode, int bm = BM) {
 
 using namespace se3ds;
 
-static const bool g_disable_glds = getenv("SE3DS_NO_GLDS") != nullptr;
+
+// SE3DS_NO_THIN=1: the thin-layer kernels (Cin <= 8 forward / weight gradient, Cout <= 4 forward /
+// data / weight gradient, the 4x4 stride-2 data gradient into <= 4 channels) are skipped and their
+// layers take the general implicit-GEMM kernels (read per call: tests/test_nets_gpu.py compares the
+// two routings on the production heads and stems).
+static bool thin_on() { return getenv("SE3DS_NO_THIN") == nullptr; }
 
 // SE3DS_BIG_TILE: unset = cost model below, 0 = never, 1 = whenever the shape allows (read per
 // call so that tests can switch it).
@@ -4241,8 +4245,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   p.stats = nullptr;
   p.addend = addend;
   hipStream_t s = as_stream(stream);
-  const bool glds = (p.sC % (2 * bk)) == 0 && (src_mask == nullptr || mask_binary) &&
-                    !g_disable_glds;
+  const bool glds = (p.sC % (2 * bk)) == 0 && (src_mask == nullptr || mask_binary);
   if (stats != nullptr && !(fwd_stats_rows(p, dtype, stride, kh, kw, glds, mode) > 0))
     return SE3DS_E_UNSUPPORTED;   // callers ask se3ds_conv2d_{fwd_stats,dgrad_bnstats}_rows first
   if (stats != nullptr && mode == MODE_DGRAD &&
@@ -4255,7 +4258,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   if (mode == MODE_DGRAD && dtype == SE3DS_BF16 && kh == 4 && kw == 4 && stride == 2 && cin <= 4 &&
       cout == 128 && src_mask == nullptr && row_a == nullptr && bias == nullptr && act == 0 &&
       !wrap_w && (pad_t == 0 || pad_t == 2) && (pad_l == 0 || pad_l == 2) &&
-      !getenv("SE3DS_NO_THIN_S2_DGRAD")) {
+      thin_on()) {
     int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinSRows) * ceil_div(p.oW, kThinSCols);
     if (blocks > 2 * 256) blocks = 2 * 256;   // persistent, two workgroups per CU
     hipLaunchKernelGGL(thin_s2_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
@@ -4263,7 +4266,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   }
   if (mode == MODE_FWD && dtype == SE3DS_BF16 && cin <= kThinCinMax && (cout % 128) == 0 &&
       kh * kw * cin <= kThinKMax && kh <= 7 && kw <= 7 && stats == nullptr && addend == nullptr &&
-      !pitched && !getenv("SE3DS_NO_THIN_CIN")) {
+      !pitched && thin_on()) {
     const ThinCinLds L = thin_cin_lds(kh, kw, cin, stride);
     static size_t lds_set = 0;
     if (L.bytes > lds_set) {
@@ -4281,7 +4284,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   }
   if (mode == MODE_DGRAD && dtype == SE3DS_BF16 && kh == 3 && kw == 3 && stride == 1 && cout <= 4 &&
       (cin % 64) == 0 && cin <= kThinDCinMax && src_mask == nullptr && row_a == nullptr &&
-      !getenv("SE3DS_NO_THIN_DGRAD")) {
+      thin_on()) {
     int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinDRows) * ceil_div(p.oW, kThinCols);
     if (blocks > 3 * 256) blocks = 3 * 256;   // persistent: three workgroups per CU
     hipLaunchKernelGGL(thin_cout_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
@@ -4289,7 +4292,7 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   }
   if (mode == MODE_FWD && dtype == SE3DS_BF16 && kh == 3 && kw == 3 && stride == 1 && cout <= 4 &&
       (cin % 64) == 0 && cin <= 128 && src_mask == nullptr && row_a == nullptr &&
-      stats == nullptr && addend == nullptr && !getenv("SE3DS_NO_THIN_FWD")) {
+      stats == nullptr && addend == nullptr && thin_on()) {
     const size_t lds = thin_lds_bytes(cin, cout);
     static size_t lds_set = 0;
     if (lds > lds_set) {
@@ -4398,7 +4401,7 @@ int se3ds_conv2d_fwd(const void* x, const void* wt, void* y, int dtype, int n, i
 int64_t se3ds_conv2d_fwd_stats_rows(int dtype, int n, int cin, int ho, int wo, int cout, int kh,
                                     int kw, int stride, int has_in_mask, int in_mask_binary) {
   if (dtype != SE3DS_BF16 || stride < 1 || stride > 2 || (cin % 64) != 0 ||
-      (has_in_mask && !in_mask_binary) || g_disable_glds)
+      (has_in_mask && !in_mask_binary))
     return 0;
   // SE3DS_FUSED_BN_STATS: 0 = never, 1 = only the halo-resident 3x3 kernel, default = every
   // LDS-DMA kernel
@@ -4468,11 +4471,8 @@ int se3ds_conv2d_dgrad_acc(const void* dy, const void* wn, void* dx, int dtype, 
 // rows == 0: this shape / routing cannot (strided, fp32, thin or ragged channel tiles).
 int64_t se3ds_conv2d_dgrad_bnstats_rows(int dtype, int n, int h, int w, int cin, int cout, int kh,
                                         int kw, int stride, int has_row_scale) {
-  if (dtype != SE3DS_BF16 || stride != 1 || (cout % 64) != 0 || (cin % 8) != 0 || has_row_scale ||
-      g_disable_glds)
+  if (dtype != SE3DS_BF16 || stride != 1 || (cout % 64) != 0 || (cin % 8) != 0 || has_row_scale)
     return 0;
-  const char* e = getenv("SE3DS_FUSED_BN_BWD_STATS");
-  if (e && atoi(e) == 0) return 0;
   IgemmParams p;
   p.N = n; p.oH = h; p.oW = w; p.oC = cin; p.stride = stride;
   return fwd_stats_rows(p, dtype, stride, kh, kw, true, MODE_DGRAD);
@@ -4509,26 +4509,16 @@ static int wgrad_splits(int64_t L, int64_t tiles, int64_t nel) {
   return best;
 }
 
-// CUs a weight-gradient launch may count on (SE3DS_WGRAD_SLOTS; default: all 256).  With the two
-// decoders on two streams a 128-item launch of one branch shares the chip with the other
-// branch's; 128 makes the cost model prefer unsplit launches (no partial slabs, no reduce).
-// Measured: 221.1 / 221.4 ms per step with 128 against 222.7 / 221.5 with 256 on one box -- the
-// launches of the two branches do not pair up reliably; the default stays 256.
-static int wgrad_slots() {
-  static const int v = [] {
-    const char* e = getenv("SE3DS_WGRAD_SLOTS");
-    const int x = e ? atoi(e) : 0;
-    return x >= 16 && x <= 256 ? x : 256;
-  }();
-  return v;
-}
+// CUs a weight-gradient launch may count on.  (With the two decoders on two streams a 128-item
+// launch of one branch shares the chip with the other branch's; counting on 128 was measured
+// 221.1 / 221.4 ms per step against 222.7 / 221.5 with 256 on one box in round 3 -- the launches of
+// the two branches do not pair up reliably: all 256.)
+static constexpr int wgrad_slots() { return 256; }
 
 // tap-fused 3x3 kernel: steps of 64 pixels, work items = (Cin/64) x (Cout/128) x splits on 256
 // single-workgroup CUs.  Returns the split count (0: shape not eligible).
 static int wgrad_taps_splits(int n, int ho, int wo, int cin, int cout, int kh, int kw, int* steps) {
   if (kh != 3 || kw != 3 || (cin % 64) != 0 || (cout % 128) != 0) return 0;
-  const char* e = getenv("SE3DS_WGRAD_TAPS");
-  if (e && atoi(e) == 0) return 0;
   const int64_t total = (int64_t)n * ceil_div(ho, 2) * ceil_div(wo, 32);
   if (total > (1 << 30)) return 0;
   *steps = (int)total;
@@ -4551,7 +4541,7 @@ static int wgrad_taps_splits(int n, int ho, int wo, int cin, int cout, int kh, i
 
 static bool thin_cin_wgrad_ok(int cin, int cout, int kh, int kw) {
   return cin <= kThinCinMax && cout == 128 && kh * kw * cin <= kThinKMax && kh <= 7 && kw <= 7 &&
-         !getenv("SE3DS_NO_THIN_CIN_WGRAD");
+         thin_on();
 }
 
 size_t se3ds_conv2d_wgrad_workspace_bytes(int n, int ho, int wo, int cin, int cout, int kh,
@@ -4585,7 +4575,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
     return SE3DS_E_WORKSPACE;
   hipStream_t s = as_stream(stream);
   if (dtype == SE3DS_BF16 && stride == 1 && row_scale == nullptr &&
-      (in_mask == nullptr || in_mask_binary) && !g_disable_glds) {
+      (in_mask == nullptr || in_mask_binary)) {
     int tsteps = 0;
     const int tsplits = wgrad_taps_splits(n, ho, wo, cin, cout, kh, kw, &tsteps);
     if (tsplits > 0) {
@@ -4599,8 +4589,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
       q.steps_per_split = ceil_div(tsteps, tsplits);
       q.dy_cstride = cout; q.co_valid = cout;
       dim3 tgrid((unsigned)(cin / 64), (unsigned)(cout / 128), (unsigned)tsplits);
-      static const bool taps3 = [] { const char* e = getenv("SE3DS_WGRAD_TAPS3"); return !e || atoi(e) != 0; }();
-      if (taps3 && !wrap_w)
+      if (!wrap_w)
         if (halo_m16()) hipLaunchKernelGGL(wgrad_taps3_kernel<true>, tgrid, dim3(512), 0, s, q);
         else hipLaunchKernelGGL(wgrad_taps3_kernel<false>, tgrid, dim3(512), 0, s, q);
       else
@@ -4646,7 +4635,7 @@ int se3ds_conv2d_wgrad(const void* x, const void* dy, float* dw, int dtype, int 
   p.l_per_split = ceil_div(ceil_div(L, p.splits), WG_BL) * WG_BL;
   dim3 grid((unsigned)row_tiles, (unsigned)ceil_div(cout, 128), (unsigned)p.splits);
   const int epc = dtype == SE3DS_F32 ? 4 : 8;
-  const bool glds = !g_disable_glds && !p.linear_k && (in_mask == nullptr || in_mask_binary) &&
+  const bool glds = !p.linear_k && (in_mask == nullptr || in_mask_binary) &&
                     row_scale == nullptr &&
                     (cin % epc) == 0 && (cout % epc) == 0;
   if (glds) {
@@ -4691,7 +4680,6 @@ int se3ds_wgrad_reduce_tile(void) { return kRedTile; }
 // thin-Cout layers through the tap-fused kernel (padded dy copy): split count, 0 = not eligible
 static int wgrad_taps_thin_splits(int n, int h, int w, int cin, int cout, int k, int* steps) {
   if (k != 3 || cout > 8 || (cin % 64) != 0) return 0;
-  if (getenv("SE3DS_WGRAD_TAPS_THIN") && atoi(getenv("SE3DS_WGRAD_TAPS_THIN")) == 0) return 0;
   const int64_t total = (int64_t)n * ceil_div(h, 2) * ceil_div(w, 32);
   if (total > (1 << 30)) return 0;
   *steps = (int)total;
@@ -4722,7 +4710,7 @@ int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dty
     return SE3DS_E_WORKSPACE;
   if (dtype == SE3DS_BF16 && k == 3 && cout <= 4 && (cin % 32) == 0 && cin <= 128 &&
       workspace_bytes >= sizeof(float) * (size_t)kThinQSlabs * 9 * cin * cout &&
-      !getenv("SE3DS_NO_THIN_COUT_WGRAD")) {
+      thin_on()) {
     hipStream_t s = as_stream(stream);
     ThinCoutWgradParams q;
     q.x = (const uint16_t*)x; q.dy = (const uint16_t*)dy; q.part = (float*)workspace;
@@ -4742,7 +4730,7 @@ int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dty
     launch_wgrad_reduce((const float*)workspace, (int)blocks, tnel, accumulate, nullptr, dw, s);
     return check_launch("conv2d_wgrad(thin cout)");
   }
-  if (dtype == SE3DS_BF16 && !g_disable_glds) {
+  if (dtype == SE3DS_BF16) {
     int tsteps = 0;
     const int tsplits = wgrad_taps_thin_splits(n, h, w, cin, cout, k, &tsteps);
     if (tsplits > 0) {

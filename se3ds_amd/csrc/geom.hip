@@ -1154,8 +1154,7 @@ int launch_splat_binned(const float* coords, const float* offset, const T* feats
                      tile_lds, stream, channels, height, width, ntiles, tiles_x, nb, slice,      \
                      depth_scale, output_void, mask_void, depth, feat, mask, ws, bw,             \
                      (uint32_t)nparts)
-  static const bool no_stash = getenv("SE3DS_RESOLVE_NOSTASH") != nullptr;
-  if (channels <= kStashChannels && !no_stash) {
+  if (channels <= kStashChannels) {
     if (ordered) SE3DS_RESOLVE(true, kStashChannels); else SE3DS_RESOLVE(false, kStashChannels);
   } else {
     if (ordered) SE3DS_RESOLVE(true, 0); else SE3DS_RESOLVE(false, 0);
@@ -1698,7 +1697,7 @@ __global__ void __launch_bounds__(kPResolveThreads)
 splat_pack_resolve_kernel(int height, int width, int ntiles, int tiles_x, float depth_scale,
                           float output_void, float mask_void, float* __restrict__ depth,
                           float* __restrict__ feat, float* __restrict__ mask, SplatWs ws, PackWs pw,
-                          uint32_t zpart_count, int vec_out) {
+                          uint32_t zpart_count) {
   __shared__ uint32_t s_z[kPTilePx];
   __shared__ uint32_t s_fe[C][kPTilePx];
   __shared__ uint32_t s_w[kPResolveThreads / 64];
@@ -1832,39 +1831,18 @@ splat_pack_resolve_kernel(int height, int width, int ntiles, int tiles_x, float 
       *d_out = d;
       *m_out = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
     };
-    if (vec_out) {
-      for (int q = threadIdx.x; q < kPTilePx / 4; q += kPResolveThreads) {
-        const int p0 = 4 * q;
-        const int y = ty * kPTileY + p0 / kPTileX, x = tx * kPTileX + (p0 % kPTileX);
-        if (y >= height || x >= width || !mine((uint32_t)p0)) continue;   // (width % 4 == 0)
-        const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
-        float d[4], mk[4], f[4][C];
+    // (16-byte output stores, 4 pixels per thread, measured 2 % slower than dword stores in round 3:
+    // 100.3 vs 98.2 us per render on one box)
+    for (int p = threadIdx.x; p < kPTilePx; p += kPResolveThreads) {
+      const int y = ty * kPTileY + p / kPTileX, x = tx * kPTileX + (p % kPTileX);
+      if (y >= height || x >= width || !mine((uint32_t)p)) continue;
+      const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
+      float d, mk, f[C];
+      pixel(p, i, &d, f, &mk);
+      depth[i] = d;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pixel(p0 + e, i + e, &d[e], f[e], &mk[e]);
-        *reinterpret_cast<float4*>(depth + i) = make_float4(d[0], d[1], d[2], d[3]);
-        if (mask) *reinterpret_cast<float4*>(mask + i) = make_float4(mk[0], mk[1], mk[2], mk[3]);
-        float flat[4 * C];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int k = 0; k < C; ++k) flat[e * C + k] = f[e][k];
-#pragma unroll
-        for (int k = 0; k < C; ++k)
-          *reinterpret_cast<float4*>(feat + i * C + 4 * k) =
-              make_float4(flat[4 * k], flat[4 * k + 1], flat[4 * k + 2], flat[4 * k + 3]);
-      }
-    } else {
-      for (int p = threadIdx.x; p < kPTilePx; p += kPResolveThreads) {
-        const int y = ty * kPTileY + p / kPTileX, x = tx * kPTileX + (p % kPTileX);
-        if (y >= height || x >= width || !mine((uint32_t)p)) continue;
-        const int64_t i = (int64_t)b * hw + (int64_t)y * width + x;
-        float d, mk, f[C];
-        pixel(p, i, &d, f, &mk);
-        depth[i] = d;
-#pragma unroll
-        for (int k = 0; k < C; ++k) feat[i * C + k] = f[k];
-        if (mask) mask[i] = mk;
-      }
+      for (int k = 0; k < C; ++k) feat[i * C + k] = f[k];
+      if (mask) mask[i] = mk;
     }
   }
 }
@@ -1959,11 +1937,6 @@ int launch_splat_packed(const float* coords, const float* offset, const T* feats
   const int items = (int)resolve_items_max(nb, (int64_t)n * m, slice);
   const int vec = (ld % 4 == 0) && ((uintptr_t)coords % 16 == 0) &&
                   ((uintptr_t)feats % (sizeof(T) == 1 ? 4 : 16) == 0);
-  // 16-byte output stores (4 pixels per thread) measured 2 % SLOWER than one pixel per thread with
-  // dword stores (100.3 vs 98.2 us per render, same box): opt-in for A/B runs only
-  static const bool want_vec_out = getenv("SE3DS_PACK_VEC_OUT") != nullptr;
-  const int vec_out = want_vec_out && (width % 4 == 0) && ((uintptr_t)depth % 16 == 0) &&
-                      ((uintptr_t)feat % 16 == 0) && (mask == nullptr || (uintptr_t)mask % 16 == 0);
   // (read per call: the parity tests switch the tap on for single calls)
   const char* e_dbg = getenv("SE3DS_SPLAT_DEBUG");
   const bool dbg = e_dbg && atoi(e_dbg) != 0;
@@ -1984,7 +1957,7 @@ int launch_splat_packed(const float* coords, const float* offset, const T* feats
 #define SE3DS_P4(CC)                                                                              \
   hipLaunchKernelGGL((splat_pack_resolve_kernel<CC>), dim3(items), dim3(kPResolveThreads), 0,     \
                      stream, height, width, ntiles, tiles_x, depth_scale, output_void, mask_void,  \
-                     depth, feat, mask, ws, pw, (uint32_t)nparts, vec_out);                        \
+                     depth, feat, mask, ws, pw, (uint32_t)nparts);                        \
   hipLaunchKernelGGL((splat_pack_sink_kernel<CC>), dim3(1), dim3(1024), 0, stream, depth, feat,   \
                      mask, mask_void, ws, pw, (uint32_t)nparts)
   switch (channels) {

@@ -803,16 +803,9 @@ affine_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
 }
 
 // row blocks for the elementwise kernels: ~8 blocks per CU in total
-inline int ew_blocks_per_cu() {
-  static const int v = [] {
-    const char* e = getenv("SE3DS_NORM_EW_BLOCKS");
-    const int x = e ? atoi(e) : 0;
-    return x > 0 ? x : 8;
-  }();
-  return v;
-}
+constexpr int kEwBlocksPerCu = 8;
 inline dim3 ew_grid(const Layout2D& l, int64_t R, int G) {
-  int64_t want = (256 * (int64_t)ew_blocks_per_cu()) / ((int64_t)l.ctiles * G);
+  int64_t want = (256 * (int64_t)kEwBlocksPerCu) / ((int64_t)l.ctiles * G);
   if (want < 1) want = 1;
   int64_t max_rb = ceil_div(R, l.ry);
   if (want > max_rb) want = max_rb;
@@ -822,12 +815,7 @@ inline dim3 ew_grid(const Layout2D& l, int64_t R, int G) {
 int pick_rblocks(int64_t R, int ry, int ctiles, int G) {
   // ~2048 blocks in total (8 per CU) so the streaming reads have enough waves in flight, at
   // least 4 row-iterations per thread, at most 1024 partials per column.
-  // (SE3DS_NORM_STAT_BLOCKS: A/B override of the total)
-  static const int total = [] {
-    const char* e = getenv("SE3DS_NORM_STAT_BLOCKS");
-    const int x = e ? atoi(e) : 0;
-    return x > 0 ? x : 2048;
-  }();
+  constexpr int total = 2048;
   int64_t want = total / ((int64_t)ctiles * G);
   if (want < 1) want = 1;
   int64_t max_rb = ceil_div(R, (int64_t)ry * 4);
@@ -848,11 +836,8 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
   int rb = pick_rblocks(R, l.ry, l.ctiles, G);
   if (ws_bytes < sizeof(float) * (size_t)G * rb * 2 * C) return SE3DS_E_WORKSPACE;
   dim3 grid((unsigned)rb, (unsigned)l.ctiles, (unsigned)G);
-  static const bool unroll2 = [] {
-    const char* e = getenv("SE3DS_NORM_UNROLL");
-    return !(e && atoi(e) == 1);   // default: two rows per iteration
-  }();
-  if (l.vec > 1 && MODE == 1 && sizeof(T) == 2 && unroll2 && row_scale == nullptr &&
+  // two rows per iteration where the specialised kernel exists
+  if (l.vec > 1 && MODE == 1 && sizeof(T) == 2 && row_scale == nullptr &&
       (act == 0 || ((act == 1 || act == 2) && amask != nullptr))) {
     if (act == 0)
       hipLaunchKernelGGL((norm_partial_kernel<T, VT<T>::V, MODE, true, 0>), grid, dim3(256), 0, s, a, y,
@@ -880,14 +865,8 @@ int launch_partial(const T* a, const T* y, const T* x, const float* mean, const 
 using namespace se3ds;
 
 constexpr int kCgMaxRows = 64;
-static int cg_min_c() {   // SE3DS_NORM_CG_MINC (A/B): smallest channel count that takes this path
-  static const int v = [] {
-    const char* e = getenv("SE3DS_NORM_CG_MINC");
-    const int x = e ? atoi(e) : 0;
-    return x >= 64 ? x : 512;
-  }();
-  return v;
-}
+// smallest channel count that takes the channel-group path (256 measured slower: DESIGN 3.2)
+static int cg_min_c() { return 512; }
 
 extern "C" {
 
@@ -1000,20 +979,9 @@ int se3ds_norm_apply(const void* x, int dtype, int g, int64_t r, int c, const fl
     if (l.vec > 1) LAUNCH_APPLY(float, 4); else LAUNCH_APPLY(float, 1);
   } else if (dtype == SE3DS_BF16) {
     Layout2D l = make_layout(c, 8);
-    static const bool no_fast = getenv("SE3DS_NORM_BWD_GENERIC") != nullptr;
-    // SE3DS_NORM_APPLY_CG=1 (A/B): the channel-group layout of se3ds_norm_bwd_cg -- 8 lanes x 8
-    // channels = one 128-byte line per row and workgroup, 32 rows per pass -- for the forward apply
-    // too.  Measured round 5, same box: 198.2 / 197.1 ms per step with, 196.8 / 196.9 without: off.
-    static const int apply_cg = [] {
-      const char* e = getenv("SE3DS_NORM_APPLY_CG");
-      return e ? atoi(e) : 0;
-    }();
-    if (apply_cg && l.vec > 1 && (c % 64) == 0 && c >= cg_min_c()) {
-      l.cx = 8;
-      l.ry = 32;
-      l.ctiles = c / 64;
-    }
-    if (l.vec > 1 && post == nullptr && act >= 0 && act <= 2 && !no_fast) {
+    // (the channel-group layout of se3ds_norm_bwd_cg was tried for this forward apply too: 198.2 /
+    // 197.1 ms per step with, 196.8 / 196.9 without on one box -- not kept)
+    if (l.vec > 1 && post == nullptr && act >= 0 && act <= 2) {
 #define LAUNCH_FAST(A, RES)                                                                      \
   hipLaunchKernelGGL((norm_apply_fast_kernel<A, RES>), ew_grid(l, r, g), dim3(256), 0, s,        \
                      (const uint16_t*)x, scale, shift, (const uint16_t*)res, r, c, l.cx, l.ry,   \
@@ -1067,9 +1035,8 @@ int se3ds_norm_bwd_apply(const void* dy, const void* y, const void* x, int dtype
     if (l.vec > 1) LAUNCH_BWD(float, 4); else LAUNCH_BWD(float, 1);
   } else if (dtype == SE3DS_BF16) {
     Layout2D l = make_layout(c, 8);
-    static const bool no_fast = getenv("SE3DS_NORM_BWD_GENERIC") != nullptr;
     const bool fast = l.vec > 1 && gamma != nullptr && (act == 0 || act_mask != nullptr) &&
-                      act >= 0 && act <= 2 && (in_act == 0 || in_act == 2) && !no_fast;
+                      act >= 0 && act <= 2 && (in_act == 0 || in_act == 2);
     if (fast) {
 #define LAUNCH_FAST(A, I)                                                                        \
   hipLaunchKernelGGL((norm_bwd_apply_fast_kernel<A, I>), ew_grid(l, r, g), dim3(256), 0, s,      \
@@ -1131,11 +1098,7 @@ int se3ds_norm_bwd_apply_rows(const void* dy, const void* x, int dtype, int64_t 
 // workgroup fold the partial rows of its own channels in a prologue.  One group, bf16, c % 64 == 0,
 // c >= kCgMinC (enough channel groups to fill the chip with <= kCgMaxRows partial rows).
 static int cg_stat_blocks(int64_t r, int c) {
-  static const int total = [] {
-    const char* e = getenv("SE3DS_NORM_CG_STAT_BLOCKS");
-    const int x = e ? atoi(e) : 0;
-    return x > 0 ? x : 768;
-  }();
+  constexpr int total = 768;    // 3 workgroups per CU (1 024 and 2 048 measured no faster)
   int64_t rb = total / (c / 64);
   const int64_t max_rb = ceil_div(r, (int64_t)32 * 4);   // >= 4 rows per thread
   if (rb > max_rb) rb = max_rb;
@@ -1144,11 +1107,7 @@ static int cg_stat_blocks(int64_t r, int c) {
   return (int)rb;
 }
 static int cg_apply_blocks(int64_t r, int c) {
-  static const int total = [] {
-    const char* e = getenv("SE3DS_NORM_CG_APPLY_BLOCKS");
-    const int x = e ? atoi(e) : 0;
-    return x > 0 ? x : 2048;
-  }();
+  constexpr int total = 2048;   // 8 workgroups per CU
   int64_t rb = total / (c / 64);
   const int64_t max_rb = ceil_div(r, (int64_t)32);
   if (rb > max_rb) rb = max_rb;
@@ -1157,10 +1116,10 @@ static int cg_apply_blocks(int64_t r, int c) {
 }
 
 int se3ds_norm_bwd_cg_supported(int dtype, int64_t r, int c, int act, int has_mask, int in_act) {
-  static const bool off = [] {
-    const char* e = getenv("SE3DS_NORM_CG");
-    return e && atoi(e) == 0;
-  }();
+  // SE3DS_NORM_CG=0: the three-launch backward of rounds 2-4 (read per call: the parity test of
+  // the two forms in tests/test_blocks_gpu.py switches it)
+  const char* e_cg = getenv("SE3DS_NORM_CG");
+  const bool off = e_cg && atoi(e_cg) == 0;
   if (off || dtype != SE3DS_BF16 || r <= 0 || c < cg_min_c() || (c % 64) != 0) return 0;
   if (act < 0 || act > 2 || (act != 0 && !has_mask) || !(in_act == 0 || in_act == 2)) return 0;
   return 1;

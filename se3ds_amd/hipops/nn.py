@@ -317,7 +317,7 @@ class Ctx:
     out as one all-reduce (the two decoders hold 168 of the generator's 279 batch
     norms).  The kernels of both threads go to the current stream; what a branch touches is its
     own (layers, activations, per-branch scratch)."""
-    if self.world > 1 and _PAIR_SYNCBN and len(fns) == 2:
+    if self.world > 1 and len(fns) == 2:
       return _run_paired(self, fns)
     out = {}
     keep = self.streams
@@ -365,7 +365,7 @@ class Ctx:
 
   def backward(self):
     tape, self.tape = self.tape, []
-    if self.world > 1 and _PAIR_SYNCBN:
+    if self.world > 1:
       tape = _merge_paired(tape)
     keep = self.streams
     if 'bwd' not in self.stream_phases:
@@ -518,9 +518,6 @@ class _Branch:
     if self.scope is not None:
       self.scope.__exit__(*a)
     self.ctx.branch_tag = self.prev
-
-
-_PAIR_SYNCBN = os.environ.get('SE3DS_PAIR_SYNCBN', '1') != '0'
 
 
 class _PairSync:
@@ -1352,9 +1349,6 @@ class NormLayer:
       store.add(name + '/moving_variance', (c,), ones_init, trainable=False)
 
 
-_MERGED_BN_STATS = os.environ.get('SE3DS_NORM_MERGED', '1') != '0'
-
-
 _NORM_DEBUG = {} if os.environ.get('SE3DS_NORM_DEBUG') else None
 # SE3DS_FUSED_BN_BWD=1: batch-norm backward statistics from the epilogue of the data gradient that
 # produces dy (se3ds_conv2d_dgrad_bnstats) instead of their own pass over dy and x.  OFF by
@@ -1409,7 +1403,7 @@ def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: V
     fused = getattr(x, 'col_stats', None)
     finalized = False
     if (fused is not None and not inst and fused.shape[2] == c and ctx.world == 1 and
-        fused.shape[0] <= 2048 and _MERGED_BN_STATS):
+        fused.shape[0] <= 2048):
       # statistics came out of the producing convolution's epilogue; single replica: column
       # reduction and finalize in one launch
       _chk(L.se3ds_norm_reduce_rows_finalize(

@@ -26,8 +26,8 @@ from se3ds_amd.trainers import dist_utils
 from se3ds_amd.trainers import gan_manager
 from se3ds_amd.trainers.gan_manager import Mean
 
-# the generator's spectral gradient fix-up rides on the clip pass (SE3DS_FUSED_SN_CLIP=0: separate passes)
-FUSED_SN_CLIP = os.environ.get('SE3DS_FUSED_SN_CLIP', '1') != '0'
+# the generator's spectral gradient fix-up rides on the clip pass
+FUSED_SN_CLIP = True
 GRAD_CLIP_NORM = 5.0   # _clip_grad default, reference :27
 # one replica: per-module clip + Adam on a side stream under the backward pass (0: after it)
 SEGMENT_OPTIMIZER = os.environ.get('SE3DS_SEGMENT_OPTIMIZER', '1') != '0'

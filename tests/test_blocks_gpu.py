@@ -348,3 +348,85 @@ def test_fused_backward_passes_match_separate_passes(case):
       worst.append((e, k))
       assert e <= (8e-3 if k.startswith('dx') else 2e-3), (cfg, k, e)
     print(f'{case.name} [{cfg}]: {res[cfg][1]}; worst', sorted(worst)[-2:])
+
+
+def _run_block_bf16(case, flags):
+  """forward + backward of one block with `nn` module flags overridden; returns gradients + norm path counts"""
+  dtype = torch.bfloat16
+  gen = torch.Generator().manual_seed(11)
+  store = nn.ParamStore()
+  mod = case.build(store)
+  store.finalize(DEV, torch.Generator().manual_seed(7))
+  _randomise(store, gen)
+  sg = nn.SpectralGroup(image_models._conv_layers_of(mod), torch.device(DEV))
+  xs = [_bf(torch.relu(torch.randn(s, generator=gen) * 0.7 + torch.randn(s[-1], generator=gen) * 0.5))
+        for s in case.shapes]
+  mask = _mask(*case.mask_shape, gen) if case.mask_shape else None
+  old = {k: getattr(nn, k) for k in flags}
+  old_dbg = nn._NORM_DEBUG
+  for k, v in flags.items():
+    setattr(nn, k, v)
+  nn._NORM_DEBUG = {}
+  try:
+    ctx = nn.Ctx(DEV, dtype, training=True, record=True)
+    xv = [nn.Var(x.to(DEV).to(dtype)) for x in xs]
+    sg.power_iteration(True)
+    out, _ = case.hip(ctx, mod, xv, mask.to(DEV) if mask is not None else None)
+    if case.name.startswith('head'):
+      y_h, push = nn.head(ctx, out, 0)
+      push(_bf(torch.randn(y_h.shape, generator=gen)).to(DEV))
+    else:
+      out.grad = _bf(torch.randn(out.data.shape, generator=gen)).to(DEV).to(dtype)
+    y = out.data.float().cpu().clone()
+    ctx.backward()
+    sg.backward_fixup()
+    counts = {}
+    for k, v in nn._NORM_DEBUG.items():
+      counts[k[0]] = counts.get(k[0], 0) + v
+  finally:
+    for k, v in old.items():
+      setattr(nn, k, v)
+    nn._NORM_DEBUG = old_dbg
+  g = {k: store.grad_views[k].float().cpu().clone() for k in store.trainable_names}
+  for i, v in enumerate(xv):
+    g[f'dx{i}'] = v.grad.float().cpu()
+  g['y'] = y
+  return g, counts
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c.name for c in CASES])
+def test_round5_kernel_choices_match_their_predecessors(case, monkeypatch):
+  """Round 5 switched three things on by default; each keeps its predecessor behind a switch, and this
+  test owns the switches:
+  (a) SE3DS_NORM_CG (nn._NORM_CG + the library's se3ds_norm_bwd_cg_supported): batch-norm backward in
+      two launches in the channel-group layout instead of statistics + column reduction + apply.  Same
+      sums in a different order: parameter gradients 2e-3 of their class scale, input gradients one
+      bf16 ulp of the tensor's maximum (8e-3) -- and the path is really taken where C >= 512;
+  (b) SE3DS_CONVT_2X2 (nn._CONVT_2X2): 2x2 stride-2 transposed convs as two pitched 1x1 convolutions
+      (se3ds_conv_transpose2x2_fwd) instead of the parity-class data-gradient kernel: BIT-identical;
+  (c) SE3DS_MASK_CACHE (nn._MASK_CACHE): partial convs that see the same mask tensor share one
+      mask-window launch: BIT-identical."""
+  base, cnt = _run_block_bf16(case, {})
+  wide = case.name.startswith(('bottleneck', 'trans_basic', 'upsampling'))   # batch norms with C >= 512
+  assert cnt.get('cg', 0) >= (1 if wide else 0), cnt
+  for name in ('_CONVT_2X2', '_MASK_CACHE'):
+    got, _ = _run_block_bf16(case, {name: False})
+    for k, b in base.items():
+      assert torch.equal(got[k], b), (name, k)
+  monkeypatch.setenv('SE3DS_NORM_CG', '0')
+  got, cnt0 = _run_block_bf16(case, {'_NORM_CG': False})
+  assert cnt0.get('cg', 0) == 0, cnt0
+  vec_scale = max([float(v.abs().max()) for k, v in base.items() if v.dim() <= 1] or [1.0])
+  worst = []
+  for k, b in base.items():
+    a = got[k]
+    if k == 'y':
+      assert torch.equal(a, b)   # (the forward pass is not touched)
+      continue
+    den = max(float(b.abs().max()), 1e-30)
+    if b.dim() <= 1:
+      den = max(den, 1e-2 * vec_scale)
+    e = float((a - b).abs().max() / den)
+    worst.append((e, k))
+    assert e <= (8e-3 if k.startswith('dx') else 2e-3), (k, e)
+  print(f'{case.name}: cg norms {cnt.get("cg", 0)}; worst vs three-launch backward', sorted(worst)[-2:])

@@ -116,6 +116,15 @@ def test_conv_thin_cin(case):
   _run_conv_case(case, torch.bfloat16)
 
 
+@pytest.mark.parametrize('case', THIN_CASES[:2] + THIN_CIN_CASES[:2] + THIN_CIN_CASES[4:5])
+def test_conv_thin_layers_through_the_general_kernels(case, monkeypatch):
+  """SE3DS_NO_THIN=1: heads and stems through the general implicit-GEMM kernels (the routing of
+  round 1) against the same oracle and tolerance -- the switch that separates a thin-kernel fault
+  from a model fault keeps working."""
+  monkeypatch.setenv('SE3DS_NO_THIN', '1')
+  _run_conv_case(case, torch.bfloat16)
+
+
 @pytest.mark.parametrize('halo', ['0', '1'])
 @pytest.mark.parametrize('case', BIG_TILE_CASES)
 def test_conv_macro_tile_fwd_bwd(case, halo, monkeypatch):
@@ -1236,7 +1245,7 @@ def test_scheduling_switches_are_bit_identical():
   r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'step_compare.py'), '128', '2', '4'],
                      env=env, cwd=root, capture_output=True, text=True, timeout=900)
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-  assert r.stdout.count('IDENTICAL to serial') == 10, r.stdout[-2000:]
+  assert r.stdout.count('IDENTICAL to serial') == 11, r.stdout[-2000:]
 
 
 def test_default_schedule_is_bit_identical_to_serial_at_production_size():

@@ -512,6 +512,18 @@ def test_packed_splat_variants_and_byte_range_promise():
         torch.cuda.synchronize()
   finally:
     point_cloud_utils._PROMISE_POLL_EVERY = old_every
+  # SE3DS_CHECK_PROMISE=1 (module flag _CHECK_PROMISE_SYNC): the debugging mode reads the flag back
+  # synchronously behind EVERY promised splat -- the offending call itself raises
+  try:
+    point_cloud_utils._poll_promise(dev(), force=True)
+  except point_cloud_utils.PromiseBroken:
+    pass
+  old_sync, point_cloud_utils._CHECK_PROMISE_SYNC = point_cloud_utils._CHECK_PROMISE_SYNC, True
+  try:
+    with pytest.raises(point_cloud_utils.PromiseBroken):
+      pano_utils.project_feats_to_equirectangular(good, t(xyz_np), h, w, -1, DEPTH_SCALE)
+  finally:
+    point_cloud_utils._CHECK_PROMISE_SYNC = old_sync
     try:   # drain the flag this test raised on purpose (it is sticky: later tests share the workspace)
       point_cloud_utils._poll_promise(dev(), force=True)
     except point_cloud_utils.PromiseBroken:

@@ -34,13 +34,14 @@ if len(sys.argv) > 1 and sys.argv[1] == '--worker':
   sys.exit(0)
 
 size, batch, steps = (sys.argv[1:] + ['128', '2', '4'])[:3]
-# (dual stream, segment optimiser, phases | 'nowg' = WITH the opt-in wgrad stream, passes): passes
+# (dual stream, segment optimiser, phases | 'nowg' = WITH the opt-in wgrad stream | 'dov' = WITH the
+# opt-in discriminator overlap SE3DS_D_OVERLAP, passes): passes
 # 'old' = the round-3 kernels' schedule -- clip and Adam as separate passes over the gradient arena,
 # every weight gradient reduced right behind its kernel; '' = round 4 (clip inside Adam, a module's
 # split reductions in one deferred launch).  The reference row is the serial order with 'old'.
 configs = [('0', '0', '', 'old'), ('0', '0', '', ''), ('0', '1', '', ''), ('1', '0', '', ''), ('1', '1', '', ''),
            ('1', '1', '', 'old'), ('1', '0', 'fwd', ''), ('1', '0', 'bwd', ''), ('1', '1', 'nowg', ''),
-           ('1', '0', 'nowg', 'old')]
+           ('1', '0', 'nowg', 'old'), ('1', '1', 'dov', '')]
 if os.environ.get('SE3DS_CMP_CONFIGS'):   # e.g. '0:0::old,1:1::' -- a subset (the reference row must be in it)
   configs = [tuple((c.split(':') + [''])[:4]) for c in os.environ['SE3DS_CMP_CONFIGS'].split(',')]
 out = {}
@@ -48,7 +49,8 @@ for ds, so, ph, ps in configs:
   env = dict(os.environ, SE3DS_DUAL_STREAM=ds, SE3DS_SEGMENT_OPTIMIZER=so,
              SE3DS_FUSED_CLIP_ADAM='0' if ps == 'old' else '1',
              SE3DS_DEFER_WGRAD_REDUCE='0' if ps == 'old' else '1',
-             SE3DS_DUAL_PHASES='' if ph == 'nowg' else ph, SE3DS_WGRAD_STREAM='1' if ph == 'nowg' else '0')
+             SE3DS_DUAL_PHASES='' if ph in ('nowg', 'dov') else ph,
+             SE3DS_WGRAD_STREAM='1' if ph == 'nowg' else '0', SE3DS_D_OVERLAP='1' if ph == 'dov' else '0')
   r = subprocess.run([sys.executable, os.path.abspath(__file__), '--worker', size, batch, steps],
                      env=env, capture_output=True, text=True)
   lines = [l for l in r.stdout.splitlines() if l.startswith('STEP')]
