@@ -35,6 +35,16 @@ def summarize_collectives(log):
   gaps = sorted(b - a for a, b in zip(ts, ts[1:]))
   out['total'] = {'count': len(log), 'bytes': sum(4 * n for _, n, _ in log)}
   out['syncbn_host_gap_us_median'] = 1e6 * gaps[len(gaps) // 2] if gaps else None
+  # host-side issue timeline: the span from the first to the last collective of the step cut into
+  # ten equal parts, collectives per part and kind (forward: singles, then the decoders' pairs;
+  # backward: pairs first, gradient buckets leaving while the encoder's singles are still going)
+  if log:
+    t0, t1 = log[0][2], log[-1][2]
+    span = max(t1 - t0, 1e-9)
+    tl = {}
+    for kind, _, t in log:
+      tl.setdefault(kind, [0] * 10)[min(int(10 * (t - t0) / span), 9)] += 1
+    out['timeline'] = {'span_ms': 1e3 * (t1 - t0), 'per_tenth': tl}
   return out
 
 

