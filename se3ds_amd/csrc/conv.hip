@@ -3302,7 +3302,7 @@ __global__ void __launch_bounds__(256)
 thin_s2_dgrad_kernel(const IgemmParams p) {
   constexpr int C = 128, PB = C * 2 + 16;   // dy channels, bytes per patch pixel
   __shared__ __attribute__((aligned(16))) unsigned char ds[kThinSPH * kThinSPW * PB];
-  __shared__ __attribute__((aligned(16))) uint16_t wl[16 * 4 * C];   // wn [(tap * Ci + ci)][co]
+  __shared__ __attribute__((aligned(16))) uint16_t wl[16 * 4 * C + C];   // wn [(tap * Ci + ci)][co] + a zero row
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
@@ -3312,6 +3312,8 @@ thin_s2_dgrad_kernel(const IgemmParams p) {
   const uint16_t* __restrict__ dy = (const uint16_t*)p.src;
   for (int i = tid; i < 16 * Ci * C / 8; i += 256)
     reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(p.w)[i];
+  // (the MFMA rows beyond Ci read the zero row instead of zeroing every fragment with v_cndmask)
+  if (tid < C / 8) reinterpret_cast<uint4*>(wl + 16 * 4 * C)[tid] = make_uint4(0u, 0u, 0u, 0u);
   const float scale = p.scale ? *p.scale : 1.0f;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     int64_t b = tile;
@@ -3365,12 +3367,11 @@ thin_s2_dgrad_kernel(const IgemmParams p) {
         const int r = ((y0 + py + 2 * wave + p.pad_t - ky) >> 1) - oyb;
         const int q = ((x0 + px + p.pad_l - kx) >> 1) - oxb;
         const unsigned char* xrow = ds + (r * kThinSPW + q + l32) * PB + half * 16;
-        const uint16_t* wrow = wl + ((ky * 4 + kx) * Ci + (l32 < Ci ? l32 : 0)) * C + half * 8;
+        const uint16_t* wrow = (l32 < Ci ? wl + ((ky * 4 + kx) * Ci + l32) * C : wl + 16 * 4 * C) + half * 8;
 #pragma unroll
         for (int kc = 0; kc < C / 16; ++kc) {
           const uint4 xf = *reinterpret_cast<const uint4*>(xrow + kc * 32);
-          uint4 wf = *reinterpret_cast<const uint4*>(wrow + kc * 16);
-          if (l32 >= Ci) wf = make_uint4(0u, 0u, 0u, 0u);
+          const uint4 wf = *reinterpret_cast<const uint4*>(wrow + kc * 16);
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, wf),
                                                         __builtin_bit_cast(bf16x8_t, xf), acc, 0, 0,
                                                         0);
@@ -3590,11 +3591,17 @@ __host__ __device__ inline size_t thin_cout_wgrad_lds(int cin) {
   return (size_t)(kThinQRows + 2) * (kThinCols + 2) * thin_cw_pixel_bytes(cin) +
          (size_t)kThinQRows * kThinCols * 4 * 2;
 }
+// MAXT = column tiles per wave = ceil(9 * Cin / 32 / 8): 5 for the heads (Cin 128).  Every wave runs
+// MAXT tiles per pixel slot -- a wave with one tile fewer repeats its last one into an accumulator
+// nobody stores (it would otherwise wait at the tile's barrier) -- so the slot's body has no
+// branches: all its transposing LDS reads are issued before the first MFMA.  (With a wave-uniform
+// `break` per tile every MFMA waited for its own two reads: 80 serial LDS round trips per tile.)
+template <int MAXT>
 __global__ void __launch_bounds__(kThinWThreads)
 thin_cout_wgrad_kernel(const ThinCoutWgradParams p) {
   typedef __attribute__((address_space(3))) s16x4_t* lds_seg;
   constexpr int NT = kThinWThreads, PX = kThinQRows * kThinCols;
-  constexpr int PH = kThinQRows + 2, PW = kThinCols + 2, MAXT = 5;   // tiles per wave (Cin <= 128: 36 / 8)
+  constexpr int PH = kThinQRows + 2, PW = kThinCols + 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char tq_smem[];
   const int Ci = p.Cin, Co = p.Cout, PB = thin_cw_pixel_bytes(Ci);
   unsigned char* xs = tq_smem;                                                  // [PH * PW][PB]
@@ -3609,81 +3616,131 @@ thin_cout_wgrad_kernel(const ThinCoutWgradParams p) {
   for (int i = 0; i < MAXT; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  // LDS offset of tile i's fragment reads relative to the pixel slot (tile = (tap, 32 input channels))
+  int xoff[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    int t = wave + 8 * i;
+    t = t < ntile ? t : ntile - 1;
+    const int tap = t / cblocks, cb = t - tap * cblocks;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    xoff[i] = (ky * PW + kx + half * 8 + jrow) * PB + (cb * 32 + g16 * 16 + qcol * 4) * 2;
+  }
   const int tiles_x = ceil_div(p.W, kThinCols), tiles_y = ceil_div(p.H, kThinQRows);
   const int64_t n_tiles = (int64_t)p.N * tiles_y * tiles_x;
-  // the next tile's x patch is fetched into registers while the current one is computed
+  // the next tile's x patch is fetched into registers while the current one is computed.  Thread ->
+  // (pixel, 16-byte chunk) without runtime divisions where Cin / 8 is a power of two (the heads: 16):
+  // chunk = tid % cpp, pixels tid / cpp + u * (NT / cpp); the patch row / column of a pixel is a
+  // division by the constant PW.  (The generic form cost ~100 VALU instructions per 16-byte load,
+  // 1 100 per tile and wave -- more than the tile's MFMAs.)
   constexpr int NV = (PH * PW * 16 + NT - 1) / NT;   // Cin <= 128: 16 chunks of 16 bytes per pixel
   const int cpp = Ci / 8, total = PH * PW * cpp;
+  const bool pow2 = (cpp & (cpp - 1)) == 0;
+  const int csh = 31 - __builtin_clz((unsigned)cpp);
+  const int fc = tid & (cpp - 1), fp0 = tid >> csh, fpp = NT >> csh;
+  auto chunk_of = [&](int u, int& pix, int& c) -> bool {   // false: nothing to do for this thread
+    if (pow2) {
+      pix = fp0 + u * fpp; c = fc;
+      return pix < PH * PW;
+    }
+    const int i = tid + u * NT;
+    pix = i / cpp; c = i - pix * cpp;
+    return i < total;
+  };
+  const uint32_t utiles_x = (uint32_t)tiles_x, utiles_y = (uint32_t)tiles_y;
+  auto tile_pos = [&](uint32_t t, int& n, int& oy0, int& ox0) {
+    const uint32_t ty_n = t / utiles_x;
+    ox0 = (int)(t - ty_n * utiles_x) * kThinCols;
+    const uint32_t nn = ty_n / utiles_y;
+    oy0 = (int)(ty_n - nn * utiles_y) * kThinQRows;
+    n = (int)nn;
+  };
   uint4 nxt[NV];
+  // ... and so is its dy tile ([8 rows][32 * Co] values, rows contiguous in memory: <= 2 values per
+  // thread; fetched synchronously it exposed one global round trip per tile, ~1 us of 7)
+  constexpr int ND = (PX * 4 + NT - 1) / NT;
+  uint16_t nxd[ND];
+  const int rowlen = kThinCols * Co;
   auto fetch = [&](int64_t tile) {
-    int64_t b = tile;
-    const int tx = (int)(b % tiles_x);
-    b /= tiles_x;
-    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
-    const int oy0 = ty * kThinQRows, ox0 = tx * kThinCols;
+    int n, oy0, ox0;
+    tile_pos((uint32_t)tile, n, oy0, ox0);
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * NT;
+      nxd[u] = 0;
+      if (i < kThinQRows * rowlen) {
+        const int ry = i / rowlen, e = i - ry * rowlen;
+        const int oy = oy0 + ry, ox_e = ox0 * Co + e;   // element index inside the image row
+        if (oy < p.H && ox_e < p.W * Co) nxd[u] = p.dy[((int64_t)n * p.H + oy) * p.W * Co + ox_e];
+      }
+    }
+    const int sy0 = oy0 - p.pad, sx0 = ox0 - p.pad;
+    const bool interior = sy0 >= 0 && sy0 + PH <= p.H && sx0 >= 0 && sx0 + PW <= p.W;   // (uniform)
+    const int64_t base = (((int64_t)n * p.H + sy0) * p.W + sx0) * Ci;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int i = tid + u * NT;
+      int pix, c;
       nxt[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (i < total) {
-        const int pix = i / cpp, c = i - pix * cpp;
+      if (chunk_of(u, pix, c)) {
         const int r = pix / PW, q = pix - r * PW;
-        const int sy = oy0 - p.pad + r, sx = ox0 - p.pad + q;
-        if (sy >= 0 && sy < p.H && sx >= 0 && sx < p.W)
-          nxt[u] = *reinterpret_cast<const uint4*>(p.x + (((int64_t)n * p.H + sy) * p.W + sx) * Ci + c * 8);
+        if (interior || ((unsigned)(sy0 + r) < (unsigned)p.H && (unsigned)(sx0 + q) < (unsigned)p.W))
+          nxt[u] = *reinterpret_cast<const uint4*>(p.x + (base + (int64_t)((r * p.W + q) * Ci + c * 8)));
       }
     }
   };
   if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    int64_t b = tile;
-    const int tx = (int)(b % tiles_x);
-    b /= tiles_x;
-    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
-    const int oy0 = ty * kThinQRows, ox0 = tx * kThinCols;
+    int n, oy0, ox0;
+    tile_pos((uint32_t)tile, n, oy0, ox0);
     __syncthreads();   // the previous tile's operands are consumed
-    for (int i = tid; i < PX * Co; i += NT) {
-      const int px = i / Co, c = i - px * Co;
-      const int oy = oy0 + (px >> 5), ox = ox0 + (px & 31);
-      dys[i] = (oy < p.H && ox < p.W) ? p.dy[(((int64_t)n * p.H + oy) * p.W + ox) * Co + c] : (uint16_t)0;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int i = tid + u * NT;
+      if (i < kThinQRows * rowlen) {
+        const int ry = i / rowlen, e = i - ry * rowlen;
+        // stored channel-major [Co][PX]: a lane's 8 consecutive pixels of one output channel are one
+        // 16-byte LDS read (pixel-major needed eight 2-byte reads and their packing per fragment)
+        int cx, c;
+        switch (Co) {
+          case 1: cx = e; c = 0; break;
+          case 2: cx = e >> 1; c = e & 1; break;
+          case 3: cx = e / 3; c = e - cx * 3; break;
+          default: cx = e >> 2; c = e & 3; break;
+        }
+        dys[c * PX + ry * kThinCols + cx] = nxd[u];
+      }
     }
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int i = tid + u * NT;
-      if (i < total) {
-        const int pix = i / cpp, c = i - pix * cpp;
-        *reinterpret_cast<uint4*>(xs + pix * PB + c * 16) = nxt[u];
-      }
+      int pix, c;
+      if (chunk_of(u, pix, c)) *reinterpret_cast<uint4*>(xs + pix * PB + c * 16) = nxt[u];
     }
     __syncthreads();
     if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
+#pragma unroll 2
     for (int sidx = 0; sidx < PX / 16; ++sidx) {
       const int row = sidx >> 1, cs = (sidx & 1) * 16;
-      // A: dy[px][co], 8 pixels of this lane's output channel (rows co >= Cout are zero)
-      uint16_t ea[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        ea[j] = l32 < Co ? dys[(row * kThinCols + cs + half * 8 + j) * Co + l32] : (uint16_t)0;
-      const uint4 af = make_uint4((uint32_t)ea[0] | ((uint32_t)ea[1] << 16), (uint32_t)ea[2] | ((uint32_t)ea[3] << 16),
-                                  (uint32_t)ea[4] | ((uint32_t)ea[5] << 16), (uint32_t)ea[6] | ((uint32_t)ea[7] << 16));
+      // A: dy[co][px], 8 pixels of this lane's output channel (rows co >= Cout are zero)
+      uint4 af = make_uint4(0u, 0u, 0u, 0u);
+      if (l32 < Co)
+        af = *reinterpret_cast<const uint4*>(dys + l32 * PX + row * kThinCols + cs + half * 8);
+      // B: x[pixel][ci], pixels (row + ky, cs + kx + half * 8 .. + 7), channel cb * 32 + l32:
+      // address lane (4 j + q) -> pixel + j, channels 4 q .. 4 q + 3 of the 16-channel group
+      const unsigned char* sp = xs + (row * PW + cs) * PB;
+      uint4 bf[MAXT];
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
-        const int t = wave + 8 * i;
-        if (t >= ntile) break;   // wave-uniform
-        const int tap = t / cblocks, cb = t - tap * cblocks;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        // B: x[pixel][ci], pixels (row + ky, cs + kx + half * 8 .. + 7), channel cb * 32 + l32:
-        // address lane (4 j + q) -> pixel + j, channels 4 q .. 4 q + 3 of the 16-channel group
-        const unsigned char* xp = xs + ((row + ky) * PW + cs + kx + half * 8 + jrow) * PB +
-                                  (cb * 32 + g16 * 16 + qcol * 4) * 2;
+        const unsigned char* xp = sp + xoff[i];
         const uint2 b0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)xp));
         const uint2 b1 = __builtin_bit_cast(
             uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_seg)(xp + 4 * PB)));
-        const uint4 bf = make_uint4(b0.x, b0.y, b1.x, b1.y);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af),
-                                                         __builtin_bit_cast(bf16x8_t, bf), acc[i], 0, 0,
-                                                         0);
+        bf[i] = make_uint4(b0.x, b0.y, b1.x, b1.y);
       }
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af),
+                                                         __builtin_bit_cast(bf16x8_t, bf[i]), acc[i], 0,
+                                                         0, 0);
     }
   }
   // lanes of half 0 hold co 0..3 of column (tap, cb * 32 + l32) in acc[.][0..3]
@@ -3874,7 +3931,8 @@ constexpr int kThinRows = 4, kThinPH = kThinRows + 2, kThinPW = kThinCols + 2;
 __host__ __device__ inline int thin_pixel_bytes(int cin) { return cin * 2 + 16; }
 __host__ __device__ inline int thin_weight_bytes(int cin) { return 9 * cin * 2 + 16; }
 __host__ __device__ inline size_t thin_lds_bytes(int cin, int cout) {
-  return (size_t)kThinPH * kThinPW * thin_pixel_bytes(cin) + (size_t)cout * thin_weight_bytes(cin);
+  // (+ one all-zero weight row: what the MFMA rows beyond Cout read)
+  return (size_t)kThinPH * kThinPW * thin_pixel_bytes(cin) + (size_t)(cout + 1) * thin_weight_bytes(cin);
 }
 
 __global__ void __launch_bounds__(256)
@@ -3898,50 +3956,64 @@ thin_cout_fwd_kernel(const IgemmParams p) {
       *reinterpret_cast<uint4*>(ws + co * wstride + c * 16) =
           *reinterpret_cast<const uint4*>(w + (int64_t)co * K + c * 8);
     }
+    // row oC: zeros.  The MFMA's A operand has 32 rows and only oC <= 4 carry weights; the other lanes
+    // read this row (one address: a broadcast) instead of zeroing their fragments with four
+    // v_cndmask per read -- that was 570 of the 670 VALU instructions per tile and wave
+    for (int i = tid; i < chunks; i += 256)
+      *reinterpret_cast<uint4*>(ws + p.oC * wstride + i * 16) = make_uint4(0u, 0u, 0u, 0u);
   }
   // Persistent workgroups; the next tile's patch is fetched into registers (NV 16-byte chunks
   // per thread, Cin <= 128) while the current one is computed, and parked in LDS afterwards.
   constexpr int NV = (kThinPH * kThinPW * 16 + 255) / 256;
+  // thread -> (pixel, 16-byte chunk): chunk = tid % cpp, pixels tid / cpp + u * (256 / cpp) -- Cin is
+  // 64 or 128 here, so cpp is a power of two and nothing in the loop divides by a runtime value
+  // (the generic form cost ~100 VALU instructions per load, twice the tile's MFMA cycles)
   const int cpp = C / 8;   // 16-byte chunks per pixel
-  const int total = kThinPH * kThinPW * cpp;
+  const int csh = 31 - __builtin_clz((unsigned)cpp);
+  const int fc = tid & (cpp - 1), fp0 = tid >> csh, fpp = 256 >> csh;
+  const uint32_t utiles_x = (uint32_t)tiles_x, utiles_y = (uint32_t)tiles_y;
+  auto tile_pos = [&](uint32_t t, int& n, int& oy0, int& ox0) {
+    const uint32_t ty_n = t / utiles_x;
+    ox0 = (int)(t - ty_n * utiles_x) * kThinCols;
+    const uint32_t nn = ty_n / utiles_y;
+    oy0 = (int)(ty_n - nn * utiles_y) * kThinRows;
+    n = (int)nn;
+  };
   uint4 nxt[NV];
   auto fetch = [&](int64_t tile) {
-    int64_t b = tile;
-    const int tx = (int)(b % tiles_x);
-    b /= tiles_x;
-    const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
-    const int oy0 = ty * kThinRows, ox0 = tx * kThinCols;
+    int n, oy0, ox0;
+    tile_pos((uint32_t)tile, n, oy0, ox0);
+    const int sy0 = oy0 - p.pad_t, sx0 = ox0 - p.pad_l;
+    const bool interior = sy0 >= 0 && sy0 + kThinPH <= p.sH && sx0 >= 0 && sx0 + kThinPW <= p.sW;
+    const int64_t rowbase = ((int64_t)n * p.sH + sy0) * p.sW;
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
-      const int i = tid + u * 256;
+      const int pix = fp0 + u * fpp;
       nxt[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (i < total) {
-        const int pix = i / cpp, c = i - pix * cpp;
+      if (pix < kThinPH * kThinPW) {
         const int r = pix / kThinPW, q = pix - r * kThinPW;
-        const int sy = oy0 - p.pad_t + r;
-        int sx = ox0 - p.pad_l + q;
-        if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
-        if (sy >= 0 && sy < p.sH && sx >= 0 && sx < p.sW)
+        if (interior) {
           nxt[u] = *reinterpret_cast<const uint4*>(
-              src + (((int64_t)n * p.sH + sy) * p.sW + sx) * C + c * 8);
+              src + ((rowbase + sx0) * C + (int64_t)((r * p.sW + q) * C + fc * 8)));
+        } else {
+          int sx = sx0 + q;
+          if (p.wrap_w) sx = sx < 0 ? sx + p.sW : (sx >= p.sW ? sx - p.sW : sx);
+          if ((unsigned)(sy0 + r) < (unsigned)p.sH && (unsigned)sx < (unsigned)p.sW)
+            nxt[u] = *reinterpret_cast<const uint4*>(
+                src + ((rowbase + (int64_t)r * p.sW + sx) * C + fc * 8));
+        }
       }
     }
   };
   if ((int64_t)blockIdx.x < n_tiles) fetch(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-  int64_t b = tile;
-  const int tx = (int)(b % tiles_x);
-  b /= tiles_x;
-  const int ty = (int)(b % tiles_y), n = (int)(b / tiles_y);
-  const int oy0 = ty * kThinRows, ox0 = tx * kThinCols;
+  int n, oy0, ox0;
+  tile_pos((uint32_t)tile, n, oy0, ox0);
   __syncthreads();   // the previous tile's fragments are read (and, the first time, ws is written)
 #pragma unroll
   for (int u = 0; u < NV; ++u) {
-    const int i = tid + u * 256;
-    if (i < total) {
-      const int pix = i / cpp, c = i - pix * cpp;
-      *reinterpret_cast<uint4*>(xs + pix * pstride + c * 16) = nxt[u];
-    }
+    const int pix = fp0 + u * fpp;
+    if (pix < kThinPH * kThinPW) *reinterpret_cast<uint4*>(xs + pix * pstride + fc * 16) = nxt[u];
   }
   __syncthreads();
   if (tile + gridDim.x < n_tiles) fetch(tile + gridDim.x);
@@ -3954,14 +4026,13 @@ thin_cout_fwd_kernel(const IgemmParams p) {
   for (int tap = 0; tap < 9; ++tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
     const unsigned char* xrow = xs + ((wave + ky) * kThinPW + l32 + kx) * pstride + half * 16;
-    const unsigned char* wrow = ws + (wrow_ok ? l32 : 0) * wstride + tap * C * 2 + half * 16;
+    const unsigned char* wrow = ws + (wrow_ok ? l32 : p.oC) * wstride + tap * C * 2 + half * 16;
     for (int kc = 0; kc < kc_n; kc += 4) {   // Cin % 64 == 0: four fragments per trip
       uint4 xf[4], wf[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         xf[u] = *reinterpret_cast<const uint4*>(xrow + (kc + u) * 32);
         wf[u] = *reinterpret_cast<const uint4*>(wrow + (kc + u) * 32);
-        if (!wrow_ok) wf[u] = make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -4716,16 +4787,29 @@ int se3ds_conv2d_wgrad_swapped(const void* x, const void* dy, float* dw, int dty
     q.x = (const uint16_t*)x; q.dy = (const uint16_t*)dy; q.part = (float*)workspace;
     q.N = n; q.H = h; q.W = w; q.Cin = cin; q.Cout = cout; q.pad = pad;
     const size_t lds = thin_cout_wgrad_lds(cin);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-      if (hipFuncSetAttribute((const void*)thin_cout_wgrad_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return SE3DS_E_LAUNCH;
-      lds_set = lds;
-    }
     int64_t blocks = (int64_t)n * ceil_div(h, kThinQRows) * ceil_div(w, kThinCols);
     if (blocks > kThinQSlabs) blocks = kThinQSlabs;
-    hipLaunchKernelGGL(thin_cout_wgrad_kernel, dim3((unsigned)blocks), dim3(kThinWThreads), lds, s, q);
+    // column tiles per wave: 9 * Cin / 32 tiles dealt to 8 waves
+    const int tiles_per_wave = ceil_div(9 * (cin / 32), 8);
+#define SE3DS_THIN_CW(M)                                                                          \
+  do {                                                                                            \
+    static size_t lds_set = 0;                                                                    \
+    if (lds > lds_set) {                                                                          \
+      if (hipFuncSetAttribute((const void*)thin_cout_wgrad_kernel<M>,                             \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+        return SE3DS_E_LAUNCH;                                                                    \
+      lds_set = lds;                                                                              \
+    }                                                                                             \
+    hipLaunchKernelGGL(thin_cout_wgrad_kernel<M>, dim3((unsigned)blocks), dim3(kThinWThreads), lds, \
+                       s, q);                                                                     \
+  } while (0)
+    switch (tiles_per_wave) {
+      case 2: SE3DS_THIN_CW(2); break;
+      case 3: SE3DS_THIN_CW(3); break;
+      case 4: SE3DS_THIN_CW(4); break;
+      default: SE3DS_THIN_CW(5); break;
+    }
+#undef SE3DS_THIN_CW
     const int64_t tnel = (int64_t)9 * cin * cout;
     launch_wgrad_reduce((const float*)workspace, (int)blocks, tnel, accumulate, nullptr, dw, s);
     return check_launch("conv2d_wgrad(thin cout)");

@@ -14,6 +14,7 @@
 #   pmc_warp_valu TAG           VALU / LDS counters of the warp kernels (1 pass) -> gpurun_out/TAG_warp_valu_pmc.json
 #   pmc_step TAG [ENV=v ...]    MFMA-busy + shader clock of every kernel inside the step (1 pass, tools/pmc_step.py)
 #   prof_py TAG <file.py> [args] rocprofv3 kernel stats of any python tool -> gpurun_out/TAG_kernel_stats.csv
+#   pmc_py TAG "PMC ..." REGEX <file.py> [args]   one --pmc pass over any python tool -> gpurun_out/TAG_pmc.json
 #   py <file.py> [args]         any python tool
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -123,6 +124,20 @@ task_prof_py() {
   python tools/rocpd_summary.py gpurun_out/prof_tmp/run_results.db gpurun_out/${tag}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python $*"
   head -${PROF_HEAD:-16} gpurun_out/${tag}_kernel_stats.csv | cut -c1-160
   rm -rf gpurun_out/prof_tmp
+}
+task_pmc_py() {
+  local tag=$1 pmc="$2" re="$3"; shift; shift; shift
+  rm -rf gpurun_out/pmc_tmp_g
+  rocprofv3 --kernel-trace --pmc $pmc -d gpurun_out/pmc_tmp_g -o pmc -- python "$@" > /dev/null 2>&1
+  python tools/pmc_summary.py gpurun_out/${tag}_pmc.json "gpurun_out/pmc_tmp_g/*.db" "$re"
+  python - gpurun_out/${tag}_pmc.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1]))
+for k, v in d.items():
+  if k.startswith('_'): continue
+  print(k[:60], ' '.join('%s=%.4g' % (a, (b['avg'] if isinstance(b, dict) else b)) for a, b in v.items()))
+PY
+  rm -rf gpurun_out/pmc_tmp_g
 }
 task_py() { timeout 1500 python "$@"; }
 args=()
