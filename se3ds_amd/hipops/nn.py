@@ -1105,6 +1105,15 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
         cache[key] = (ratio, um, ru, bu, m)   # (m: keeps the keyed storage alive)
     else:
       ratio, um, ru, bu = ent[:4]
+    if in_mask is not None and k == 1 and ctx.binary_masks and _DROP_1X1_MASK:
+      # A 1 x 1 partial conv with a {0, 1} mask does not need x * mask: its window IS the pixel, so
+      # ratio = update_mask = 0 exactly where the mask is 0 and the epilogue's `* ratio` (and
+      # `* update_mask` behind the bias) zeroes those outputs whatever the product was (activations
+      # are finite); backward, dy * ratio * update_mask is 0 there, so neither the weight gradient
+      # nor dx sees the masked pixels.  Without the mask the kernels skip one dependent global load
+      # (mask -> source address of the first LDS-DMA) at the head of every workgroup: ~10 us of a
+      # 60 us launch on the encoder's 512 <-> 2048 bottleneck convs.
+      in_mask = None
   # SpectralConv convolves with W/(sigma+eps); PartialSpectralConv with the raw kernel.
   scale = layer.sn['sig'][1:] if layer.kind == 'spectral' else None
   bias = layer.bias
@@ -1369,6 +1378,8 @@ _NORM_CG = os.environ.get('SE3DS_NORM_CG', '1') != '0'
 _CONVT_2X2 = os.environ.get('SE3DS_CONVT_2X2', '1') != '0'
 # SE3DS_MASK_CACHE=0: every partial conv launches its own mask-window kernel
 _MASK_CACHE = os.environ.get('SE3DS_MASK_CACHE', '1') != '0'
+# SE3DS_DROP_1X1_MASK=0: 1 x 1 partial convs with a binary mask still multiply their input by it
+_DROP_1X1_MASK = os.environ.get('SE3DS_DROP_1X1_MASK', '1') != '0'
 
 
 def norm_act(ctx: Ctx, x: Var, layer: NormLayer, act=ACT_NONE, alpha=0.0, res: Var = None,

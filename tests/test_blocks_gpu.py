@@ -405,11 +405,14 @@ def test_round5_kernel_choices_match_their_predecessors(case, monkeypatch):
   (b) SE3DS_CONVT_2X2 (nn._CONVT_2X2): 2x2 stride-2 transposed convs as two pitched 1x1 convolutions
       (se3ds_conv_transpose2x2_fwd) instead of the parity-class data-gradient kernel: BIT-identical;
   (c) SE3DS_MASK_CACHE (nn._MASK_CACHE): partial convs that see the same mask tensor share one
-      mask-window launch: BIT-identical."""
+      mask-window launch: BIT-identical;
+  (d) SE3DS_DROP_1X1_MASK (nn._DROP_1X1_MASK): 1 x 1 partial convs with a {0, 1} mask leave x * mask
+      to the epilogue's `* ratio * update_mask` (both 0 exactly where the mask is 0): equal values
+      everywhere (a masked output may change the sign of its zero)."""
   base, cnt = _run_block_bf16(case, {})
   wide = case.name.startswith(('bottleneck', 'trans_basic', 'upsampling'))   # batch norms with C >= 512
   assert cnt.get('cg', 0) >= (1 if wide else 0), cnt
-  for name in ('_CONVT_2X2', '_MASK_CACHE'):
+  for name in ('_CONVT_2X2', '_MASK_CACHE', '_DROP_1X1_MASK'):
     got, _ = _run_block_bf16(case, {name: False})
     for k, b in base.items():
       assert torch.equal(got[k], b), (name, k)

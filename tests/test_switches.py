@@ -23,6 +23,7 @@ OWNERS = {
     'SE3DS_NORM_CG': ('tests/test_blocks_gpu.py', 'SE3DS_NORM_CG'),
     'SE3DS_CONVT_2X2': ('tests/test_blocks_gpu.py', '_CONVT_2X2'),
     'SE3DS_MASK_CACHE': ('tests/test_blocks_gpu.py', '_MASK_CACHE'),
+    'SE3DS_DROP_1X1_MASK': ('tests/test_blocks_gpu.py', '_DROP_1X1_MASK'),
     'SE3DS_FUSED_BN_BWD': ('tests/test_blocks_gpu.py', '_FUSED_BN_BWD'),
     'SE3DS_FUSED_ROW_SCALE': ('tests/test_blocks_gpu.py', '_FUSED_ROW_SCALE'),
     'SE3DS_NORM_DEBUG': ('tests/test_blocks_gpu.py', '_NORM_DEBUG'),
