@@ -54,6 +54,27 @@ template <> struct TT<uint16_t> {  // bf16 raw bits
   static __device__ __forceinline__ uint16_t from_f(float v) { return f32_to_bf16(v); }
 };
 
+// Division of a 32-bit unsigned value by a runtime constant, multiplier and shifts from the host
+// (Granlund-Montgomery): q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(n, m); exact for every
+// n < 2^32.  Tile row -> (image, row, column) is four of these pairs per thread at the head of a
+// workgroup and four more in front of its epilogue; as 64-bit / 32-bit hardware-less divisions they
+// were ~1 000 VALU instructions per tile on the critical path (~2 us of a 25 us 1x1 tile).
+struct FastDiv { uint32_t m, s1, s2; };
+inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  if (d == 0) d = 1;
+  uint32_t l = 0;
+  while (l < 32 && ((uint64_t)1 << l) < d) ++l;
+  f.m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l - f.s1;
+  return f;
+}
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, const FastDiv& f) {
+  const uint32_t t = __umulhi(n, f.m);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 struct IgemmParams {
   // source tensor of the gather (x for FWD, dy for DGRAD) and its dims
   const void* src; int sH, sW, sC;
@@ -64,6 +85,7 @@ struct IgemmParams {
   int kh, kw, stride, pad_t, pad_l, wrap_w;
   // DGRAD parity classes (stride^2 of them); FWD uses class 0 only
   int n_classes; int cls_tile_start[5]; int cls_py[4], cls_px[4];
+  FastDiv fd_hw[4], fd_w[4];   // division by a class's cH * cW and cW (fill_classes)
   // gather-side per-pixel multiplier (partial conv: x * mask), (N,sH,sW) fp32 or null
   const float* src_mask;
   int mask_binary;        // src_mask holds only {0,1}: masked rows may be fetched from the zero page
@@ -105,6 +127,16 @@ struct IgemmParams {
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+// row m of a class's pixel list -> (image, row, column) of the class sub-grid (m < N * cH * cW < 2^31)
+__device__ __forceinline__ void pix_of(const IgemmParams& p, int cls, int64_t m, int cH, int cW, int& n,
+                                       int& a, int& b) {
+  const uint32_t mu = (uint32_t)m;
+  const uint32_t nn = fd_div(mu, p.fd_hw[cls]);
+  const uint32_t rem = mu - nn * (uint32_t)(cH * cW);
+  const uint32_t aa = fd_div(rem, p.fd_w[cls]);
+  n = (int)nn; a = (int)aa; b = (int)(rem - aa * (uint32_t)cW);
+}
 
 template <typename T>
 __device__ __forceinline__ void mfma_tile(f32x16_t (&acc)[2][2], const uint4 (&wf)[2][2],
@@ -657,7 +689,7 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)
                                            int64_t m_base, int co_base, int64_t Mc, int cH, int cW,
                                            int py, int px, int half, int l32,
                                            unsigned char* scratch = nullptr,
-                                           float* stats_row = nullptr) {
+                                           float* stats_row = nullptr, int cls = 0) {
   const int s = p.stride;
   const float scale = p.scale ? *p.scale : 1.0f;
   int64_t opix[2];
@@ -666,9 +698,8 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)
     int64_t m = m_base + j * 32 + l32;
     opix[j] = -1;
     if (m >= Mc) continue;
-    int n = (int)(m / ((int64_t)cH * cW));
-    int rem = (int)(m - (int64_t)n * cH * cW);
-    int a = rem / cW, b = rem - a * cW;
+    int n, a, b;
+    pix_of(p, cls, m, cH, cW, n, a, b);
     if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
     opix[j] = ((int64_t)n * p.oH + a) * p.o_pitch + p.o_off + b;
   }
@@ -694,7 +725,8 @@ __device__ __forceinline__ void store_tile(const IgemmParams& p, f32x16_t (&acc)
 template <int MODE, int CB, bool BNB = false>
 __device__ __forceinline__ void store_tile16(const IgemmParams& p, f32x4_t (&acc)[CB][4], int64_t m_base,
                                              int co_base, int64_t Mc, int cH, int cW, int py, int px,
-                                             int lane, unsigned char* scratch, float* stats_row) {
+                                             int lane, unsigned char* scratch, float* stats_row,
+                                             int cls = 0) {
   const int s = p.stride;
   int64_t opix[4];
 #pragma unroll
@@ -702,9 +734,8 @@ __device__ __forceinline__ void store_tile16(const IgemmParams& p, f32x4_t (&acc
     const int64_t m = m_base + j * 16 + (lane & 15);
     opix[j] = -1;
     if (m >= Mc) continue;
-    const int n = (int)(m / ((int64_t)cH * cW));
-    const int rem = (int)(m - (int64_t)n * cH * cW);
-    int a = rem / cW, b = rem - a * cW;
+    int n, a, b;
+    pix_of(p, cls, m, cH, cW, n, a, b);
     if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
     opix[j] = ((int64_t)n * p.oH + a) * p.o_pitch + p.o_off + b;
   }
@@ -759,9 +790,8 @@ igemm_kernel(const IgemmParams p) {
     int64_t m = (int64_t)tile_m * BM + srow + h * 64;
     ri[h].valid = m < Mc;
     int64_t mm = ri[h].valid ? m : 0;
-    int n = (int)(mm / ((int64_t)cH * cW));
-    int rem = (int)(mm - (int64_t)n * cH * cW);
-    int a = rem / cW, b = rem - a * cW;
+    int n, a, b;
+    pix_of(p, cls, mm, cH, cW, n, a, b);
     ri[h].n = n;
     ri[h].a = MODE == MODE_DGRAD ? py + a * s : a;
     ri[h].b = MODE == MODE_DGRAD ? px + b * s : b;
@@ -937,7 +967,7 @@ igemm_kernel(const IgemmParams p) {
   }
 
   store_tile<T, MODE>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py, px,
-                      half, l32);
+                      half, l32, nullptr, nullptr, cls);
 }
 
 // ------------------------------------------------------------------ LDS-DMA implicit GEMM
@@ -1019,9 +1049,8 @@ igemm_glds_kernel(const IgemmParams p) {
     int64_t m = (int64_t)tile_m * BM + row;
     ri[j].valid = m < Mc;
     int64_t mm = ri[j].valid ? m : 0;
-    int n = (int)(mm / ((int64_t)cH * cW));
-    int rem = (int)(mm - (int64_t)n * cH * cW);
-    int a = rem / cW, b = rem - a * cW;
+    int n, a, b;
+    pix_of(p, cls, mm, cH, cW, n, a, b);
     ri[j].n = n;
     ri[j].a = MODE == MODE_DGRAD ? py + a * s : a;
     ri[j].b = MODE == MODE_DGRAD ? px + b * s : b;
@@ -1201,10 +1230,10 @@ igemm_glds_kernel(const IgemmParams p) {
                          ? p.stats + ((int64_t)(tile_m * (BM / 64) + wn) * 2) * p.oC : nullptr;
   if constexpr (M16) {
     store_tile16<MODE, 4, BNB>(p, acc16, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py, px,
-                               lane, stage0 + wave * kEpiScratch<2>, stats_row);
+                               lane, stage0 + wave * kEpiScratch<2>, stats_row, cls);
   } else {
   store_tile<T, MODE, 2, BNB>(p, acc, (int64_t)tile_m * BM + wn * 64, n0 + wm * 64, Mc, cH, cW, py,
-                              px, half, l32, stage0 + wave * kEpiScratch<2>, stats_row);
+                              px, half, l32, stage0 + wave * kEpiScratch<2>, stats_row, cls);
   }
 }
 
@@ -1275,9 +1304,8 @@ igemm_big_kernel(const IgemmParams p) {
     const int64_t m = (int64_t)tile_m * PIX + row;
     const bool valid = m < Mc;
     const int64_t mm = valid ? m : 0;
-    const int n = (int)(mm / ((int64_t)cH * cW));
-    const int rem = (int)(mm - (int64_t)n * cH * cW);
-    int a = rem / cW, b = rem - a * cW;
+    int n, a, b;
+    pix_of(p, cls, mm, cH, cW, n, a, b);
     if (MODE == MODE_DGRAD) { a = py + a * s; b = px + b * s; }
     a0[j] = MODE == MODE_FWD ? a * s - p.pad_t : a + p.pad_t;
     b0[j] = MODE == MODE_FWD ? b * s - p.pad_l : b + p.pad_l;
@@ -1492,12 +1520,13 @@ igemm_big_kernel(const IgemmParams p) {
     if ((p.oC & 7) == 0) {   // (always: oC % CO == 0)
       store_tile16<MODE, CB16, BNB>(p, acc16, (int64_t)tile_m * PIX + wn * 64, n0 + wm * (CO / 2), Mc, cH,
                                     cW, py, px, lane,
-                                    (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>, stats_row);
+                                    (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>, stats_row,
+                                    cls);
     }
   } else {
   store_tile<T, MODE, NI, BNB>(p, acc, (int64_t)tile_m * PIX + wn * 64, n0 + wm * (CO / 2), Mc, cH, cW,
                           py, px, half, l32,
-                          (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>, stats_row);
+                          (wave < 4 ? stage0 : stage1) + (wave & 3) * kEpiScratch<NI>, stats_row, cls);
   }
 }
 
@@ -4164,6 +4193,8 @@ int fill_classes(IgemmParams& p, int mode, int bm = BM) {
     int64_t m = (int64_t)p.N * p.oH * p.oW;
     total = (int)ceil_div(m, bm);
     p.cls_tile_start[1] = total;
+    p.fd_hw[0] = make_fastdiv((uint32_t)(p.oH * p.oW));
+    p.fd_w[0] = make_fastdiv((uint32_t)p.oW);
     return total;
   }
   const int s = p.stride;
@@ -4176,6 +4207,8 @@ int fill_classes(IgemmParams& p, int mode, int bm = BM) {
       int cH = (p.oH - py + s - 1) / s, cW = (p.oW - px + s - 1) / s;
       if (cH < 0) cH = 0;
       if (cW < 0) cW = 0;
+      p.fd_hw[c] = make_fastdiv((uint32_t)(cH * cW));
+      p.fd_w[c] = make_fastdiv((uint32_t)cW);
       total += (int)ceil_div((int64_t)p.N * cH * cW, bm);
     }
   p.cls_tile_start[c] = total;
@@ -4289,6 +4322,9 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
   // stride-1 'same width' case (inference-mode backward through strided convs is not needed)
   if (wrap_w && mode == MODE_DGRAD && (stride != 1 || wo != wdt)) return SE3DS_E_UNSUPPORTED;
   if (dtype != SE3DS_F32 && dtype != SE3DS_BF16) return SE3DS_E_BADDTYPE;
+  // (pixel lists are indexed with 32 bits: FastDiv)
+  if ((int64_t)n * h * wdt >= ((int64_t)1 << 31) || (int64_t)n * ho * wo >= ((int64_t)1 << 31))
+    return SE3DS_E_BADSHAPE;
   IgemmParams p;
   p.src = src; p.w = w; p.out = out;
   p.N = n; p.kh = kh; p.kw = kw; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
