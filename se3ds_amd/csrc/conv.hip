@@ -3200,7 +3200,7 @@ constexpr int kThinDRows = 8, kThinCols = 32;
 constexpr int kThinDCinMax = 256;
 __global__ void __launch_bounds__(256)
 thin_cout_dgrad_kernel(const IgemmParams p) {
-  constexpr int NI = 2;   // 64 output channels per pass (keeps three workgroups on a CU)
+  constexpr int NI = 2;   // 64 output channels per pass (32 accumulator registers per lane less than 128 channels per pass)
   constexpr int PH = kThinDRows + 2, PW = kThinCols + 2, KP = 48;   // K padded to 3 MFMA steps
   __shared__ __attribute__((aligned(16))) unsigned char scratch[4][kEpiScratch<NI>];
   __shared__ __attribute__((aligned(16))) uint16_t dys[PH * PW * 4];
@@ -4393,7 +4393,9 @@ static int conv_common(int mode, const void* src, const void* w, void* out, int 
       (cin % 64) == 0 && cin <= kThinDCinMax && src_mask == nullptr && row_a == nullptr &&
       thin_on()) {
     int64_t blocks = (int64_t)p.N * ceil_div(p.oH, kThinDRows) * ceil_div(p.oW, kThinCols);
-    if (blocks > 3 * 256) blocks = 3 * 256;   // persistent: three workgroups per CU
+    // persistent: two workgroups per CU (236 registers per lane: the third does not fit, and a grid
+    // of three per CU ran its last third at half occupancy)
+    if (blocks > 2 * 256) blocks = 2 * 256;
     hipLaunchKernelGGL(thin_cout_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p);
     return check_launch("conv2d_dgrad(thin)");
   }
