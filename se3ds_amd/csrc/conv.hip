@@ -3457,8 +3457,10 @@ thin_cin_wgrad_kernel(const ThinCinWgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l32 = lane & 31;
+  // (rows k >= K of the im2col operand read the pixel's first element: their accumulator rows are
+  // never stored -- no per-element select in the gather)
   for (int k = tid; k < kThinKMax; k += NT) {
-    int o = -1;
+    int o = 0;
     if (k < K) {
       const int tap = k / Ci, ci = k - tap * Ci;
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -3473,7 +3475,7 @@ thin_cin_wgrad_kernel(const ThinCinWgradParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int mb = (wave + 8 * i) >> 2;
-    ko[i] = mb < MB ? koff[mb * 32 + l32] : -1;
+    ko[i] = mb < MB ? koff[mb * 32 + l32] : 0;
   }
   f32x16_t acc[4];
 #pragma unroll
@@ -3579,7 +3581,7 @@ thin_cin_wgrad_kernel(const ThinCinWgradParams p) {
         if (((wave + 8 * i) >> 2) >= MB) break;   // wave-uniform
         uint16_t ea[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ea[j] = ko[i] >= 0 ? xs[xbase + ko[i] + j * st * Ci] : (uint16_t)0;
+        for (int j = 0; j < 8; ++j) ea[j] = xs[xbase + ko[i] + j * st * Ci];
         const uint4 af = make_uint4((uint32_t)ea[0] | ((uint32_t)ea[1] << 16), (uint32_t)ea[2] | ((uint32_t)ea[3] << 16),
                                     (uint32_t)ea[4] | ((uint32_t)ea[5] << 16), (uint32_t)ea[6] | ((uint32_t)ea[7] << 16));
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af),
@@ -3831,8 +3833,10 @@ thin_cin_fwd_kernel(const IgemmParams p) {
   const int64_t n_tiles = (int64_t)p.N * tiles_y * tiles_x;
   const uint16_t* __restrict__ src = (const uint16_t*)p.src;
   const uint16_t* __restrict__ wt = (const uint16_t*)p.w;   // wt [oC][K], k = (ky * kw + kx) * Ci + ci
+  // (padding elements k >= K read the pixel's first element: their weights are zero, the product
+  // vanishes -- no per-element select in the gather)
   for (int k = tid; k < KP; k += NT) {
-    int o = -1;
+    int o = 0;
     if (k < K) {
       const int tap = k / Ci, ci = k - tap * Ci;
       const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -3920,7 +3924,7 @@ thin_cin_fwd_kernel(const IgemmParams p) {
           const int base = j ? base1 : base0;
           uint16_t e[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) e[q] = o[q] >= 0 ? xs[base + o[q]] : (uint16_t)0;
+          for (int q = 0; q < 8; ++q) e[q] = xs[base + o[q]];
           xf[j] = make_uint4((uint32_t)e[0] | ((uint32_t)e[1] << 16), (uint32_t)e[2] | ((uint32_t)e[3] << 16),
                              (uint32_t)e[4] | ((uint32_t)e[5] << 16), (uint32_t)e[6] | ((uint32_t)e[7] << 16));
         }

@@ -135,7 +135,7 @@ import json, sys
 d = json.load(open(sys.argv[1]))
 for k, v in d.items():
   if k.startswith('_'): continue
-  print(k[:60], ' '.join('%s=%.4g' % (a, (b['avg'] if isinstance(b, dict) else b)) for a, b in v.items()))
+  print(k[:60], ' '.join('%s=%.4g' % (a, (b['avg'] if isinstance(b, dict) and 'avg' in b else b)) for a, b in v.items() if not isinstance(b, dict) or 'avg' in b))
 PY
   rm -rf gpurun_out/pmc_tmp_g
 }
