@@ -362,6 +362,9 @@ int se3ds_conv2d_wgrad_partial(const void* x, const void* dy, float* dw, int dty
                                size_t workspace_bytes, int64_t* reduce_row, void* stream);
 int se3ds_wgrad_reduce_multi(const int64_t* table, int rows, int64_t workgroups, void* stream);
 int se3ds_wgrad_reduce_tile(void);
+/* n / d as the convolution kernels compute it for tile row -> (image, row, column): the host-made
+ * multiplier and shifts, evaluated on the host (test hook: no device work).  d >= 1. */
+uint32_t se3ds_fastdiv_host(uint32_t n, uint32_t d);
 
 /* Weight gradient of a THIN-Cout (cout <= 16), stride-1, same-size conv (the generator's
  * 128->3 / 128->1 output convs, image_models.py:93-104) computed with the operand roles

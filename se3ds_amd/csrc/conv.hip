@@ -4790,6 +4790,15 @@ int se3ds_wgrad_reduce_multi(const int64_t* table, int rows, int64_t workgroups,
 
 int se3ds_wgrad_reduce_tile(void) { return kRedTile; }
 
+// Host-side evaluation of the division the conv kernels use for tile row -> (image, row, column)
+// (FastDiv: multiplier and shifts made by make_fastdiv, quotient formed exactly as fd_div forms it
+// on the device): the CPU suite checks it against n / d without a GPU.
+uint32_t se3ds_fastdiv_host(uint32_t n, uint32_t d) {
+  const FastDiv f = make_fastdiv(d);
+  const uint32_t t = (uint32_t)(((uint64_t)n * f.m) >> 32);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 // thin-Cout layers through the tap-fused kernel (padded dy copy): split count, 0 = not eligible
 static int wgrad_taps_thin_splits(int n, int h, int w, int cin, int cout, int k, int* steps) {
   if (k != 3 || cout > 8 || (cin % 64) != 0) return 0;

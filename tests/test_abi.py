@@ -41,3 +41,24 @@ def test_no_cpu_fallback():
   from se3ds_amd.utils import pano_utils
   with pytest.raises(_lib.Se3dsHipError):
     pano_utils.mask_pano(torch.zeros((1, 8, 16, 3)))
+
+
+def test_fastdiv_matches_integer_division():
+  """The conv kernels turn a tile row into (image, row, column) with host-made multipliers instead of
+  divisions (csrc/conv.hip FastDiv: q = (t + ((n - t) >> s1)) >> s2, t = mulhi(n, m)).  The same
+  arithmetic evaluated on the host (se3ds_fastdiv_host) must equal n // d for every divisor class:
+  1, powers of two, odd, the image sizes of the configs, large -- at the edges of the 32-bit range."""
+  import random
+  import se3ds_amd.hipops  # noqa: F401
+  L = _lib.lib()
+  rng = random.Random(5)
+  divisors = [1, 2, 3, 5, 7, 16, 17, 31, 32, 33, 64, 129, 255, 256, 257, 512, 513, 1024, 2048, 32 * 64,
+              129 * 257, 512 * 1024, 1024 * 2048, 1000003, 2 ** 20 + 1, 2 ** 30, 2 ** 31 - 1, 2 ** 31,
+              2 ** 32 - 1] + [rng.randrange(1, 2 ** 31) for _ in range(40)]
+  for d in divisors:
+    ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 1]
+    ns += [k * d + r for k in (3, 1000, 65535) for r in (-1, 0, 1)]
+    ns += [rng.randrange(0, 2 ** 32) for _ in range(200)]
+    for n in ns:
+      if 0 <= n < 2 ** 32:
+        assert L.se3ds_fastdiv_host(n, d) == n // d, (n, d)
