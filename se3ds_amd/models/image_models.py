@@ -345,8 +345,26 @@ class ResNetGenerator(_Model):
     x = Var(nn.concat_channels(ctx, [p.to(torch.float32) for p in parts]), requires_grad=False)
     n, h, w, _ = x.shape
     mask = gm.to(torch.float32).reshape(n, h, w).contiguous()
-    self.spectral.power_iteration(ctx.training)
+    # The power iteration reads every spectral kernel twice (2.8 ms alone, HBM-bound) and nothing in
+    # the encoder needs its result: PartialSpectralConv convolves with the raw kernel
+    # (layers.py:189-195), sigma is first applied by the context convs.  With branch streams it runs
+    # on the first decoder's stream under the encoder's forward pass; the main stream waits for it in
+    # front of the context module (the decoders' streams are ordered behind the main stream there).
+    # Same-box A/B: 190.9 / 191.1 vs 191.6 / 191.8 ms per step; bit-identical to the serial order
+    # (tools/step_compare.py).
+    sn_ev = None
+    if ctx.streams is not None and 'fwd' in ctx.stream_phases:
+      side = ctx.streams[1]
+      side.wait_stream(torch.cuda.current_stream(ctx.device))
+      with torch.cuda.stream(side):
+        self.spectral.power_iteration(ctx.training)
+        sn_ev = torch.cuda.Event()
+        sn_ev.record()
+    else:
+      self.spectral.power_iteration(ctx.training)
     hidden, skip = self.encoder(ctx, x, mask)   # (marks its own segments)
+    if sn_ev is not None:
+      torch.cuda.current_stream(ctx.device).wait_event(sn_ev)
     taps = getattr(ctx, 'taps', None)
     if taps is not None:
       taps.update(b1=skip[0], s1=skip[1], s2=skip[2], s3=skip[3], enc=hidden)
