@@ -92,6 +92,11 @@ THIN_CASES = [
     ('spectral', 128, 1, 3, 1, 'VALID', 1, False, True, False, 2, 9, 37),     # ragged tiles
     ('plain', 64, 3, 3, 1, 'VALID', 1, True, False, False, 1, 16, 32),        # circular width
     ('plain', 256, 4, 3, 1, 'SAME', 0, False, True, False, 1, 7, 45),         # SAME padding, 4 rows
+    # the weight-gradient kernel's other instantiations: 9 * Cin / 32 column tiles dealt to 8 waves
+    # = 2 per wave (Cin 32), 4 (Cin 96: also the only channel count whose patch fetch takes the
+    # generic, non-power-of-two indexing)
+    ('spectral', 32, 3, 3, 1, 'VALID', 1, False, True, False, 2, 17, 40),
+    ('plain', 96, 2, 3, 1, 'VALID', 1, False, False, False, 1, 20, 70),
 ]
 
 
