@@ -7,6 +7,7 @@ from se3ds_amd import _lib
 from se3ds_amd import hipops  # noqa
 L = _lib.lib()
 DEV = 'cuda:0'
+ACT = int(os.environ.get('ACT', '1'))   # activation kind of the norm (0 none, 1 relu): selects the kernel variants
 shapes = [(8, 512, 1024, 128, False), (8, 256, 512, 128, True), (8, 128, 256, 128, True),
           (8, 64, 128, 256, True), (8, 32, 64, 512, True), (8, 32, 64, 1024, True), (8, 32, 64, 2048, True)]
 def timeit(fn, reps=20):
@@ -28,15 +29,15 @@ for n, h, w, c, with_res in shapes:
   s = _lib.stream()
   nb = r * c * 2
   ta = timeit(lambda: L.se3ds_norm_apply(x.data_ptr(), 3, 1, r, c, scale.data_ptr(), shift.data_ptr(),
-                                         res.data_ptr() if with_res else None, None, 1, 0.0,
-                                         y.data_ptr(), amask.data_ptr(), s))
+                                         res.data_ptr() if with_res else None, None, ACT, 0.0,
+                                         y.data_ptr(), amask.data_ptr() if ACT else None, s))
   ts = timeit(lambda: L.se3ds_norm_bwd_stats(dy.data_ptr(), y.data_ptr(), x.data_ptr(), 3, 1, r, c,
-                                             mean.data_ptr(), rstd.data_ptr(), 1, 0.0, sums.data_ptr(),
-                                             None, None, amask.data_ptr(), ws.data_ptr(), ws.numel(), s))
+                                             mean.data_ptr(), rstd.data_ptr(), ACT, 0.0, sums.data_ptr(),
+                                             None, None, amask.data_ptr() if ACT else None, ws.data_ptr(), ws.numel(), s))
   tb = timeit(lambda: L.se3ds_norm_bwd_apply(dy.data_ptr(), y.data_ptr(), x.data_ptr(), 3, 1, r, c,
                                              mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
-                                             sums.data_ptr(), float(r), 1, 0.0, dx.data_ptr(),
-                                             dres.data_ptr() if with_res else None, amask.data_ptr(),
+                                             sums.data_ptr(), float(r), ACT, 0.0, dx.data_ptr(),
+                                             dres.data_ptr() if with_res else None, amask.data_ptr() if ACT else None,
                                              0, 0.0, s))
   ba = nb * (2 + (1 if with_res else 0)) + nb / 16
   bs = nb * 2 + nb / 16
