@@ -162,9 +162,13 @@ SE3DS_HD int32_t se3ds_splat_index(float px, float py, float pz, int width, int 
  * accept the index when fx and fy are farther than a margin
  * from every integer -- then no integer lies between the fast and the exact value and
  * trunc / range tests agree.  Everything else takes the exact path.  The margin
- * SE3DS_FAST_MARGIN * size is >= 16x the largest deviation tests/test_oracle_warp.py measures.
+ * SE3DS_FAST_MARGIN * size is >= 8x the largest deviation tests/test_oracle_warp.py measures
+ * (1.8e-7 * size = 2.3 ulp of the heading, the same on 64 .. 2048-row images; the device's screen with
+ * its hardware reciprocal / square root is bounded by tests/test_warp_gpu.py).  Round 6 halved it
+ * (4e-6 -> 2e-6): the undecided points cost a dense binary64 pass per chunk -- 20 % of the sorted
+ * splat's first kernel at 1024 x 2048 -- and their number is proportional to the margin.
  * z (= rad) does not depend on the transcendentals and is the same op in both paths. */
-#define SE3DS_FAST_MARGIN 4.0e-6f
+#define SE3DS_FAST_MARGIN 2.0e-6f
 
 /* Reciprocal / square root of the SCREEN only: on the device the 1-ulp hardware approximations
  * (v_rcp_f32 / v_sqrt_f32: one instruction instead of the ~10-instruction IEEE sequences), on the

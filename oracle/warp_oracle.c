@@ -6,7 +6,8 @@
  * Transcendentals come from include/se3ds_geom_math.h (binary64 evaluation, IEEE basic ops
  * only), so this file is the bit-exact CPU twin of the HIP kernels; oracle/warp_np.py is
  * the independent NumPy statement (libm) that tests hold it against, together with the
- * reference's golden vectors (tests/test_oracle_golden.py).
+ * reference's golden vectors (tests/test_oracle_warp.py: the pixel-ray array, the plane at 1 m,
+ * the >= 95 % round trip; fixtures in tests/golden/reference_literals.npz).
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  * Build: make -C oracle   (gcc -O2 -ffp-contract=off)
  */

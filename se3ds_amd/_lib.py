@@ -6,7 +6,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, 'csrc', 'libse3ds_hip.so')
+# SE3DS_LIB: another build of the library for this process (the A/B scripts under tools/probes/ compare
+# two builds on one box; they used to copy over the in-tree file and a killed job left the wrong one
+# behind -- ADVICE r5).  Unset: the in-tree build, the only one the tests and the bench ever load.
+SO_PATH = os.environ.get('SE3DS_LIB') or os.path.join(_HERE, 'csrc', 'libse3ds_hip.so')
 
 F32, I32, U8, BF16 = 0, 1, 2, 3
 _DTYPE_CODE = {torch.float32: F32, torch.int32: I32, torch.uint8: U8, torch.bfloat16: BF16}

@@ -210,12 +210,14 @@ constexpr int kPromiseStickyWord = 3;
 // workgroup stores the epoch into ctl[kPromiseEpochWord], and the reader compares the two.  Round 4
 // zeroed ctl[1] from block (0, 0) of the same launch whose other blocks OR into it: a block that
 // finished before block (0, 0) started lost its bit.  Nothing is zeroed now.
+// ctl[1] is never initialised (the workspace is caller memory and the control words move with n * m):
+// an epoch carries a tag in its upper byte so that left-over data -- small counts, histogram words --
+// cannot equal the current one (a 24-bit call counter under 0xA5).
 constexpr int kPromiseEpochWord = 6;
+constexpr uint32_t kEpochTag = 0xA5000000u, kEpochTagMask = 0xff000000u;
 inline uint32_t next_splat_epoch() {
   static std::atomic<uint32_t> epoch{0};
-  uint32_t e = ++epoch;
-  if (e == 0u) e = ++epoch;
-  return e;
+  return kEpochTag | (++epoch & ~kEpochTagMask);
 }
 struct SplatWs {
   uint32_t* sink_z;
@@ -457,21 +459,103 @@ splat_finalize_kernel(float* __restrict__ depth, float* __restrict__ feat,
   }
 }
 
+// ---- the fp32 index screen of TWO points at a time on the packed fp32 pipe (round 6).
+// S1 is VALU-bound (profiles/r05_warp_valu_pmc.json: 3 719 VALU instructions per 1 024-point wave = 232 per
+// point, VALU 0.73 busy).  gfx950 issues v_pk_mul / v_pk_add / v_pk_fma_f32 -- two lanes' worth of work
+// per issue slot -- so the screen (se3ds_equirect_fxy_fast: sum of squares, two polynomial arc tangents,
+// the scalings) runs on float2 pairs: the same operations in the same order, each individually rounded
+// (no contraction in this file), so rad -- an OUTPUT -- is bit for bit the scalar chain's.  Selects,
+// the IEEE square root and the IEEE quotient z / rad stay per point.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) {
+  f32x2 r = {v, v};
+  return r;
+}
+// se3ds_atan2_fast on two points.  POS_Y: both y are >= 0 (the elevation's sqrt term): no sign step.
+template <bool POS_Y>
+__device__ __forceinline__ f32x2 atan2_fast2(f32x2 y, f32x2 x) {
+  const float ay0 = __builtin_fabsf(y.x), ax0 = __builtin_fabsf(x.x);
+  const float ay1 = __builtin_fabsf(y.y), ax1 = __builtin_fabsf(x.y);
+  const bool sw0 = ay0 > ax0, sw1 = ay1 > ax1;
+  const f32x2 a = {sw0 ? ax0 : ay0, sw1 ? ax1 : ay1};
+  const f32x2 b = {sw0 ? ay0 : ax0, sw1 ? ay1 : ax1};
+  const f32x2 rb = {__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+  const f32x2 q = a * rb;   // b == 0 -> NaN / inf -> the margin test fails
+  const f32x2 sq = q * q;
+  f32x2 p = splat2(-0.004668773151934147f);
+  p = __builtin_elementwise_fma(p, sq, splat2(0.02416618913412094f));
+  p = __builtin_elementwise_fma(p, sq, splat2(-0.0593671016395092f));
+  p = __builtin_elementwise_fma(p, sq, splat2(0.09906096756458282f));
+  p = __builtin_elementwise_fma(p, sq, splat2(-0.14016585052013397f));
+  p = __builtin_elementwise_fma(p, sq, splat2(0.19969235360622406f));
+  p = __builtin_elementwise_fma(p, sq, splat2(-0.33331960439682007f));
+  p = __builtin_elementwise_fma(p, sq, splat2(0.9999998807907104f));
+  f32x2 r = q * p;
+  const f32x2 r2 = splat2(1.57079632679489661923f) - r;
+  r.x = sw0 ? r2.x : r.x;
+  r.y = sw1 ? r2.y : r.y;
+  const f32x2 r3 = splat2(3.14159265358979323846f) - r;
+  r.x = x.x < 0.0f ? r3.x : r.x;
+  r.y = x.y < 0.0f ? r3.y : r.y;
+  if (!POS_Y) {
+    r.x = y.x < 0.0f ? -r.x : r.x;
+    r.y = y.y < 0.0f ? -r.y : r.y;
+  }
+  return r;
+}
+// se3ds_equirect_fxy_fast on two points (camera-relative x, y, z): fx, fy and rad.
+__device__ __forceinline__ void equirect_fxy_fast2(f32x2 x, f32x2 y, f32x2 z, float fwidth, float fheight,
+                                                   f32x2* fx, f32x2* fy, f32x2* rad_out) {
+  const f32x2 s2 = (x * x + y * y) + z * z;
+  const f32x2 rad = {__builtin_sqrtf(s2.x), __builtin_sqrtf(s2.y)};   // IEEE: rad IS an output (depth)
+  *rad_out = rad;
+  f32x2 heading = splat2(SE3DS_F32_ONE_HALF_PI) - atan2_fast2<false>(y, x);
+  // (1.5 pi - atan2 lies in [0.5 pi, 2.5 pi]: the scalar chain's "+ 2 pi if <= 0" never fires here)
+  const f32x2 hw = heading - splat2(SE3DS_F32_TWO_PI);
+  heading.x = heading.x > SE3DS_F32_TWO_PI ? hw.x : heading.x;
+  heading.y = heading.y > SE3DS_F32_TWO_PI ? hw.y : heading.y;
+  // w must be the reference's individually rounded quotient (se3ds_equirect_fxy_fast)
+  const f32x2 w = {z.x / rad.x, z.y / rad.y};
+  const f32x2 t = (splat2(1.0f) - w) * (splat2(1.0f) + w);
+  const f32x2 st = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
+  const f32x2 elevation = atan2_fast2<true>(st, w);
+  *fx = (heading * splat2(0.159154943091895336f)) * splat2(fwidth);
+  *fy = (elevation * splat2(0.318309886183790672f)) * splat2(fheight);
+}
+// the verdict of se3ds_equirect_uv_fast on one point of a pair
+__device__ __forceinline__ bool screen_decided(float fx, float fy, float rad, float mx, float my) {
+  const float dx = __builtin_fabsf(fx - __builtin_rintf(fx)), dy = __builtin_fabsf(fy - __builtin_rintf(fy));
+  return (dx > mx) && (dy > my) && (rad > 1.0e-30f) && (rad < 1.0e30f);
+}
+
 // Parity tap of the DEVICE fast screen (se3ds_geom_math.h: v_rcp_f32 / v_sqrt_f32 inside): fx, fy
 // and the screen's verdict per point (decided: idx >= -1, undecided: -2), so that the tests can
-// bound its deviation from the exact chain on the real hardware.
+// bound its deviation from the exact chain on the real hardware.  It runs the PACKED pair screen the
+// sorted splat ships (equirect_fxy_fast2 / screen_decided: points i and i + 1 as one pair).
 __global__ void __launch_bounds__(kBlock)
 debug_fast_fxy_kernel(const float* __restrict__ xyz, int64_t m, int width, int height,
                       float* __restrict__ fx, float* __restrict__ fy, int32_t* __restrict__ verdict) {
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m;
-       i += (int64_t)gridDim.x * kBlock) {
-    const float x = xyz[i], y = xyz[m + i], z = xyz[2 * m + i];
-    float gx, gy, pz;
-    se3ds_equirect_fxy_fast(x, y, z, width, height, &gx, &gy, &pz);
-    fx[i] = gx;
-    fy[i] = gy;
-    int32_t idx = -1;
-    verdict[i] = se3ds_equirect_index_fast(x, y, z, width, height, 1, &idx, &pz) ? idx : -2;
+  const float fw = (float)width, fh = (float)height;
+  const float mx = SE3DS_FAST_MARGIN * fw, my = SE3DS_FAST_MARGIN * fh;
+  for (int64_t i = 2 * ((int64_t)blockIdx.x * kBlock + threadIdx.x); i < m;
+       i += 2 * (int64_t)gridDim.x * kBlock) {
+    const int64_t j = i + 1 < m ? i + 1 : i;
+    const f32x2 x = {xyz[i], xyz[j]}, y = {xyz[m + i], xyz[m + j]}, z = {xyz[2 * m + i], xyz[2 * m + j]};
+    f32x2 gx, gy, rad;
+    equirect_fxy_fast2(x, y, z, fw, fh, &gx, &gy, &rad);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t k = e ? j : i;
+      const float ex = e ? gx.y : gx.x, ey = e ? gy.y : gy.x, er = e ? rad.y : rad.x;
+      fx[k] = ex;
+      fy[k] = ey;
+      int32_t v = -2;
+      if (screen_decided(ex, ey, er, mx, my)) {
+        const bool ok = (ex > -1.0f) && (ex < fw) && (ey > -1.0f) && (ey < fh);
+        v = ok ? (int32_t)ey * width + (int32_t)ex : -1;
+      }
+      verdict[k] = v;
+    }
   }
 }
 
@@ -1911,7 +1995,8 @@ feats_byte_range_kernel(const T* __restrict__ f, int64_t count, float void_class
 }
 
 __global__ void splat_promise_kernel(PackWs pw, uint32_t* out) {
-  out[0] = pw.ctl[1] == pw.ctl[kPromiseEpochWord] ? 1u : 0u;
+  const uint32_t e = pw.ctl[kPromiseEpochWord];
+  out[0] = (pw.ctl[1] == e && (e & kEpochTagMask) == kEpochTag) ? 1u : 0u;
 }
 __global__ void splat_promise_sticky_kernel(uint32_t* hdr, uint32_t* out, int clear) {
   out[0] = hdr[kPromiseStickyWord] != 0u ? 1u : 0u;
@@ -2041,41 +2126,66 @@ inline int sort_env(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-inline SortGeom sort_geom(int64_t m, int height, int width, int pts_forced = 0) {
-  // points per thread: 16 (8192-point chunks) when that still gives the chip two workgroups per CU,
-  // else 8 (4096-point chunks) -- at 512 x 1024 with two views (1 M points) 16 left half the CUs
-  // without a chunk (S1 + S2 41 us for a quarter of the 1024 x 2048 work).  SE3DS_SPLAT_PTS forces.
-  static const int pts_forced_env = sort_env("SE3DS_SPLAT_PTS", 0);
-  const int pts_env = pts_forced_env == 8 || pts_forced_env == 16
-                          ? pts_forced_env
-                          : (ceil_div(m > 0 ? m : 1, (int64_t)kSThreads * 16) >= 512 ? 16 : 8);
-  // SE3DS_SPLAT_SUPERPX (A/B): pixels per supertile, 256 .. 2048 (default 2048 = one full row of
-  // a 1024 x 2048 target; smaller supertiles = more, lighter resolve workgroups)
-  static const int super_px = [] {
-    const int v = sort_env("SE3DS_SPLAT_SUPERPX", kSDefaultPx);
-    return v >= 256 && v <= kSMaxPx ? v : kSDefaultPx;
-  }();
-  SortGeom g;
-  g.pts = pts_forced ? pts_forced : pts_env;
-  g.chunk_pts = kSThreads * g.pts;
-  g.chunks = (int)ceil_div(m > 0 ? m : 1, (int64_t)g.chunk_pts);
-  g.super_w = width <= super_px ? width : super_px;
-  if (width > g.super_w) {   // column strips of equal width (the last one may be ragged)
-    const int strips = ceil_div(width, g.super_w);
-    g.super_w = ceil_div(width, strips);
+// Geometry of one call.  Both kernels want TWO workgroups per CU (S1 is VALU- and S2 latency-bound: at one
+// 8-wave workgroup per CU every barrier and every load round trip is exposed).  Round 5 sized both for
+// the 4.2 M points of cfg5; at north_star's 512 x 1024 with two views that left 256 chunks and 256
+// supertiles for 256 CUs and each kernel took 16.8 us for a quarter of the work that takes 34-39 us at
+// 1024 x 2048 (profiles/r06_warp_512_*).  Now: points per thread = the largest of 16 / 8 / 4 that still
+// gives kSTargetWgs chunks, pixels per supertile = the largest of 2048 / 1024 / 512 that gives as
+// many supertiles (full image rows first, see above).
+constexpr int kSTargetWgs = 512;
+inline int sort_super_count(int height, int width, int super_px, int* super_w_out, int* rlog_out) {
+  int super_w = width <= super_px ? width : super_px;
+  if (width > super_w) {   // column strips of equal width (the last one may be ragged)
+    const int strips = ceil_div(width, super_w);
+    super_w = ceil_div(width, strips);
   }
-  g.rlog = 0;
-  while ((2 << g.rlog) * g.super_w <= super_px && (1 << g.rlog) < height) ++g.rlog;
+  int rlog = 0;
+  while ((2 << rlog) * super_w <= super_px && (1 << rlog) < height) ++rlog;
+  if (super_w_out) *super_w_out = super_w;
+  if (rlog_out) *rlog_out = rlog;
+  return ceil_div(width, super_w) * ceil_div(height, 1 << rlog);
+}
+inline SortGeom sort_geom(int n, int64_t m, int height, int width, int pts_forced = 0, int px_forced = 0) {
+  // SE3DS_SPLAT_PTS forces 4 / 8 / 16 points per thread, SE3DS_SPLAT_SUPERPX 256 .. 4096 pixels per
+  // supertile (A/B runs and the parity tests' small images)
+  static const int pts_forced_env = sort_env("SE3DS_SPLAT_PTS", 0);
+  static const int px_forced_env = [] {
+    const int v = sort_env("SE3DS_SPLAT_SUPERPX", 0);
+    return v >= 256 && v <= kSMaxPx ? v : 0;
+  }();
+  const int64_t mm = m > 0 ? m : 1;
+  const int nn = n > 0 ? n : 1;
+  SortGeom g;
+  g.pts = pts_forced ? pts_forced
+                     : (pts_forced_env == 4 || pts_forced_env == 8 || pts_forced_env == 16) ? pts_forced_env : 0;
+  if (!g.pts) {
+    g.pts = 4;
+    for (int pts = 16; pts > 4; pts >>= 1)
+      if (ceil_div(mm, (int64_t)kSThreads * pts) * nn >= kSTargetWgs) {
+        g.pts = pts;
+        break;
+      }
+  }
+  g.chunk_pts = kSThreads * g.pts;
+  g.chunks = (int)ceil_div(mm, (int64_t)g.chunk_pts);
+  int super_px = px_forced ? px_forced : px_forced_env;
+  if (!super_px) {
+    super_px = kSDefaultPx;
+    while (super_px > 512 && (int64_t)nn * sort_super_count(height, width, super_px, nullptr, nullptr) < kSTargetWgs)
+      super_px >>= 1;
+  }
+  g.nsuper = sort_super_count(height, width, super_px, &g.super_w, &g.rlog);
   g.super_x = ceil_div(width, g.super_w);
   g.super_y = ceil_div(height, 1 << g.rlog);
-  g.nsuper = g.super_x * g.super_y;
   g.px = g.super_w << g.rlog;
   return g;
 }
 inline size_t sort_ws_bytes(int n, int64_t m, int height, int width) {
+  // (independent of the A/B environment switches: the worst case over every geometry a call may take)
   size_t worst = 0;
-  for (int pts = 8; pts <= 16; pts += 8) {   // (independent of the A/B environment switch)
-    const SortGeom g = sort_geom(m, height, width, pts);
+  for (int pts = 4; pts <= 16; pts <<= 1) {
+    const SortGeom g = sort_geom(n, m, height, width, pts, 256);   // (256-pixel supertiles: the longest run table)
     const size_t b = 64 + align16(4 * kSinkSlots * kPMaxChannels) +
                      align16(4 * (size_t)n * kSMaxSuper * (size_t)(8 * ceil_div(g.chunks, 8))) +
                      align16(8 * (size_t)n * g.chunks * g.chunk_pts) +
@@ -2099,7 +2209,21 @@ inline SortWs carve_sort_ws(void* base, int n, const SortGeom& g) {
   return w;
 }
 
-// S1.  PTS points per thread (8 or 16).  Supertile of pixel (u, v): (v >> rlog, u / super_w).
+#ifdef SE3DS_PROBE
+// -DSE3DS_PROBE builds only (tools/warp_phases.py; never the shipped library): every workgroup of the two
+// sorted-splat kernels stamps the 100 MHz wall clock at its phase boundaries.
+constexpr int kProbeWgs = 4096, kProbeStamps = 12;
+__device__ uint64_t g_probe[2][kProbeWgs][kProbeStamps];
+#define SE3DS_STAMP(K, I)                                                                       \
+  do {                                                                                          \
+    const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                   \
+    if (threadIdx.x == 0 && wg_ < (unsigned)kProbeWgs) g_probe[K][wg_][I] = wall_clock64();     \
+  } while (0)
+#else
+#define SE3DS_STAMP(K, I) do {} while (0)
+#endif
+
+// S1.  PTS points per thread (4, 8 or 16).  Supertile of pixel (u, v): (v >> rlog, u / super_w).
 template <typename T, bool EQUIRECT, int C, bool DEBUG, int PTS>
 __global__ void __launch_bounds__(kSThreads, 4)   // (<= 128 VGPRs: two workgroups per CU)
 splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ offset,
@@ -2108,14 +2232,21 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
                   int vec, SplatWs ws, SortWs sw) {
   constexpr int kChunk = kSThreads * PTS;
   constexpr int kIter = PTS / kPPts;
-  constexpr int kQPer = kSQueue / kSThreads;
+  // queue of the undecided points: at most a quarter of the chunk (more: every thread takes its own),
+  // coordinates / features / offsets parked in the record area, which is only written in phase 4
+  constexpr int kQCap = kSQueue < kChunk / 4 ? kSQueue : kChunk / 4;
+  constexpr int kQPer = (kQCap + kSThreads - 1) / kSThreads;
+  static_assert((size_t)kQCap * (12 + 4 * C) <= (size_t)kChunk * 8, "the queue lives in the record area");
   extern __shared__ uint64_t s_dyn64[];          // [kChunk] records, [kChunk] hi bytes, counts, offsets
   uint64_t* s_rec = s_dyn64;
   uint8_t* s_hi = reinterpret_cast<uint8_t*>(s_dyn64 + kChunk);
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_hi + kChunk);   // [nsuper] counts, then offsets
   __shared__ uint16_t s_queue[kSQueue];   // (point offsets inside the chunk: < 8192)
+  float* s_qxyz = reinterpret_cast<float*>(s_rec);                      // [3][kQCap] camera-relative x, y, z
+  int32_t* s_qf = reinterpret_cast<int32_t*>(s_rec) + 3 * kQCap;        // [C][kQCap] features
   __shared__ uint32_t s_qn;
   __shared__ uint32_t s_w[kSThreads / 64];
+  SE3DS_STAMP(0, 0);   // start
   const int b = blockIdx.y;
   for (int t = threadIdx.x; t < nsuper; t += kSThreads) s_cnt[t] = 0u;
   if (threadIdx.x == 0) s_qn = 0u;
@@ -2249,6 +2380,34 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
   // ---- phase 1: every point's record and (supertile, rank) stay in registers
   uint64_t rec[PTS];
   uint32_t meta[PTS];
+  // (round 6, the screened path: the two rare outcomes of a point are handled WITHOUT a divergent
+  //  branch -- with 2-3 % of the points each, nearly every wave used to execute both side paths for
+  //  every point.  An invalid point only feeds the sink: raw-bit / integer partials, converted once
+  //  below.  An undecided point sets a bit; the bits are queued once per thread after the loop.)
+  uint32_t pend = 0u;             // bit j: point j waits for the binary64 pass
+  uint32_t inv_z = 0xffffffffu;   // min raw bits of rad over the screened-out points (rad > 0: bit order = value order)
+  int32_t inv_f[C];               // ... max of their features, as integers ((float) and the ordered map are monotone)
+#pragma unroll
+  for (int k = 0; k < C; ++k) inv_f[k] = INT32_MIN;
+  uint32_t fbits = 0u;            // OR of the valid points' feature words (the byte-range promise)
+  const float fwidth = (float)width, fheight = (float)height;
+  const float mgx = SE3DS_FAST_MARGIN * fwidth, mgy = SE3DS_FAST_MARGIN * fheight;
+  const uint32_t rmask = (1u << rlog) - 1u;
+  // a valid point of the screen: histogram rank + record
+  auto emit_valid = [&](int u, int v, float pz, const int32_t (&f)[C], uint64_t* rec_o, uint32_t* meta_o) {
+    const uint32_t sy_ = (uint32_t)v >> rlog, sx_ = super_x == 1 ? 0u : (uint32_t)u / (uint32_t)super_w;
+    const uint32_t st = sy_ * (uint32_t)super_x + sx_;
+    const uint32_t pix = ((uint32_t)v & rmask) * (uint32_t)super_w + ((uint32_t)u - sx_ * (uint32_t)super_w);
+    const uint32_t rank = atomicAdd(&s_cnt[st], 1u);
+    uint32_t fb[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      fb[k] = (uint32_t)f[k] & 255u;
+      fbits |= (uint32_t)f[k];
+    }
+    *rec_o = pack_rec(pix & 511u, pz, fb[0], fb[1], fb[2]);
+    *meta_o = st | (rank << 11) | ((pix >> 9) << 25);   // 11-bit supertile, 14-bit rank, pixel bits 9..
+  };
 #pragma unroll
   for (int it = 0; it < kIter; ++it) {
     const int64_t i0 = lo + ((int64_t)it * kSThreads + threadIdx.x) * kPPts;
@@ -2257,40 +2416,98 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
       rec[it * kPPts + p] = 0ull;
       meta[it * kPPts + p] = kSMetaNone;
     }
+    float x[kPPts], y[kPPts], z[kPPts];
+    int32_t f[kPPts][C];
+    uint32_t pend_it = 0u;   // this group's undecided points (bit p)
     if (i0 < hi) {
-      float x[kPPts], y[kPPts], z[kPPts];
-      int32_t f[kPPts][C];
       load_group(i0, x, y, z, f);
+      if (EQUIRECT) {
+        static_assert(kPPts % 2 == 0, "the screen works on pairs");
 #pragma unroll
-      for (int p = 0; p < kPPts; ++p) {
-        if (i0 + p >= hi) continue;
-        float px = x[p], py = y[p], pzz = z[p];
-        if (EQUIRECT && offset) {
-          px = px - ox;
-          py = py - oy;
-          pzz = pzz - oz;
-        }
-        if (EQUIRECT) {
-          int u = 0, v = 0, ok = 0;
-          float pz;
-          if (se3ds_equirect_uv_fast(px, py, pzz, width, height, feat_valid(f[p]), &u, &v, &ok, &pz)) {
-            emit(ok != 0, u, v, pz, f[p], &rec[it * kPPts + p], &meta[it * kPPts + p]);
-            if (DEBUG) {
+        for (int pp = 0; pp < kPPts; pp += 2) {
+          // (x - 0 is exact: no separate path for a null offset)
+          const f32x2 qx = {x[pp] - ox, x[pp + 1] - ox}, qy = {y[pp] - oy, y[pp + 1] - oy};
+          const f32x2 qz = {z[pp] - oz, z[pp + 1] - oz};
+          x[pp] = qx.x; x[pp + 1] = qx.y;   // (camera-relative from here on: what the queue parks)
+          y[pp] = qy.x; y[pp + 1] = qy.y;
+          z[pp] = qz.x; z[pp + 1] = qz.y;
+          f32x2 fx2, fy2, rad2;
+          equirect_fxy_fast2(qx, qy, qz, fwidth, fheight, &fx2, &fy2, &rad2);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int p = pp + e, j = it * kPPts + p;
+            const float fx = e ? fx2.y : fx2.x, fy = e ? fy2.y : fy2.x, pz = e ? rad2.y : rad2.x;
+            const bool in = i0 + p < hi;   // (the tail group repeats the last point)
+            const bool decided = screen_decided(fx, fy, pz, mgx, mgy);
+            const bool ok = (fx > -1.0f) && (fx < fwidth) && (fy > -1.0f) && (fy < fheight) &&
+                            feat_valid(f[p]);
+            const int u = (int)fx, v = (int)fy;
+            if (in && decided && ok) emit_valid(u, v, pz, f[p], &rec[j], &meta[j]);
+            const bool inv = in && decided && !ok;
+            const uint32_t zb = __float_as_uint(pz);
+            inv_z = inv && zb < inv_z ? zb : inv_z;
+#pragma unroll
+            for (int k = 0; k < C; ++k) inv_f[k] = inv && f[p][k] > inv_f[k] ? f[p][k] : inv_f[k];
+            pend |= (in && !decided) ? (1u << j) : 0u;
+            pend_it |= (in && !decided) ? (1u << p) : 0u;
+            if (DEBUG && in && decided) {
               ws.idx[(int64_t)b * m + i0 + p] = ok ? v * width + u : -1;
               ws.z[(int64_t)b * m + i0 + p] = pz;
             }
-          } else {
-            // undecided (~2.5 %): queued for the dense binary64 pass below
-            meta[it * kPPts + p] = kSMetaPending;
-            const uint32_t slot = atomicAdd(&s_qn, 1u);
-            if (slot < (uint32_t)kSQueue) s_queue[slot] = (uint16_t)(i0 + p - lo);
           }
-        } else {
-          exact(i0 + p, px, py, pzz, f[p], &rec[it * kPPts + p], &meta[it * kPPts + p]);
+        }
+      } else {
+#pragma unroll
+        for (int p = 0; p < kPPts; ++p) {
+          if (i0 + p >= hi) continue;
+          exact(i0 + p, x[p], y[p], z[p], f[p], &rec[it * kPPts + p], &meta[it * kPPts + p]);
+        }
+      }
+    }
+    if (EQUIRECT) {
+      // the group's undecided points (~1.3 % of all) are queued for the dense binary64 pass WITH their
+      // coordinates and features (round 6: the pass used to start with a global round trip to fetch
+      // them again); one LDS atomic per wave, all lanes take part in the scan
+      const uint32_t np = (uint32_t)__popc(pend_it);
+      const uint32_t incl = wave_incl_scan_u32(np);
+      const uint32_t wtot = (uint32_t)__shfl((int)incl, 63, 64);
+      if (wtot) {
+        uint32_t base = 0u;
+        if ((threadIdx.x & 63) == 63) base = atomicAdd(&s_qn, wtot);
+        base = (uint32_t)__shfl((int)base, 63, 64);
+        uint32_t slot = base + incl - np;
+#pragma unroll
+        for (int p = 0; p < kPPts; ++p) {
+          if (!((pend_it >> p) & 1u)) continue;
+          if (slot < (uint32_t)kQCap) {
+            s_qxyz[slot] = x[p];
+            s_qxyz[kQCap + slot] = y[p];
+            s_qxyz[2 * kQCap + slot] = z[p];
+#pragma unroll
+            for (int k = 0; k < C; ++k) s_qf[k * kQCap + slot] = f[p][k];
+            s_queue[slot] = (uint16_t)((it * kSThreads + (int)threadIdx.x) * kPPts + p);
+          }
+          ++slot;
         }
       }
     }
   }
+  SE3DS_STAMP(0, 1);   // loads + screen + histogram done (this wave)
+  bad |= fbits >> 8;   // (negative or > 255 under the promise)
+  if (inv_z != 0xffffffffu) {   // the screened-out points join the sink partials in their final form
+    const uint32_t o = inv_z | 0x80000000u;   // se3ds_f32_to_ordered of a positive float
+    sink = o < sink ? o : sink;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const uint32_t of = se3ds_f32_to_ordered((float)inv_f[k]);
+      smax[k] = of > smax[k] ? of : smax[k];
+    }
+  }
+  // point j of this thread, as an offset inside the chunk
+  auto chunk_offset = [&](int j) {
+    return (uint32_t)(((j / kPPts) * kSThreads + (int)threadIdx.x) * kPPts + (j % kPPts));
+  };
+  SE3DS_STAMP(0, 2);   // pending points queued
   // ---- phase 2: the undecided points, densely (their records stay with the thread that ran them)
   uint64_t qrec[kQPer];
   uint32_t qmeta[kQPer];
@@ -2302,23 +2519,28 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
   if (EQUIRECT) {
     __syncthreads();
     const uint32_t qn = s_qn;
-    if (qn <= (uint32_t)kSQueue) {
+    if (qn <= (uint32_t)kQCap) {
 #pragma unroll
       for (int r = 0; r < kQPer; ++r) {
         const uint32_t q = threadIdx.x + r * kSThreads;
-        if (q < qn) exact_at(lo + s_queue[q], &qrec[r], &qmeta[r]);
+        if (q < qn) {
+          int32_t qf[C];
+#pragma unroll
+          for (int k = 0; k < C; ++k) qf[k] = s_qf[k * kQCap + q];
+          exact(lo + s_queue[q], s_qxyz[q], s_qxyz[kQCap + q], s_qxyz[2 * kQCap + q], qf, &qrec[r], &qmeta[r]);
+        }
       }
     } else {
       // queue overflow (> 12 % undecided: lattice clouds): every thread takes its own marked points
 #pragma unroll
       for (int j = 0; j < PTS; ++j) {
-        if (meta[j] != kSMetaPending) continue;
-        const int64_t i = lo + ((int64_t)(j / kPPts) * kSThreads + threadIdx.x) * kPPts + (j % kPPts);
-        exact_at(i, &rec[j], &meta[j]);
+        if (!((pend >> j) & 1u)) continue;
+        exact_at(lo + chunk_offset(j), &rec[j], &meta[j]);
       }
     }
   }
   __syncthreads();
+  SE3DS_STAMP(0, 3);   // exact pass done, all waves through the barrier
   // ---- phase 3: exclusive scan of the supertile counts (<= 2048: four per thread), run descriptors
   uint32_t all;
   {
@@ -2342,6 +2564,7 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
   }
   {
     __syncthreads();
+    SE3DS_STAMP(0, 4);   // scan + run descriptors
     // ---- phase 4: placement in LDS, then full-line stores of the chunk
     auto place = [&](uint64_t r, uint32_t mt) {
       if (mt >= kSMetaPending) return;
@@ -2354,6 +2577,7 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
 #pragma unroll
     for (int r = 0; r < kQPer; ++r) place(qrec[r], qmeta[r]);
     __syncthreads();
+    SE3DS_STAMP(0, 5);   // placed in LDS
     uint64_t* G = sw.rec + ((int64_t)b * sw.chunks + blockIdx.x) * kChunk;
     uint8_t* H = sw.hi + ((int64_t)b * sw.chunks + blockIdx.x) * kChunk;
     for (uint32_t j = 2 * threadIdx.x; j < all; j += 2 * kSThreads)
@@ -2361,6 +2585,7 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
     for (uint32_t j = 16 * threadIdx.x; j < all; j += 16 * kSThreads)
       *reinterpret_cast<uint4*>(H + j) = *reinterpret_cast<const uint4*>(s_hi + j);
   }
+  SE3DS_STAMP(0, 6);   // chunk stores issued
   // ---- sink partials of the invalid points (as the packed path)
   __shared__ uint32_t s_red[1 + C][kSThreads / 64];
   sink = wave_min_u32(sink);
@@ -2388,6 +2613,7 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
     for (int i = 0; i < kSThreads / 64; ++i) v = s_red[1 + k][i] > v ? s_red[1 + k][i] : v;
     ws.fpart[(int64_t)part * C + k] = v;
   }
+  SE3DS_STAMP(0, 7);   // end
 }
 
 // byte-wise max of two words of three feature bytes
@@ -2399,7 +2625,9 @@ __device__ __forceinline__ uint32_t bytemax3(uint32_t a, uint32_t b) {
 
 // S2.  One workgroup per (image, supertile).
 template <int C>
-__global__ void __launch_bounds__(kRThreads, 6)   // (<= 80 VGPRs: three workgroups per CU)
+__global__ void __launch_bounds__(kRThreads, 6)   // (<= 80 VGPRs: three workgroups per CU.  Round 6 tried 64 VGPRs / kRStash 8 / four per CU so that all
+                                                  //  1 024 supertiles of cfg5 are resident: lifetime 16.3 -> 22.6 us, span 30 -> 30 us, room 78 -> 85 us --
+                                                  //  the kernel is bound by the LDS atomic rate, not by occupancy)
 splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int super_w, int rlog,
                           float depth_scale, float output_void, float mask_void,
                           float* __restrict__ depth, float* __restrict__ feat,
@@ -2414,6 +2642,7 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
   __shared__ uint32_t s_c[C][kRThreads / 64];
   __shared__ uint32_t s_flag;
   __shared__ uint32_t s_q[kRStash * kRThreads / 64];   // first run of every 64-record block of a batch
+  SE3DS_STAMP(1, 0);   // start
   const int chunks = sw.chunks;
   const int bs = blockIdx.x;
   const int b = bs / nsuper, st = bs - b * nsuper;
@@ -2443,6 +2672,7 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
     }
     if (threadIdx.x == 0) s_cpre[nnz] = total;   // sentinel: every walk below stops here
   }
+  SE3DS_STAMP(1, 1);   // run row read, compacted, prefix
   {
     uint32_t sink_o = 0xffffffffu;
     if (first) {
@@ -2464,6 +2694,7 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
       s_f[p] = 0u;
     }
     __syncthreads();
+    SE3DS_STAMP(1, 2);   // LDS tile initialised
     // flat record index j -> record number inside this image: run k with cpre[k] <= j < cpre[k + 1],
     // record cbase[k] + (j - cpre[k]).  A binary search per RECORD made the LDS pipe the kernel's
     // bottleneck (11 conflicted reads per record against ~1.4 atomics): one search per aligned block
@@ -2556,9 +2787,16 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
 #pragma unroll
       for (int k = 0; k < kRStash; ++k) {
         const uint32_t j = base + threadIdx.x + k * kRThreads;
-        if (j < total) atomicMin(&s_z[sp[k]], rec_zbits(sr[k]));   // valid => z > 0
+        // valid => z > 0.  LDS atomics run at ~1 lane per clock and CU and are this kernel's floor: a
+        // plain read first, the atomic only where the record can lower the minimum (a stale read costs
+        // an unneeded atomic, never a missed one: the minimum only falls)
+        if (j < total) {
+          const uint32_t zb = rec_zbits(sr[k]);
+          if (zb < s_z[sp[k]]) atomicMin(&s_z[sp[k]], zb);
+        }
       }
     }
+    SE3DS_STAMP(1, 3);   // pass A (searches, loads, z-min atomics) done by this wave
     __syncthreads();
     // pass B: survivors (z < zmin + 0.1) max their features; the rest feed the sink
     uint32_t sbytes = 0u;   // byte-wise max of the occluded records' feature words
@@ -2591,6 +2829,7 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
           if (base + threadIdx.x + k * kRThreads < total) passb(sr[k], sp[k]);
       }
     }
+    SE3DS_STAMP(1, 4);   // pass B done by this wave
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       // (a feature of 0 never raises the sink's maximum over fill(0): ordered(0.0f) stays out)
@@ -2599,12 +2838,16 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
       if ((threadIdx.x & 63) == 0) s_c[k][threadIdx.x >> 6] = v;
     }
     __syncthreads();
+    // (returned atomic: performed memory-side before this thread passes the ticket's barrier below.  Its
+    //  round trip -- ~1.5 us, profiles/r06_warp_phases.txt -- flies under the output stores: the return
+    //  value is only consumed behind them)
+    uint32_t sink_ret = 0u;
     if ((int)threadIdx.x < C) {
       uint32_t v = 0u;
       for (int i = 0; i < kRThreads / 64; ++i) v = s_c[threadIdx.x][i] > v ? s_c[threadIdx.x][i] : v;
-      // (returned atomic: performed memory-side before this thread passes the barrier below)
-      if (v != 0u) s_c[threadIdx.x][0] = atomicMax(&sw.fpart2[(blockIdx.x % kSinkSlots) * C + threadIdx.x], v);
+      if (v != 0u) sink_ret = atomicMax(&sw.fpart2[(blockIdx.x % kSinkSlots) * C + threadIdx.x], v);
     }
+    SE3DS_STAMP(1, 5);   // sink slots
     // outputs of this item's pixels -- all but flat pixel 0, which only the last workgroup writes
     const int64_t hw = (int64_t)height * width;
     float* __restrict__ depth_b = depth + (int64_t)b * hw;
@@ -2637,6 +2880,8 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
       depth_b[ip] = d;
       if (mask_b) mask_b[ip] = (d > 0.0f && d < 1.0f && all_ok) ? 1.0f : 0.0f;
     }
+    if ((int)threadIdx.x < C) s_c[threadIdx.x][0] = sink_ret;   // (the wait for the sink atomic)
+    SE3DS_STAMP(1, 6);   // outputs stored
     if (first) {
       // the invalid points' feature maxima (S1's per-chunk partials, a kernel ago) join the occluded
       // points' slots here, so that the last workgroup only reads the slots
@@ -2668,6 +2913,7 @@ splat_sort_resolve_kernel(int height, int width, int nsuper, int super_x, int su
   __syncthreads();   // (this workgroup's sink / pixel-0 atomics have returned)
   if (threadIdx.x == 0) s_flag = atomicAdd(&sw.ctl[0], 1u) == gridDim.x - 1 ? 1u : 0u;
   __syncthreads();
+  SE3DS_STAMP(1, 7);   // ticket taken
   if (s_flag == 0u) return;
   uint32_t fm[C];
 #pragma unroll
@@ -2765,7 +3011,7 @@ int launch_splat_sorted(const float* coords, const float* offset, const T* feats
   return launch_splat_sorted_c<T, EQUIRECT, CC, PP>(coords, offset, feats, n, m, ld, height, width, \
                                                     depth_scale, input_void, output_void, depth,  \
                                                     feat, mask, mask_void, ws, sw, g, stream)
-#define SE3DS_SC(CC) if (g.pts == 8) SE3DS_S(CC, 8); else SE3DS_S(CC, 16);
+#define SE3DS_SC(CC) if (g.pts == 4) SE3DS_S(CC, 4); else if (g.pts == 8) SE3DS_S(CC, 8); else SE3DS_S(CC, 16);
   switch (channels) {
     case 1: SE3DS_SC(1)
     case 2: SE3DS_SC(2)
@@ -2799,7 +3045,7 @@ int launch_splat(const float* coords, const float* offset, const T* feats, int n
           (std::is_same<T, uint8_t>::value || byte_range) && output_void >= 0.0f &&
           (int64_t)n * m < ((int64_t)1 << 31) && (int64_t)height * width * width < ((int64_t)1 << 40);
       if (packable && sort_mode != 0) {
-        const SortGeom sg = sort_geom(m, height, width);
+        const SortGeom sg = sort_geom(n, m, height, width);
         if (sg.nsuper <= kSMaxSuper && sg.chunks <= kSMaxChunks &&
             (int64_t)sg.chunks * n <= kMaxSinkBlocks && (int64_t)n * sg.nsuper < ((int64_t)1 << 24) &&
             (sort_mode == 2 || (int64_t)n * sg.nsuper >= 128))
@@ -3711,5 +3957,13 @@ int se3ds_compact_valid(const float* xyz1, const void* feats, int feat_dtype, in
       return SE3DS_E_BADDTYPE;
   }
 }
+
+#ifdef SE3DS_PROBE
+/* probe builds only: the phase stamps of the last sorted splat (host buffer of 2 * 4096 * 12 uint64) */
+int se3ds_geom_probe_read(uint64_t* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(se3ds::g_probe), sizeof(uint64_t) * 2 * 4096 * 12) == hipSuccess
+             ? SE3DS_OK : SE3DS_E_LAUNCH;
+}
+#endif
 
 }  // extern "C"

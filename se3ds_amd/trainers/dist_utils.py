@@ -110,6 +110,7 @@ class GradSync:
     self.launched = []   # (e0, e1) ranges handed over this step (for tests)
     self.seen = 0            # collectives of this step that called pump() so far
     self.prev_seen = None    # ... of the previous step (None: first step, pace one per call)
+    self.last_finish_buckets = 0   # buckets the last finish() still had to issue itself
 
   def _issue(self, arena, o, n, ready):
     with torch.cuda.stream(self.side):
@@ -142,8 +143,20 @@ class GradSync:
       self._issue(*self.pending.pop(0))
       k -= 1
 
-  def finish(self):
+  def _end_step(self):
+    """Pacing bookkeeping of finish() (pure host logic: tests/test_dist_cpu.py drives it without a
+    GPU).  A step that paced nothing -- train_d: its only buckets are the discriminator's, handed
+    over in one go -- keeps the count of the last step that did, so train_d / train_g_d alternation
+    (d_step_per_g_step = 2) does not reset the pace.  When the count CHANGES between two pacing
+    steps, the first step after the change runs on the stale figure: more collectives than
+    expected -> everything pending goes out behind each one past the old count (drained early);
+    fewer -> the tail is left for finish() once, and the next step paces on the new count."""
     self.prev_seen, self.seen = (self.seen or self.prev_seen), 0
+    left = len(self.pending)   # what the pacing did NOT hide behind a collective (bench: `finish_buckets`)
     self.pump(len(self.pending))
+    return left
+
+  def finish(self):
+    self.last_finish_buckets = self._end_step()
     torch.cuda.current_stream(self.device).wait_stream(self.side)
     self.launched = []

@@ -49,11 +49,22 @@ _workspaces = {}
 _WS_BYTES = {}   # (n, m, height, width, channels) -> se3ds_splat_workspace_bytes
 
 
+def _dev_key(device) -> str:
+  """ONE key per physical device: 'cuda', torch.device('cuda') and 'cuda:0' name the same workspace
+  (a memory created on torch.device('cuda') stored its workspace under 'cuda' while the
+  promise poll looked under 'cuda:0', found nothing and skipped silently)."""
+  d = torch.device(device)
+  if d.type == 'cuda' and d.index is None:
+    d = torch.device('cuda', torch.cuda.current_device())
+  return str(d)
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
   """Grow-only scratch buffer per device (keeps allocation out of the trajectory loop).  Its
   256-byte header is zeroed at creation: header word 3 is the library's STICKY promise-violation
-  flag (include/se3ds_hip.h, se3ds_splat_promise_sticky)."""
-  key = str(device)
+  flag (include/se3ds_hip.h, se3ds_splat_promise_sticky); words 1 and 2 are the single-launch
+  splat's grid barrier and ticket (zero at rest)."""
+  key = _dev_key(device)
   ws = _workspaces.get(key)
   if ws is None or ws.numel() < nbytes:
     _poll_promise(device, force=True)   # (a pending verdict of the old buffer is read first)
@@ -85,7 +96,7 @@ class PromiseBroken(RuntimeError):
 def _poll_promise(device, force=False, launch=False):
   """Bookkeeping of the sticky flag (see above).  force: launch the read-back now and wait;
   launch: launch it now, examine it at a later call."""
-  key = str(device)
+  key = _dev_key(device)
   st = _promise_state.setdefault(key, dict(calls=0, pending=[]))
   ws = _workspaces.get(key)
   still = []
@@ -126,10 +137,10 @@ def check_promise(device=None, wait=True):
   new one for the next call (no host synchronisation: SE3DSModel.__call__ does this on every
   return, so a short inference trajectory that never reaches the 64th promised splat is covered
   one call late at most, and by the atexit hook for its last call)."""
-  keys = [str(device)] if device is not None else list(_workspaces)
+  keys = [_dev_key(device)] if device is not None else list(_workspaces)
   for key in keys:
     if key in _workspaces:
-      _poll_promise(_workspaces[key].device, force=wait, launch=not wait)
+      _poll_promise(key, force=wait, launch=not wait)
 
 
 def _check_promise_at_exit():
@@ -300,7 +311,7 @@ def project_to_feat(transformed_coords: torch.Tensor, feats: torch.Tensor, heigh
 
 def splat_debug_indices(n: int, m: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
   """(idx, z) of the last splat on `device` (parity tap; idx = v*W+u or -1 for the sink)."""
-  ws = _workspaces[str(device)]
+  ws = _workspaces[_dev_key(device)]
   idx = torch.empty((n, m), dtype=torch.int32, device=device)
   z = torch.empty((n, m), dtype=torch.float32, device=device)
   rc = _lib.lib().se3ds_splat_debug_indices(_lib.ptr(ws), n, m, _lib.ptr(idx), _lib.ptr(z),
@@ -334,7 +345,7 @@ class PointCloudMemory:
 
   def __init__(self, batch_size: int, channels: int, dtype=torch.int32, device='cuda:0',
                capacity: int = 0):
-    self.n, self.c, self.dtype, self.device = batch_size, channels, dtype, torch.device(device)
+    self.n, self.c, self.dtype, self.device = batch_size, channels, dtype, torch.device(_dev_key(device))
     self.m = 0
     self.byte_range = True   # every appended frame's features were void or in [0, 255]
     self._x = torch.empty((batch_size, 4, 0), dtype=torch.float32, device=self.device)
@@ -407,6 +418,7 @@ class PointCloudMemory:
     p = vh * vw
     self.reserve(self.m + len(views) * p)
     fl, dl, pl, keep = [], [], [], []
+    br_new = self.byte_range   # (committed with self.m once the call has succeeded: ADVICE r5)
     any_pos = any(v[2] is not None for v in views)
     for feats, depth, pos in views:
       if feats.dim() == 3:
@@ -415,7 +427,7 @@ class PointCloudMemory:
       if (feats.dtype != self.dtype or tuple(feats.shape) != (self.n, vh, vw, self.c) or
           tuple(depth.shape) != (self.n, vh, vw)):
         raise ValueError('views must share the memory\'s dtype, batch, channels and one size')
-      self.byte_range = self.byte_range and byte_range(feats, void_class)
+      br_new = br_new and byte_range(feats, void_class)
       feats, depth = feats.contiguous(), depth.to(torch.float32).contiguous()
       if any_pos:
         pos = (torch.zeros((self.n, 3), dtype=torch.float32, device=self.device) if pos is None
@@ -432,13 +444,18 @@ class PointCloudMemory:
     base = tab.data_ptr()
     if out is not None:
       depth_o, out, mask = out
-      if (tuple(depth_o.shape) != (n, height, width) or tuple(out.shape) != (n, height, width, c) or
-          depth_o.dtype != torch.float32 or out.dtype != torch.float32 or
-          not (depth_o.is_contiguous() and out.is_contiguous()) or
-          (with_mask and (mask is None or tuple(mask.shape) != (n, height, width)))):
-        raise ValueError('out = (depth (N,H,W), feats (N,H,W,C), mask (N,H,W) or None), fp32, contiguous')
       if not with_mask:
         mask = None
+      if with_mask and mask is None:
+        raise ValueError('with_mask needs out = (depth, feats, mask)')
+      # (raw pointers from here on: every buffer is checked for device, dtype, shape and layout)
+      _lib.require_cuda(depth_o, out, mask)
+      for t, shape in ((depth_o, (n, height, width)), (out, (n, height, width, c)),
+                       (mask, (n, height, width))):
+        if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or
+                              not t.is_contiguous() or _dev_key(t.device) != _dev_key(dev)):
+          raise ValueError('out = (depth (N,H,W), feats (N,H,W,C), mask (N,H,W) or None): fp32, '
+                           f'contiguous, on {dev}; got {tuple(t.shape)} {t.dtype} on {t.device}')
     else:
       depth_o = torch.empty((n, height, width), dtype=torch.float32, device=dev)
       out = torch.empty((n, height, width, c), dtype=torch.float32, device=dev)
@@ -453,7 +470,7 @@ class PointCloudMemory:
     if target is not None:
       _lib.require_cuda(target)
       target = target.to(torch.float32).contiguous()
-    hint = FEAT_BYTE_RANGE if (self.dtype == torch.int32 and c <= 3 and self.byte_range) else 0
+    hint = FEAT_BYTE_RANGE if (self.dtype == torch.int32 and c <= 3 and br_new) else 0
     rc = L.se3ds_warp_views_to_target(
         arr(fl), _lib.dtype_code(self._f) | hint, arr(dl), arr(pl) if any_pos else None, nv, n, vh, vw,
         c, float(void_class), float(depth_scale), base, base + 4 * vh, base + 8 * vh,
@@ -461,7 +478,7 @@ class PointCloudMemory:
         _lib.ptr(target), height, width, float(output_void_class), _lib.ptr(depth_o), _lib.ptr(out),
         _lib.ptr(mask), float(mask_void), _lib.ptr(ws), ws.numel(), _lib.stream())
     _lib.check(rc, 'se3ds_warp_views_to_target')
-    self.m = m_new
+    self.m, self.byte_range = m_new, br_new
     if hint:
       _poll_promise(dev)
     return (depth_o, out, mask) if with_mask else (depth_o, out)

@@ -184,3 +184,75 @@ def test_paired_syncbn_collectives_gloo():
   other): 12 reduced tensors, 6 collectives, every value the cross-replica sum."""
   out = _run('paired_syncbn')
   assert int(out[0][0]) == 6 and int(out[1][0]) == 6
+
+
+class _PacedSync(dist_utils.GradSync):
+  """GradSync's host-side pacing without a GPU: buckets are recorded instead of all-reduced."""
+
+  def __init__(self, bucket):   # pylint: disable=super-init-not-called
+    self.group, self.drip, self.bucket = None, True, bucket
+    self.pending, self.launched, self.issued = [], [], []
+    self.seen, self.prev_seen, self.last_finish_buckets = 0, None, 0
+
+  def _issue(self, arena, o, n, ready):
+    self.issued.append((o, n, self.seen))
+
+  def reduce_range(self, arena, e0, e1):   # (the product's, minus the HIP event)
+    for o in range(e0, e1, self.bucket):
+      self.pending.append((arena, o, min(self.bucket, e1 - o), None))
+    self.launched.append((e0, e1))
+    self.pump(1 if self.drip else len(self.pending))
+
+
+def _paced_step(sync, collectives, segments):
+  """One train_g_d backward: `collectives` SyncBN sums, a gradient segment of `n` buckets becoming
+  ready just before collective k for every (k, n) in `segments`.  Returns (buckets still queued
+  right after the LAST collective, buckets finish() had to issue itself)."""
+  sync.issued = []
+  at = dict(segments)
+  queued_after_last = None
+  for k in range(collectives):
+    if k in at:
+      sync.reduce_range(None, 0, at[k] * sync.bucket)
+    sync.pump()   # Ctx.after_collective
+    queued_after_last = len(sync.pending)
+  left = sync._end_step()
+  assert not sync.pending
+  return queued_after_last, left
+
+
+def test_drip_pacing_drains_by_the_last_collective_and_follows_a_changing_count():
+  """GradSync.pump paces the drip-fed gradient buckets so that the queue is
+  empty by the LAST SyncBN collective of the backward pass, whose number it only knows from the
+  previous step.  Steady state; train_d steps in between (they pace nothing and must not reset the
+  count); the count GROWING (everything queued goes out behind each extra collective) and
+  SHRINKING (one step leaves a tail to finish(), the next one is paced on the new count)."""
+  sync = _PacedSync(bucket=16)
+  segs = [(0, 40), (50, 30), (120, 25)]   # 95 buckets over a 194-collective backward pass
+  # first step: no history, one bucket per collective -> 194 >= 95: drained
+  q, left = _paced_step(sync, 194, segs)
+  assert (q, left) == (0, 0) and sync.prev_seen == 194
+  # steady state: drained by the last collective, and not all up front (the bytes in flight follow
+  # the remaining backward time: the first segment's 40 buckets are spread over many collectives)
+  q, left = _paced_step(sync, 194, segs)
+  assert (q, left) == (0, 0)
+  first_seg = [s for o, n, s in sync.issued[:40]]
+  assert max(first_seg) - min(first_seg) >= 20, first_seg
+  # a train_d step in between: reduce_range + finish only, no pacing calls
+  sync.reduce_range(None, 0, 5 * sync.bucket)
+  assert sync._end_step() == 4 and sync.prev_seen == 194
+  q, left = _paced_step(sync, 194, segs)
+  assert (q, left) == (0, 0)
+  # the count grows (e.g. another model width): past the stale count every call empties the queue
+  q, left = _paced_step(sync, 260, segs + [(230, 12)])
+  assert (q, left) == (0, 0) and sync.prev_seen == 260
+  # the count shrinks: the stale figure paces too slowly ONCE ...
+  late = [(0, 40), (80, 50)]
+  q1, left1 = _paced_step(sync, 100, late)
+  assert left1 == q1 and left1 > 0 and sync.prev_seen == 100
+  # ... and the next step with the same shape is drained by its last collective again
+  q2, left2 = _paced_step(sync, 100, late)
+  assert (q2, left2) == (0, 0)
+  # a segment that only becomes ready at the very last collective is all finish() ever has to send
+  q3, left3 = _paced_step(sync, 100, [(0, 40), (99, 3)])
+  assert (q3, left3) == (0, 0)

@@ -197,7 +197,8 @@ def test_interpolate_bilinear_identity_and_clamp():
 @pytest.mark.parametrize('h', [64, 1024, 2048])
 def test_fast_index_screen_error_bound(h):
   """include/se3ds_geom_math.h: the fp32 screen the splat kernels use before the binary64 path.
-  Every index it decides equals the exact one, and its deviation stays >= 16x below the margin."""
+  Every index it decides equals the exact one, and its deviation stays >= 8x below the margin
+  (measured: 1.79e-7 of the image size at every height, margin 2e-6)."""
   rng = np.random.default_rng(5 + h)
   w, m = 2 * h, 400_000
   clouds = [rng.standard_normal((3, m)) * rng.uniform(0.01, 20, (1, m))]
@@ -210,13 +211,13 @@ def test_fast_index_screen_error_bound(h):
   clouds.append(v)
   clouds.append(rng.standard_normal((3, m)) * 1e-18)
   clouds.append(rng.integers(-3, 4, (3, m)))               # exact ties, zeros
-  margin = 4.0e-6                                          # SE3DS_FAST_MARGIN
+  margin = 2.0e-6                                          # SE3DS_FAST_MARGIN
   for v in clouds:
     ex, ey, decided, wrong = warp_c.fast_screen_stats(v.astype(np.float32), h, w)
     assert wrong == 0
     # the heading wrap (fx ~ 0 vs ~ W) is the one place the two chains differ by a full width;
     # both values then sit on an integer and the screen leaves the point to the exact path
-    assert ex <= margin / 16 or ex > 0.99
-    assert ey <= margin / 16
+    assert ex <= margin / 8 or ex > 0.99, ex
+    assert ey <= margin / 8, ey
   ex, ey, decided, _ = warp_c.fast_screen_stats(clouds[0].astype(np.float32), h, w)
   assert decided / m > 0.9

@@ -53,6 +53,8 @@ OWNERS = {
     # bench
     'SE3DS_BENCH_BACKEND': ('tests/test_dist_gpu.py', 'SE3DS_BENCH_BACKEND'),
     'SE3DS_BENCH_SHAPES': ('tools/probes/shapes_ab.sh', 'SE3DS_BENCH_SHAPES'),
+    # which build of the library a process loads (A/B of two builds on one box)
+    'SE3DS_LIB': ('tools/probes/lib_ab_step.sh', 'SE3DS_LIB'),
 }
 
 _READ = re.compile(r'''(?:getenv\(\s*|sort_env\(\s*|environ\.get\(\s*|environ\[\s*)["'](SE3DS_[A-Z0-9_]+)["']''')

@@ -25,6 +25,18 @@ def t(a):
   return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
 
 
+def np_project(feats, xyz1, h, w, void, offset=None):
+  """The INDEPENDENT statement of the render (oracle/warp_np.py: NumPy scatter-min / max, libm
+  transcendentals -- it shares no arithmetic with the kernels, unlike the C twin warp_c, which includes
+  the kernels' own se3ds_geom_math.h): (depth, feats) of project_feats_to_equirectangular on
+  xyz1 - offset."""
+  xyz1 = np.asarray(xyz1, F32)
+  if offset is not None:
+    n = xyz1.shape[0]
+    xyz1 = (xyz1 - np.concatenate([np.asarray(offset, F32), np.zeros((n, 1), F32)], 1)[:, :, None]).astype(F32)
+  return warp_np.project_feats_to_equirectangular(feats, xyz1, h, w, void, DEPTH_SCALE)
+
+
 def synth_pano(rng, n, h, w):
   rgb = rng.integers(0, 256, (n, h, w, 3)).astype(np.int32)
   depth = rng.uniform(0, 1, (n, h, w)).astype(F32)
@@ -127,6 +139,17 @@ def test_trajectory_step_in_one_call_equals_the_separate_calls(n, h, views):
                                                      -1, DEPTH_SCALE, offset=tgt)
   np.testing.assert_array_equal(da.cpu().numpy(), d_o)
   np.testing.assert_array_equal(fa.cpu().numpy(), f_o)
+  # ... and the independent NumPy / libm statement of both halves
+  xs_n, fs_n = [], []
+  for r, d, p in vs:
+    x, f = warp_np.equirectangular_to_pointcloud(r, d, -1, DEPTH_SCALE)
+    xs_n.append((x + np.concatenate([p, np.zeros((n, 1), F32)], 1)[:, :, None]).astype(F32))
+    fs_n.append(f)
+  np.testing.assert_array_equal(a.coords.cpu().numpy(), np.concatenate(xs_n, 2))
+  np.testing.assert_array_equal(a.feats.cpu().numpy(), np.concatenate(fs_n, 1))
+  d_n, f_n = np_project(np.concatenate(fs_n, 1), np.concatenate(xs_n, 2), h, w, -1, offset=tgt)
+  np.testing.assert_array_equal(da.cpu().numpy(), d_n)
+  np.testing.assert_array_equal(fa.cpu().numpy(), f_n)
   # a second step appends behind the first and renders everything
   rgb, depth = synth_pano(rng, n, h, w)
   d2, f2 = a.append_views_and_project([(t(rgb), t(depth), None)], -1, DEPTH_SCALE, t(tgt), h, w)
@@ -237,6 +260,9 @@ def test_project_wide_features_take_the_scatter_path():
   d_g, f_g = pano_utils.project_feats_to_equirectangular(t(feats), t(xyz), h, w, -1, DEPTH_SCALE)
   np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
   np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+  d_n, f_n = np_project(feats, xyz, h, w, -1)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_n)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_n)
 
 
 def test_project_edge_cases():
@@ -255,6 +281,9 @@ def test_project_edge_cases():
   d_g, f_g = pano_utils.project_feats_to_equirectangular(t(feats), t(xyz), h, w, -1, DEPTH_SCALE)
   np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
   np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+  d_n, f_n = np_project(feats, xyz, h, w, -1)   # (the independent statement, here and below)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_n)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_n)
   # heavy collisions: all points in a few pixels, scalar uint8 semantic feats
   xyz = (rng.standard_normal((1, 4, 5000)) * 0.01 + np.array([1, 1, 1, 0])[None, :, None]).astype(F32)
   sem = rng.integers(0, 42, (1, 5000)).astype(np.uint8)
@@ -262,6 +291,9 @@ def test_project_edge_cases():
   d_g, f_g = pano_utils.project_feats_to_equirectangular(t(sem), t(xyz), h, w, 0, DEPTH_SCALE)
   np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
   np.testing.assert_array_equal(f_g.cpu().numpy(), f_o)
+  d_n, f_n = np_project(sem, xyz, h, w, 0)
+  np.testing.assert_array_equal(d_g.cpu().numpy(), d_n)
+  np.testing.assert_array_equal(f_g.cpu().numpy(), f_n)
   with pytest.raises(ValueError):
     pano_utils.project_feats_to_equirectangular(torch.zeros((1, 2, 3, 4), device=d),
                                                 torch.zeros((1, 4, 2), device=d), h, w, 0, 20.0)
@@ -389,8 +421,11 @@ _SORT = dict(SE3DS_SPLAT_SORT='2')    # round 4: sorted chunks + gathering resol
     dict(_OLD, SE3DS_SPLAT_SLICE='48'),                    # three-pass, 20-byte records, every tile banded
     dict(_SORT, SE3DS_SPLAT_PTS='16'),                     # sorted chunks (16 points / thread) + gathering resolve
     dict(_SORT, SE3DS_SPLAT_PTS='8'),                      # ... 8 points / thread (4096-point chunks)
+    dict(_SORT, SE3DS_SPLAT_PTS='4'),                      # ... 4 points / thread (2048-point chunks: what 512 x 1024 takes)
     dict(_SORT, SE3DS_SPLAT_SUPERPX='4096'),               # ... supertiles of 4096 pixels (two rows at 1024 x 2048)
-], ids=['packed-banded', 'three-pass-banded', 'sorted-16pt', 'sorted-8pt', 'sorted-4096px'])
+    dict(_SORT, SE3DS_SPLAT_SUPERPX='512'),                # ... of 512 pixels (small images: column strips)
+], ids=['packed-banded', 'three-pass-banded', 'sorted-16pt', 'sorted-8pt', 'sorted-4pt', 'sorted-4096px',
+        'sorted-512px'])
 def test_splat_banded_tiles_bit_exact(env_extra):
   """The splat parity tests re-run in a child process under switches that are read once per
   process: tiny slices (every tile of the small parity images is cut into bands of rows, in the
@@ -437,6 +472,9 @@ def test_packed_splat_variants_and_byte_range_promise():
                                                                  mask_void=0)
     np.testing.assert_array_equal(d_g.cpu().numpy(), d_o, err_msg=str((m, c, dt)))
     np.testing.assert_array_equal(f_g.cpu().numpy(), f_o, err_msg=str((m, c, dt)))
+    d_n, f_n = np_project(feats, xyz, h, w, void, offset=off)   # (independent NumPy / libm statement)
+    np.testing.assert_array_equal(d_g.cpu().numpy(), d_n, err_msg=str((m, c, dt)))
+    np.testing.assert_array_equal(f_g.cpu().numpy(), f_n, err_msg=str((m, c, dt)))
   # the cache follows torch's version counter: an in-place edit re-runs the check
   tf = t(rng.integers(0, 256, (1, 1000, 3)).astype(np.int32))
   assert point_cloud_utils.byte_range(tf, -1)
@@ -580,7 +618,7 @@ def test_resize_branches_size_mult_crop_resize_and_mean_padding():
 def test_device_fast_screen_error_bound(h):
   """The fast index screen as the DEVICE evaluates it (hardware reciprocal / square root inside,
   include/se3ds_geom_math.h): every index it decides equals the exact chain's, and its deviation
-  from the exact (fx, fy) stays >= 8x below the margin -- over 4.4 M points incl. the wrap, the
+  from the exact (fx, fy) stays >= 5x below the margin -- over 4.4 M points incl. the wrap, the
   poles, the equator, denormal-scale clouds and exact ties."""
   rng = np.random.default_rng(50 + h)
   w, m = 2 * h, 400_000
@@ -594,8 +632,9 @@ def test_device_fast_screen_error_bound(h):
   clouds.append(v)
   clouds.append(rng.standard_normal((3, m)) * 1e-18)
   clouds.append(rng.integers(-3, 4, (3, m)).astype(np.float64))
-  margin = 4.0e-6   # SE3DS_FAST_MARGIN
+  margin = 2.0e-6   # SE3DS_FAST_MARGIN
   decided_total = 0
+  worst = [0.0, 0.0]
   for c in clouds:
     xyz = c.astype(F32)
     proj = warp_c.equirect_project_coords(np.concatenate([xyz, np.ones((1, m), F32)])[None])[0]
@@ -616,8 +655,10 @@ def test_device_fast_screen_error_bound(h):
     dx = np.abs(gx[fin].astype(np.float64) - fx[fin]) / w
     dy = np.abs(gy[fin].astype(np.float64) - fy[fin]) / h
     dx = dx[dx < 0.99]   # the heading wrap: both chains sit on an integer, the screen abstains
-    assert dx.size == 0 or dx.max() <= margin / 8, dx.max()
-    assert dy.size == 0 or dy.max() <= margin / 8, dy.max()
+    worst = [max(worst[0], dx.max() if dx.size else 0.0), max(worst[1], dy.max() if dy.size else 0.0)]
+    assert dx.size == 0 or dx.max() <= margin / 5, dx.max()
+    assert dy.size == 0 or dy.max() <= margin / 5, dy.max()
+  print(f'device screen, height {h}: max |dfx| / W = {worst[0]:.3g}, max |dfy| / H = {worst[1]:.3g} (margin {margin:g})')
   assert decided_total > 0.5 * len(clouds) * m
 
 

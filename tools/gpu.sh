@@ -6,7 +6,7 @@
 #   smoke                       __graft_entry__.smoke()
 #   bench [bench.py args]       default bench line -> gpurun_out/bench_default.log
 #   ab 'ENV=v ENV=v' ...        A/B of the gan_step bench under env settings (baseline first), 2 reps
-#   abwarp 'ENV=v' ...          the same for --workload warp (random and room depth)
+#   abwarp 'ENV=v' ...          the same for --workload warp (random and room depth; WARP_H=512 in the environment: at that height)
 #   prof_step TAG [ENV=v ...]   rocprofv3 kernel stats of the default bench -> gpurun_out/TAG_kernel_stats.csv
 #   prof_warp TAG [ENV=v ...]   kernel stats of the warp bench, random + room depth
 #   pmc_conv TAG "SHAPE"        MFMA-busy / FETCH / WRITE counters of tools/one_conv.py SHAPE (3 passes)
@@ -51,7 +51,7 @@ task_abwarp() {
     for v in "SE3DS_NOP=1" "$@"; do
       for d in random room; do
         echo "== $v ($d)"
-        env $v timeout 300 python bench.py --workload warp --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline 2>gpurun_out/ab.err | python -c "import json,sys
+        env $v timeout 300 python bench.py --workload warp --warp-height ${WARP_H:-1024} --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline 2>gpurun_out/ab.err | python -c "import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']
 print('us/render %.1f frac %.4f step_ms %.4f' % (1e3*r['ms_per_launch'], r['frac'], d['ms_per_step']))" || tail -5 gpurun_out/ab.err
       done
@@ -76,8 +76,8 @@ task_prof_warp() {
   for v in "$@"; do export "$v"; done
   for d in random room; do
     rm -rf gpurun_out/prof_tmp
-    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o warp -- python bench.py --workload warp --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
-    python tools/rocpd_summary.py gpurun_out/prof_tmp/warp_results.db gpurun_out/${tag}_warp_${d}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload warp --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline"
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tmp -o warp -- python bench.py --workload warp --warp-height ${WARP_H:-1024} --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
+    python tools/rocpd_summary.py gpurun_out/prof_tmp/warp_results.db gpurun_out/${tag}_warp_${d}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --workload warp --warp-height ${WARP_H:-1024} --warp-depth $d --steps 200 --warmup 20 --no-cpu-baseline"
     head -9 gpurun_out/${tag}_warp_${d}_kernel_stats.csv | cut -c1-150
   done
   rm -rf gpurun_out/prof_tmp
