@@ -656,6 +656,50 @@ def _grad_mark(var):
 _WS = {}
 
 
+def make_stream(device, role: str):
+  """A side stream of the step's schedule (`role`: 'branch1' / 'branch2' = the two decoders,
+  'optimizer', 'discriminator', 'wgrad').  SE3DS_CU_MASK (round 6, VERDICT r5 item 4 -- the measured
+  attempt at CO-RUNNING the HBM-bound kernels under the convolutions: an 8-wave conv workgroup at 256
+  registers per lane owns a CU's whole register file and 150 KB of its LDS, so a kernel of another
+  stream only ever gets CUs between conv workgroups; a CU mask gives it CUs of its own) selects a
+  plan of `hipExtStreamCreateWithCUMask` masks:
+    halves     branch1 on CUs 0-127, branch2 on 128-255 (contiguous in the mask's enumeration)
+    alternate  branch1 on the even, branch2 on the odd CUs
+    opt32 / opt64   only the optimizer stream is confined, to the last 32 / 64 CUs
+  Unset (the default, and what every measurement outside tools/probes/cu_mask_ab.sh runs): plain
+  streams.  DESIGN.md section 3.4 has the A/B."""
+  plan = os.environ.get('SE3DS_CU_MASK')
+  dev = torch.device(device)
+  mask = None
+  if plan and dev.type == 'cuda':
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    bits = None
+    if plan == 'halves' and role in ('branch1', 'branch2'):
+      bits = [(i < ncu // 2) == (role == 'branch1') for i in range(ncu)]
+    elif plan == 'alternate' and role in ('branch1', 'branch2'):
+      bits = [(i % 2 == 0) == (role == 'branch1') for i in range(ncu)]
+    elif plan in ('opt32', 'opt64') and role == 'optimizer':
+      k = int(plan[3:])
+      bits = [i >= ncu - k for i in range(ncu)]
+    if bits is not None:
+      words = (ncu + 31) // 32
+      mask = [0] * words
+      for i, b in enumerate(bits):
+        if b:
+          mask[i // 32] |= 1 << (i % 32)
+  if mask is None:
+    return torch.cuda.Stream(dev)
+  import ctypes
+  hip = ctypes.CDLL('libamdhip64.so')
+  st = ctypes.c_void_p()
+  arr = (ctypes.c_uint32 * len(mask))(*mask)
+  with torch.cuda.device(dev):
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(len(mask)), arr)
+  if rc != 0:
+    raise _lib.Se3dsHipError(f'hipExtStreamCreateWithCUMask failed ({rc}) for SE3DS_CU_MASK={plan}')
+  return torch.cuda.ExternalStream(st.value, device=dev)
+
+
 class ConvProfiler:
   """HIP-event timing of every convolution launch (bench.py roofline leg).  Events are
   recorded on the stream the kernels are launched on (torch's current stream)."""

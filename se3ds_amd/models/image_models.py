@@ -89,7 +89,7 @@ class _Model:
       # so it is opt-in, SE3DS_DUAL_STREAM_DP=1, until tests/test_dist_gpu.py's two-GPU tests have
       # passed on hardware; the default multi-replica step is the single-stream schedule)
       if getattr(self, '_branch_streams', None) is None:
-        self._branch_streams = {1: torch.cuda.Stream(self.device), 2: torch.cuda.Stream(self.device)}
+        self._branch_streams = {1: nn.make_stream(self.device, 'branch1'), 2: nn.make_stream(self.device, 'branch2')}
       ctx.streams = self._branch_streams
       if _DUAL_PHASES:
         ctx.stream_phases = tuple(_DUAL_PHASES.split(','))

@@ -169,7 +169,7 @@ class GAN(gan_manager.GANManager):
 
   def _optimizer_stream(self, dev):
     if getattr(self, '_opt_stream', None) is None:
-      self._opt_stream = torch.cuda.Stream(dev)
+      self._opt_stream = nn.make_stream(dev, 'optimizer')
     return self._opt_stream
 
   def _grad_sync(self):

@@ -45,6 +45,7 @@ OWNERS = {
     'SE3DS_DEFER_WGRAD_REDUCE': ('tools/step_compare.py', 'SE3DS_DEFER_WGRAD_REDUCE'),
     'SE3DS_WGRAD_STREAM': ('tools/step_compare.py', 'SE3DS_WGRAD_STREAM'),
     'SE3DS_D_OVERLAP': ('tools/step_compare.py', 'SE3DS_D_OVERLAP'),
+    'SE3DS_CU_MASK': ('tools/probes/cu_mask_ab.sh', 'SE3DS_CU_MASK'),
     'SE3DS_UNFUSED_EMA': ('tests/test_nets_gpu.py', 'SE3DS_UNFUSED_EMA'),
     # several replicas
     'SE3DS_DUAL_STREAM_DP': ('tests/test_dist_gpu.py', 'SE3DS_DUAL_STREAM_DP'),
