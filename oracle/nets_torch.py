@@ -195,17 +195,26 @@ class Net:
     # norm / conv layer whose output is activated.  acts: tag -> pre-activation (recorded).
     self.decisions = None
     self.pre_acts = None
+    # test hook (tools/bf16_attribution.py): quant(x, site) -> tensor, called where the bf16 device
+    # path STORES a tensor -- 'weight' (the operand copy of a kernel), 'conv' (a convolution's output),
+    # 'act' (normalised + activated), 'norm' (normalised, not activated, stored on its own), 'res' (the
+    # residual stream: a block's output), 'add' (a skip connection's sum), 'resgrad' (identity on the
+    # block input as the residual operand: its GRADIENT is a stored tensor).  None: no-op.
+    self.quant = None
+
+  def q(self, x, site):
+    return x if self.quant is None else self.quant(x, site)
 
   def get(self, name):
     return self.p[name]
 
-  def act(self, x, tag, alpha=0.0):
+  def act(self, x, tag, alpha=0.0, site='act'):
     """ReLU (alpha 0) / LeakyReLU(alpha) of the tensor produced by layer `tag`."""
     if self.pre_acts is not None:
       self.pre_acts[tag] = x.detach()
     if self.decisions is not None and tag in self.decisions:
-      return torch.where(self.decisions[tag], x, x * alpha)
-    return torch.where(x > 0, x, x * alpha) if alpha else F.relu(x)
+      return self.q(torch.where(self.decisions[tag], x, x * alpha), site)
+    return self.q(torch.where(x > 0, x, x * alpha) if alpha else F.relu(x), site)
 
   def has(self, name):
     return name in self.p
@@ -237,10 +246,10 @@ class Net:
     return x * inv + (b - mean * inv)
 
   def conv2d(self, x, name, stride=1, padding='VALID'):
-    y = tf_conv2d(x, self.get(name + '/kernel'), stride, padding)
+    y = tf_conv2d(x, self.q(self.get(name + '/kernel'), 'weight'), stride, padding)
     if self.has(name + '/bias'):
       y = y + self.get(name + '/bias')
-    return y
+    return self.q(y, 'conv')
 
   def spectral_conv(self, x, name, stride=1, padding='VALID'):
     """layers.py:299-347."""
@@ -248,7 +257,10 @@ class Net:
     sigma, u_hat = power_iteration(kernel, self.get(name + '/u'))
     if self.training:
       self.updates[name + '/u'] = u_hat
-    if kernel.dtype == torch.float64 and _F64_DIV_OUTPUT:
+    if self.quant is not None:
+      # (the device path rounds the RAW kernel to its operand dtype and applies 1 / sigma in the epilogue)
+      y = tf_conv2d(x, self.q(kernel, 'weight'), stride, padding) / (sigma + 1e-10)
+    elif kernel.dtype == torch.float64 and _F64_DIV_OUTPUT:
       # binary64 yardstick runs: conv(x, W / s) = conv(x, W) / s -- the division runs over the
       # activation instead of materialising (and keeping for the backward pass) a normalised copy
       # of every kernel, 9 GB at the real dimensions; same value up to binary64 rounding
@@ -258,7 +270,7 @@ class Net:
       y = tf_conv2d(x, w_norm, stride, padding)
     if self.has(name + '/bias'):
       y = y + self.get(name + '/bias')
-    return y
+    return self.q(y, 'conv')
 
   def conv_fn(self, spectral):
     return self.spectral_conv if spectral else self.conv2d
@@ -280,19 +292,19 @@ class Net:
       if self.training:
         self.updates[name + '/u'] = u_hat
       # w_norm is computed by the reference but NOT used (layers.py:189-195)
-    out = tf_conv2d(out, kernel, stride, padding)
+    out = tf_conv2d(out, self.q(kernel, 'weight'), stride, padding)
     if self.has(name + '/bias'):
       bias = self.get(name + '/bias').reshape(1, 1, 1, -1)
       out = (out - bias) * mask_ratio + bias
       out = out * update_mask
     else:
       out = out * mask_ratio
-    return out, update_mask
+    return self.q(out, 'conv'), update_mask
 
   def conv_transpose(self, x, name, stride=2):
-    return keras_conv2d_transpose(x, self.get(name + '/kernel'),
-                                  self.get(name + '/bias') if self.has(name + '/bias') else None,
-                                  stride)
+    return self.q(keras_conv2d_transpose(x, self.q(self.get(name + '/kernel'), 'weight'),
+                                         self.get(name + '/bias') if self.has(name + '/bias') else None,
+                                         stride), 'conv')
 
   def pad(self, x, p, circular=True):
     return pad_layer(x, p, circular_pad=circular, training=self.training)
@@ -300,7 +312,7 @@ class Net:
   # -- blocks -----------------------------------------------------------------------------
   def bottleneck(self, x, mask, name, stride, has_ds, ds_name, spectral, circular):
     """layers.py:253-272."""
-    residual = x
+    residual = self.q(x, 'resgrad')
     out, um = self.partial_conv(x, mask, name + '/conv1', 1, 'SAME', spectral)
     out = self.act(self.sync_bn(out, name + '/bn1'), name + '/bn1')
     out = self.pad(out, 1, circular)
@@ -311,8 +323,8 @@ class Net:
     out = self.sync_bn(out, name + '/bn3')
     if has_ds:
       residual, _ = self.partial_conv(x, mask, ds_name, stride, 'SAME', spectral)
-      residual = self.sync_bn(residual, name + '/ds_norm')
-    return self.act(out + residual, name + '/bn3'), um
+      residual = self.q(self.sync_bn(residual, name + '/ds_norm'), 'norm')
+    return self.act(out + residual, name + '/bn3', site='res'), um
 
   def res_stack(self, x, mask, name, inplanes, planes, blocks, stride, spectral, circular,
                 expansion=4):
@@ -334,12 +346,12 @@ class Net:
     else:
       out = conv(self.pad(out, 1, circular), name + '/conv_b', stride, 'VALID')
     out = self.sync_bn(out, name + '/bn_b')
-    residual = x
+    residual = self.q(x, 'resgrad')
     if up_kind == 'convT':
-      residual = self.sync_bn(self.conv_transpose(x, up_name + '/conv', stride), up_name + '/bn')
+      residual = self.q(self.sync_bn(self.conv_transpose(x, up_name + '/conv', stride), up_name + '/bn'), 'norm')
     elif up_kind == 'conv1x1':
-      residual = self.sync_bn(conv(x, up_name + '/conv', 1, 'VALID'), up_name + '/bn')
-    return self.act(out + residual, name + '/bn_b')
+      residual = self.q(self.sync_bn(conv(x, up_name + '/conv', 1, 'VALID'), up_name + '/bn'), 'norm')
+    return self.act(out + residual, name + '/bn_b', site='res')
 
   def res_stack_transpose(self, x, name, inplanes, planes, blocks, stride, spectral, circular):
     """layers.py:458-511."""
@@ -404,13 +416,13 @@ def decoder(net, x, skip, d, version, spectral, name):
   blocks = DEC_BLOCKS[version]
   out = agent(out, 'agent4')
   out = net.res_stack_transpose(out, name + '/deconv1', d * 8, d * 4, blocks[0], 1, spectral, True)
-  out = out + agent(skip[3], 'agent3')
+  out = net.q(out + agent(skip[3], 'agent3'), 'add')
   out = net.res_stack_transpose(out, name + '/deconv2', d * 4, d * 2, blocks[1], 2, spectral, True)
-  out = out + agent(skip[2], 'agent2')
+  out = net.q(out + agent(skip[2], 'agent2'), 'add')
   out = net.res_stack_transpose(out, name + '/deconv3', d * 2, d, blocks[2], 2, spectral, True)
-  out = out + agent(skip[1], 'agent1')
+  out = net.q(out + agent(skip[1], 'agent1'), 'add')
   out = net.res_stack_transpose(out, name + '/deconv4', d, d, blocks[3], 2, spectral, True)
-  out = out + agent(skip[0], 'agent0')
+  out = net.q(out + agent(skip[0], 'agent0'), 'add')
   out = net.res_stack_transpose(out, name + '/final_conv', d, d, 3, 1, False, True)
   return net.conv_transpose(out, name + '/final_deconv', 2)
 
@@ -419,7 +431,7 @@ def head(net, x, name, spectral):
   """image_models.py:79-104."""
   conv = net.conv_fn(spectral)
   for i in range(3):
-    x = net.sync_bn(x, name + f'/bn{i}')
+    x = net.q(net.sync_bn(x, name + f'/bn{i}'), 'norm')
     x = conv(net.pad(x, 1), name + f'/conv{i}', 1, 'VALID')
     if i < 2:
       x = net.act(x, name + f'/conv{i}', 0.3)
@@ -428,9 +440,10 @@ def head(net, x, name, spectral):
 
 def generator_forward(params, cond, training, gen_dims, resnet_version='50', context_layer='convs',
                       conv_mode='spectral', use_blurred_mask=True, z_dim=128, stats_hook=None,
-                      taps=None, bn_training=None):
+                      taps=None, bn_training=None, quant=None):
   """image_models.py:132-193.  Returns (outputs list, net.updates)."""
   net = Net(params, training, stats_hook, bn_training)
+  net.quant = quant
   spectral = conv_mode == 'spectral'
   d = gen_dims
   parts = [cond['proj_image'], cond['proj_depth']]
@@ -442,7 +455,7 @@ def generator_forward(params, cond, training, gen_dims, resnet_version='50', con
     taps.update(b1=skip[0], s1=skip[1], s2=skip[2], s3=skip[3], enc=hidden)
   if context_layer == 'convs':
     for i in range(4):
-      hidden = net.sync_bn(hidden, f'context/bn{i}')
+      hidden = net.q(net.sync_bn(hidden, f'context/bn{i}'), 'norm')
       hidden = net.spectral_conv(net.pad(hidden, 1), f'context/conv{i}', 1, 'VALID')
       if i < 3:
         hidden = net.act(hidden, f'context/conv{i}', 0.3)

@@ -75,6 +75,8 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
   t0 = time.perf_counter()
   for _ in range(args.steps):
     step()
+  torch.cuda.synchronize()
+  own_dt = time.perf_counter() - t0   # (this rank's own time; the barrier below waits for the slowest)
   barrier(world)
   dt = max_over_ranks(time.perf_counter() - t0, world, dev)
   ms = 1e3 * dt / args.steps
@@ -148,6 +150,34 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
     torch.cuda.synchronize()
     out['collectives_per_step'] = dist_utils.summarize_collectives(dist_utils.COLLECTIVE_LOG)
     dist_utils.COLLECTIVE_LOG = None
+    # ... and one with HIP events around every collective (round 6: the first scaling curve has to say
+    # where its missing fraction went): `exposed_syncbn_ms` = time the compute stream was held by the
+    # SyncBN sums; `grad_bucket_ms` = busy time of the gradient buckets on their side stream (hidden
+    # under the backward pass unless `finish_wait_ms` -- how long Adam waited for the last ones -- says
+    # otherwise); `finish_buckets` = buckets the drip pacing had not sent by the end of the backward pass
+    dist_utils.COLLECTIVE_EVENTS = []
+    t1 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    inst_ms = 1e3 * (time.perf_counter() - t1)
+    ev = dist_utils.summarize_collective_events(dist_utils.COLLECTIVE_EVENTS)
+    dist_utils.COLLECTIVE_EVENTS = None
+    sync = getattr(gan, '_sync', None)
+    out['collectives_per_step']['device'] = {
+        'exposed_syncbn_ms': sum(v['ms'] for k, v in ev.items() if k.startswith('syncbn')),
+        'syncbn_us_each': 1e3 * sum(v['ms'] for k, v in ev.items() if k.startswith('syncbn')) /
+                          max(1, sum(v['count'] for k, v in ev.items() if k.startswith('syncbn'))),
+        'grad_bucket_ms': ev.get('grad_bucket', {}).get('ms', 0.0),
+        'finish_wait_ms': ev.get('finish_wait', {}).get('ms', 0.0),
+        'finish_buckets': getattr(sync, 'last_finish_buckets', None),
+        'instrumented_step_ms': inst_ms,
+        'by_kind': ev}
+    # every rank's own time for the timed steps (the line's `ms_per_step` is their maximum)
+    import torch.distributed as dist
+    mine = torch.tensor([1e3 * own_dt / args.steps], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    out['ms_per_step_by_rank'] = [float(t.item()) for t in allr]
   if world == 1 and not getattr(args, 'no_shipped', False):
     out['shipped_schedule'] = shipped_schedule(gan, n, h, dev, rank)
   if world == 1 and args.batch <= 0 and h == 512 and not getattr(args, 'no_batch_max', False):

@@ -32,6 +32,11 @@ def _log_collective(kind, numel):
   dist_utils.log_collective(kind, numel)
 
 
+def _all_reduce_sum(t, group, kind):
+  from se3ds_amd.trainers import dist_utils
+  dist_utils.all_reduce_sum(t, group, kind)
+
+
 def _chk(rc, what):
   _lib.check(rc, what)
 
@@ -420,10 +425,9 @@ class Ctx:
   def _allreduce_joint(self, a, b):
     """ONE all-reduce for two tensors (a pair of SyncBN sums)."""
     buf = torch.cat([a.reshape(-1), b.reshape(-1)])
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+    _all_reduce_sum(buf, self.group, 'syncbn_pair')
     a.copy_(buf[:a.numel()].view_as(a))
     b.copy_(buf[a.numel():].view_as(b))
-    _log_collective('syncbn_pair', buf.numel())
     self._after_collective()
 
   def _after_collective(self):
@@ -438,8 +442,7 @@ class Ctx:
       if pair is not None and self.branch_tag:
         pair.allreduce(t, self.branch_tag)   # forward of two branches in lockstep threads
         return
-      dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-      _log_collective('syncbn', t.numel())
+      _all_reduce_sum(t, self.group, 'syncbn')
       self._after_collective()
 
   def allreduce_then(self, t, cont):

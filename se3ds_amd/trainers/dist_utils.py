@@ -24,6 +24,38 @@ def log_collective(kind, numel):
     COLLECTIVE_LOG.append((kind, int(numel), time.perf_counter()))
 
 
+# The same step seen from the DEVICE (bench.py --gpus N, one instrumented step): None = off, else a list
+# of (kind, start event, end event) recorded on the stream each collective was issued on -- for the
+# SyncBN sums that is the compute stream, so their summed durations are time the step was HELD by
+# communication; for the gradient buckets it is GradSync's side stream (busy time, hidden unless
+# finish() has to wait: 'finish_wait').
+COLLECTIVE_EVENTS = None
+
+
+def all_reduce_sum(t, group, kind):
+  """SUM all-reduce of `t` in place + the two logs above."""
+  evs = COLLECTIVE_EVENTS
+  if evs is not None and t.is_cuda:
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    e1.record()
+    evs.append((kind, e0, e1))
+  else:
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+  log_collective(kind, t.numel())
+
+
+def summarize_collective_events(evs):
+  """{kind: {count, ms}} from COLLECTIVE_EVENTS (call after a device synchronise)."""
+  out = {}
+  for kind, e0, e1 in evs:
+    e = out.setdefault(kind, {'count': 0, 'ms': 0.0})
+    e['count'] += 1
+    e['ms'] += e0.elapsed_time(e1)
+  return out
+
+
 def summarize_collectives(log):
   """{kind: count, elements, bytes}, totals and the median host-side spacing of the SyncBN sums."""
   out = {}
@@ -116,8 +148,7 @@ class GradSync:
     with torch.cuda.stream(self.side):
       self.side.wait_event(ready)
       if world_size(self.group) > 1:
-        dist.all_reduce(arena[o:o + n], op=dist.ReduceOp.SUM, group=self.group)
-        log_collective('grad_bucket', n)
+        all_reduce_sum(arena[o:o + n], self.group, 'grad_bucket')
 
   def reduce_range(self, arena: torch.Tensor, e0: int, e1: int):
     ready = torch.cuda.Event()
@@ -158,5 +189,14 @@ class GradSync:
 
   def finish(self):
     self.last_finish_buckets = self._end_step()
-    torch.cuda.current_stream(self.device).wait_stream(self.side)
+    evs = COLLECTIVE_EVENTS
+    main = torch.cuda.current_stream(self.device)
+    if evs is not None:
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record(main)
+      main.wait_stream(self.side)
+      e1.record(main)
+      evs.append(('finish_wait', e0, e1))   # how long Adam waited for the last buckets
+    else:
+      main.wait_stream(self.side)
     self.launched = []

@@ -127,6 +127,15 @@ def test_bench_gan_step_two_gloo_ranks_on_one_gpu():
   assert pairs // 2 == 85 and singles + pairs == 2 * (279 - 85), cps
   grad_bytes = sum(cps.get(k, {'bytes': 0})['bytes'] for k in ('grad_bucket', 'grad_arena'))
   assert 4.4e9 < grad_bytes < 4.8e9, cps
+  # round 6: the same step seen from the device -- HIP events around every collective on the stream
+  # it was issued on -- and every rank's own step time, so that the first scaling file explains itself
+  dev_side = cps['device']
+  by = dev_side['by_kind']
+  assert by['syncbn']['count'] == singles and by['syncbn_pair']['count'] == pairs, by
+  assert by['grad_bucket']['count'] == cps['grad_bucket']['count'] and by['finish_wait']['count'] >= 1, by
+  assert dev_side['exposed_syncbn_ms'] > 0 and dev_side['grad_bucket_ms'] > 0 and dev_side['finish_wait_ms'] >= 0
+  assert dev_side['finish_buckets'] is not None and dev_side['finish_buckets'] >= 0
+  assert len(out['ms_per_step_by_rank']) == 2 and max(out['ms_per_step_by_rank']) <= out['ms_per_step'] * 1.001
 
 
 def test_gan_step_on_two_gpus_over_rccl():
