@@ -273,10 +273,12 @@ def fp32_step(gan, h, dev, rank, nb=2, steps=2):
     torch.cuda.empty_cache()
 
 
-def batch_max(gan, h, dev, rank, candidates=(24, 16), steps=3):
+def batch_max(gan, h, dev, rank, candidates=(32, 24, 16), steps=3):
   """Throughput of the same step at the largest per-GPU batch that fits (the batch-independent
-  part -- optimiser, operand staging, launch ramps -- is amortised): one warm-up + `steps` timed
-  steps.  Falls back to the next candidate when the allocation fails."""
+  part -- optimiser, operand staging, launch ramps -- is amortised): two warm-up + `steps` timed
+  steps, then (round 6) one instrumented step for the conv family's own roofline at that batch.
+  Falls back to the next candidate when the allocation fails.  Batch 32 fits since round 6 was
+  measured (265 GiB of the 288 GB): SURVEY 8d's "cfg3 N = B, largest that fits; report B"."""
   import gc
   degraded = False   # a candidate failed mid-step: later figures come from a half-stepped model
   for nb in candidates:
@@ -295,10 +297,30 @@ def batch_max(gan, h, dev, rank, candidates=(24, 16), steps=3):
         gan.global_step += gan.num_batched_steps
       torch.cuda.synchronize()
       dt = time.perf_counter() - t0
-      return {'per_gpu_batch': nb, 'value': nb * steps / dt, 'unit': 'panoramas/sec',
-              'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': 2,
-              'hbm_gib_peak': torch.cuda.max_memory_allocated(dev) / 2**30,
-              'degraded': degraded}
+      res = {'per_gpu_batch': nb, 'value': nb * steps / dt, 'unit': 'panoramas/sec',
+             'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'warmup': 2,
+             'hbm_gib_peak': torch.cuda.max_memory_allocated(dev) / 2**30,
+             'degraded': degraded, 'roofline': None}
+      try:   # the conv family alone at this batch (serial instrumented step, as the main line's `frac`)
+        for _ in range(2):
+          prof = nn.ConvProfiler()
+          nn.set_conv_profiler(prof)
+          gan.train_g_d(big)
+          gan.global_step += gan.num_batched_steps
+          torch.cuda.synchronize()
+          nn.set_conv_profiler(None)
+        summ = prof.summary()
+        ach = summ['flops'] / (summ['ms'] * 1e-3) / 1e12
+        res['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': ach / BF16_PEAK_TFLOPS, 'conv_ms_per_step': summ['ms'],
+                           'conv_tflop_per_step': summ['flops'] / 1e12,
+                           'frac_in_step': summ['flops'] / (dt / steps) / 1e12 / BF16_PEAK_TFLOPS}
+        res['hbm_gib_peak'] = torch.cuda.max_memory_allocated(dev) / 2**30
+      except (torch.OutOfMemoryError, RuntimeError) as e:   # (the serial path's extra workspaces did not fit)
+        nn.set_conv_profiler(None)
+        res['roofline_error'] = repr(e)[:200]
+        torch.cuda.synchronize()
+      return res
     except (torch.OutOfMemoryError, RuntimeError) as e:   # does not fit: next candidate
       last = repr(e)[:200]
       big = None
