@@ -440,7 +440,11 @@ def test_splat_banded_tiles_bit_exact(env_extra):
   env = dict(os.environ, PYTHONPATH=root, **env_extra)
   env.pop('SE3DS_SPLAT_SCATTER', None)
   r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_warp_gpu.py'),
-                      '-q', '-x', '-m', 'gpu', '-k', 'project and not banded'],
+                      '-q', '-x', '-m', 'gpu',
+                      # (round 6: also the uint8 / 1-2 channel / ragged-tail cases and the trajectory step,
+                      #  so that every template variant of the sort kernel meets them)
+                      '-k', ('(project or trajectory) and not banded' if 'SE3DS_SPLAT_PACKED' in env_extra else
+                             '(project or packed_splat or trajectory) and not banded')],   # (the promise verdict is the packed paths')
                      env=env, cwd=root, capture_output=True, text=True, timeout=600)
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
   assert ' passed' in r.stdout
