@@ -503,11 +503,35 @@ __device__ __forceinline__ f32x2 atan2_fast2(f32x2 y, f32x2 x) {
   }
   return r;
 }
+// The IEEE square root and quotient of the screen WITHOUT their range scaling (round 6: 27 of the screen's
+// 74 instructions per point were these two).  sqrt_rn_mid is the compiler's own expansion of sqrtf --
+// v_sqrt_f32 (1 ulp), then the two neighbours checked with exact fma residuals -- minus the rescaling of
+// arguments below 2^-96, so it returns the correctly rounded root (bit for bit `__builtin_sqrtf`) for
+// x >= 2^-96; the screen only ACCEPTS points with rad > 1e-14 (rad^2 > 2^-93), everything else takes the
+// exact chain, which computes its own rad.  div_rn_mid likewise is the v_div_* sequence minus
+// v_div_scale / v_div_fixup: identical to IEEE division unless an intermediate leaves the normal range,
+// which for |z| <= rad in [1e-14, 1e30] only happens for quotients so small that the elevation does not
+// see their last bits (the reference's rounded quotient matters next to the poles, |w| -> 1).
+__device__ __forceinline__ float sqrt_rn_mid(float x) {
+  float s = __builtin_amdgcn_sqrtf(x);
+  const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+  s = rm <= 0.0f ? sm : s;
+  s = rp > 0.0f ? sp : s;
+  return s;
+}
+__device__ __forceinline__ float div_rn_mid(float n, float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+  float q = n * r;
+  q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+  return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
 // se3ds_equirect_fxy_fast on two points (camera-relative x, y, z): fx, fy and rad.
 __device__ __forceinline__ void equirect_fxy_fast2(f32x2 x, f32x2 y, f32x2 z, float fwidth, float fheight,
                                                    f32x2* fx, f32x2* fy, f32x2* rad_out) {
   const f32x2 s2 = (x * x + y * y) + z * z;
-  const f32x2 rad = {__builtin_sqrtf(s2.x), __builtin_sqrtf(s2.y)};   // IEEE: rad IS an output (depth)
+  const f32x2 rad = {sqrt_rn_mid(s2.x), sqrt_rn_mid(s2.y)};   // correctly rounded where accepted: rad IS an output (depth)
   *rad_out = rad;
   f32x2 heading = splat2(SE3DS_F32_ONE_HALF_PI) - atan2_fast2<false>(y, x);
   // (1.5 pi - atan2 lies in [0.5 pi, 2.5 pi]: the scalar chain's "+ 2 pi if <= 0" never fires here)
@@ -515,7 +539,7 @@ __device__ __forceinline__ void equirect_fxy_fast2(f32x2 x, f32x2 y, f32x2 z, fl
   heading.x = heading.x > SE3DS_F32_TWO_PI ? hw.x : heading.x;
   heading.y = heading.y > SE3DS_F32_TWO_PI ? hw.y : heading.y;
   // w must be the reference's individually rounded quotient (se3ds_equirect_fxy_fast)
-  const f32x2 w = {z.x / rad.x, z.y / rad.y};
+  const f32x2 w = {div_rn_mid(z.x, rad.x), div_rn_mid(z.y, rad.y)};
   const f32x2 t = (splat2(1.0f) - w) * (splat2(1.0f) + w);
   const f32x2 st = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
   const f32x2 elevation = atan2_fast2<true>(st, w);
@@ -525,7 +549,8 @@ __device__ __forceinline__ void equirect_fxy_fast2(f32x2 x, f32x2 y, f32x2 z, fl
 // the verdict of se3ds_equirect_uv_fast on one point of a pair
 __device__ __forceinline__ bool screen_decided(float fx, float fy, float rad, float mx, float my) {
   const float dx = __builtin_fabsf(fx - __builtin_rintf(fx)), dy = __builtin_fabsf(fy - __builtin_rintf(fy));
-  return (dx > mx) && (dy > my) && (rad > 1.0e-30f) && (rad < 1.0e30f);
+  // (rad > 1e-14: the range in which sqrt_rn_mid / div_rn_mid are the IEEE results, see there)
+  return (dx > mx) && (dy > my) && (rad > 1.0e-14f) && (rad < 1.0e30f);
 }
 
 // Parity tap of the DEVICE fast screen (se3ds_geom_math.h: v_rcp_f32 / v_sqrt_f32 inside): fx, fy
