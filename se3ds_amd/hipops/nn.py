@@ -1023,7 +1023,16 @@ class SpectralGroup:
          'se3ds_spectral_bwd_fixup')
 
 
+# SE3DS_CHECK_MASKS=1 (debugging): every partial-conv mask that takes a binary-mask fast path
+# is checked for {0, 1} values on the device and the host waits for the verdict -- the fast paths
+# (zero-page gathers, the shared mask windows, 1 x 1 convs without x * mask) rely on it unchecked.
+_CHECK_MASKS = os.environ.get('SE3DS_CHECK_MASKS') == '1'
+
+
 def mask_window(ctx, mask, n, h, w, ho, wo, k, stride, pad_t, pad_l, wrap, want_bwd):
+  if _CHECK_MASKS and ctx.binary_masks and not bool(((mask == 0) | (mask == 1)).all()):
+    raise _lib.Se3dsHipError('a partial-conv mask with values outside {0, 1} reached a binary-mask fast path: '
+                             'set gan.binary_masks = False (ctx.binary_masks) for fractional masks')
   ratio = torch.empty((n, ho, wo), dtype=torch.float32, device=ctx.device)
   um = torch.empty_like(ratio)
   ru = torch.empty_like(ratio) if want_bwd else None
@@ -1155,8 +1164,13 @@ def conv2d(ctx: Ctx, x: Var, layer: ConvLayer, pad=0, wrap=False, mask=None, act
     if in_mask is not None and k == 1 and ctx.binary_masks and _DROP_1X1_MASK:
       # A 1 x 1 partial conv with a {0, 1} mask does not need x * mask: its window IS the pixel, so
       # ratio = update_mask = 0 exactly where the mask is 0 and the epilogue's `* ratio` (and
-      # `* update_mask` behind the bias) zeroes those outputs whatever the product was (activations
-      # are finite); backward, dy * ratio * update_mask is 0 there, so neither the weight gradient
+      # `* update_mask` behind the bias) zeroes those outputs whatever the product was -- PROVIDED the
+      # activation there is finite: 0 * Inf and 0 * NaN are NaN, so a non-finite value at a masked pixel,
+      # which the input mask used to zero, would now reach y, the fused statistics and (dy = 0, x read
+      # unmasked) the weight gradient.  Every input of a 1 x 1 partial conv in this network is a
+      # batch-norm + ReLU output or the finite network input, and a non-finite activation anywhere else
+      # already poisons the batch statistics of its layer; SE3DS_DROP_1X1_MASK=0 keeps the product.
+      # Backward, dy * ratio * update_mask is 0 there, so neither the weight gradient
       # nor dx sees the masked pixels.  Without the mask the kernels skip one dependent global load
       # (mask -> source address of the first LDS-DMA) at the head of every workgroup: ~10 us of a
       # 60 us launch on the encoder's 512 <-> 2048 bottleneck convs.

@@ -14,6 +14,7 @@ import pytest
 import torch
 
 from oracle import nets_torch as O
+from se3ds_amd import _lib
 from se3ds_amd import gin_lite
 from se3ds_amd.hipops import nn
 from se3ds_amd.models import image_models
@@ -918,6 +919,23 @@ def test_partial_conv_fractional_mask_exact_path(cin):
   assert rel_err(xv.grad.cpu().numpy(), xo.grad.numpy()) < 1e-4
   assert rel_err(store.grad_views['c/kernel'].cpu().numpy(), p['c/kernel'].grad.numpy()) < 1e-4
   assert rel_err(store.grad_views['c/bias'].cpu().numpy(), p['c/bias'].grad.numpy()) < 1e-3
+  # SE3DS_CHECK_MASKS (attr nn._CHECK_MASKS, debugging): a fractional mask that reaches a binary-mask
+  # fast path -- Ctx.binary_masks left at its default -- is refused instead of silently mis-weighted
+  old = nn._CHECK_MASKS
+  nn._CHECK_MASKS = True
+  try:
+    ctx2 = nn.Ctx(DEV, torch.float32, training=True, record=False)
+    with pytest.raises(_lib.Se3dsHipError):
+      nn.conv2d(ctx2, nn.Var(to_dev(x.numpy(), torch.float32)), layer, pad=1,
+                mask=to_dev(mask.numpy()[..., 0], torch.float32))
+    ctx2.binary_masks = False   # (declared fractional: the exact path, no complaint)
+    nn.conv2d(ctx2, nn.Var(to_dev(x.numpy(), torch.float32)), layer, pad=1,
+              mask=to_dev(mask.numpy()[..., 0], torch.float32))
+    ctx3 = nn.Ctx(DEV, torch.float32, training=True, record=False)
+    nn.conv2d(ctx3, nn.Var(to_dev(x.numpy(), torch.float32)), layer, pad=1,
+              mask=to_dev((mask.numpy()[..., 0] > 0.5).astype(np.float32), torch.float32))
+  finally:
+    nn._CHECK_MASKS = old
 
 
 def test_fused_adam_ema_is_bit_identical(monkeypatch):

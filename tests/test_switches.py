@@ -27,6 +27,7 @@ OWNERS = {
     'SE3DS_FUSED_BN_BWD': ('tests/test_blocks_gpu.py', '_FUSED_BN_BWD'),
     'SE3DS_FUSED_ROW_SCALE': ('tests/test_blocks_gpu.py', '_FUSED_ROW_SCALE'),
     'SE3DS_NORM_DEBUG': ('tests/test_blocks_gpu.py', '_NORM_DEBUG'),
+    'SE3DS_CHECK_MASKS': ('tests/test_nets_gpu.py', '_CHECK_MASKS'),
     # warp (csrc/geom.hip, utils/point_cloud_utils.py)
     'SE3DS_SPLAT_SCATTER': ('tests/test_warp_gpu.py', 'SE3DS_SPLAT_SCATTER'),
     'SE3DS_SPLAT_PACKED': ('tests/test_warp_gpu.py', 'SE3DS_SPLAT_PACKED'),
