@@ -320,6 +320,29 @@ def batch_max(gan, h, dev, rank, candidates=(32, 24, 16), steps=3):
         nn.set_conv_profiler(None)
         res['roofline_error'] = repr(e)[:200]
         torch.cuda.synchronize()
+      if nb > 24 and 24 in candidates:
+        # ... and batch 24 beside it (rounds 3-5's figure): at 258 of the 268 GiB the allocator works
+        # harder, and the rate saturates near batch 24 -- the line says so instead of hiding it
+        try:
+          big = None
+          gc.collect()
+          torch.cuda.empty_cache()
+          b24 = synth_batch(24, h, 4321 + rank, dev)
+          for _ in range(2):
+            gan.train_g_d(b24)
+            gan.global_step += gan.num_batched_steps
+          torch.cuda.synchronize()
+          t0 = time.perf_counter()
+          for _ in range(steps):
+            gan.train_g_d(b24)
+            gan.global_step += gan.num_batched_steps
+          torch.cuda.synchronize()
+          dt24 = time.perf_counter() - t0
+          res['at_batch_24'] = {'value': 24 * steps / dt24, 'unit': 'panoramas/sec',
+                                'ms_per_step': 1e3 * dt24 / steps, 'steps': steps, 'warmup': 2}
+        except (torch.OutOfMemoryError, RuntimeError) as e:
+          res['at_batch_24'] = {'error': repr(e)[:200]}
+          torch.cuda.synchronize()
       return res
     except (torch.OutOfMemoryError, RuntimeError) as e:   # does not fit: next candidate
       last = repr(e)[:200]
