@@ -110,7 +110,7 @@ def run(args, rank, world, dev, barrier, max_over_ranks):
   if h == 512 and n == 8 and args.dtype == 'bf16':
     from se3ds_amd import bench_util
     traffic, traffic_detail = bench_util.pmc_traffic(
-        'r05_conv_pmc_1024_1024_3_1_32_64_1_8.json', ('igemm_halo_kernel<0, 256, 2',))   # (prefix: the kernel has further template arguments)
+        'r06_conv_pmc_1024_1024_3_1_32_64_1_8.json', ('igemm_halo_kernel<0, 256, 2',))   # (prefix: the kernel has further template arguments)
     if traffic_detail is not None:
       traffic_detail['kernel'] = 'igemm_halo_kernel<0, 256, 2> (3x3 1024->1024 @32x64, batch 8)'
       traffic_detail['algorithmic_mb'] = 52.4 + 33.6

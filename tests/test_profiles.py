@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SUMMARIES = [
-    'profiles/r05_conv_pmc_1024_1024_3_1_32_64_1_8.json',
+    'profiles/r06_conv_pmc_1024_1024_3_1_32_64_1_8.json',
     'profiles/r06_warp_pmc.json',
     'profiles/r06_warp_valu_pmc.json',
 ]
