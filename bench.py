@@ -247,14 +247,16 @@ def bench_warp(args, rank, world, dev):
   proj_ms = timed(project_c, reps)
   algo_bytes = 28 * M + 20 * P  # 28 B/point in, 16 B/px out + 4 B/px mask
   achieved = algo_bytes / (proj_ms * 1e-3) / 1e9
-  # the other kernel of the step: one view's unproject (44 B per pixel: 4 depth + 12 features in,
-  # 16 coordinates + 12 features out), into its window of the memory
+  # the other kernel of the step: one view's unproject (44 B per pixel algorithmic: 4 depth + 12 features in,
+  # 16 coordinates + 12 features out; into a point-cloud memory, whose homogeneous row is preset, it moves 40),
+  # into its window of the memory
   rgb0, depth0, pos0 = g[0]
   tab = _host_tables.equirect_tables(h, w, dev)
   tb = tab.data_ptr()
   def unproject_c():
     lib_mod.check(L.se3ds_unproject_equirect_into(
-        rgb0.data_ptr(), lib_mod.I32, depth0.data_ptr(), tb, tb + 4 * h, tb + 8 * h, tb + 8 * h + 4 * w,
+        rgb0.data_ptr(), lib_mod.I32 | point_cloud_utils.XYZ1_ONES_PRESET, depth0.data_ptr(), tb, tb + 4 * h,
+        tb + 8 * h, tb + 8 * h + 4 * w,
         pos0.data_ptr(), 1, h, w, 3, -1.0, 20.0, mem._x.data_ptr(), mem._f.data_ptr(), mem.capacity, 0,
         st), 'se3ds_unproject_equirect_into')
   unp_alone_ms = timed(unproject_c, reps)
@@ -270,7 +272,8 @@ def bench_warp(args, rank, world, dev):
   vf, vd, vp = arr([x[0].data_ptr() for x in g]), arr([x[1].data_ptr() for x in g]), arr([x[2].data_ptr() for x in g])
   def step_c():
     lib_mod.check(L.se3ds_warp_views_to_target(
-        vf, lib_mod.I32 | hint, vd, vp, views, 1, h, w, 3, -1.0, 20.0, tb, tb + 4 * h, tb + 8 * h,
+        vf, lib_mod.I32 | hint | point_cloud_utils.XYZ1_ONES_PRESET, vd, vp, views, 1, h, w, 3, -1.0, 20.0, tb,
+        tb + 4 * h, tb + 8 * h,
         tb + 8 * h + 4 * w, mem._x.data_ptr(), mem._f.data_ptr(), mem.capacity, 0, tgt.data_ptr(), h, w, 0.0,
         d_o.data_ptr(), f_o.data_ptr(), m_o.data_ptr(), -1.0, ws.data_ptr(), ws.numel(), st),
         'se3ds_warp_views_to_target')

@@ -41,6 +41,12 @@ extern "C" {
  * promise.  A broken promise is detected (se3ds_splat_promise_broken) but the outputs of that
  * call are undefined. */
 #define SE3DS_FEAT_BYTE_RANGE 0x100
+/* OR-ed into the `feat_dtype` of se3ds_unproject_equirect_into / se3ds_warp_views_to_target: the caller
+ * guarantees that row 3 of xyz1 (the homogeneous 1, models/models.py:225-226 adds 0 to it) ALREADY holds
+ * 1.0 in the window being written -- a point-cloud memory fills that row once when it is allocated -- and
+ * the kernel does not write it again: 40 instead of 44 bytes per pixel (round 6; the splat never reads
+ * the row, the memory keeps it for callers of the (N,4,M) view). */
+#define SE3DS_XYZ1_ONES_PRESET 0x200
 
 /* Library / build identification: returns a static string "se3ds_hip <abi> gfx950". */
 const char* se3ds_version(void);

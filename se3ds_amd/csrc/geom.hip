@@ -43,7 +43,7 @@ unproject_equirect_kernel(const T* __restrict__ feats, const float* __restrict__
                           const float* __restrict__ sin_hd, const float* __restrict__ cos_hd,
                           const float* __restrict__ position, int height, int width, int channels,
                           float void_class, float depth_scale, float* __restrict__ xyz1,
-                          T* __restrict__ feats_out, int64_t m_total, int64_t m_offset) {
+                          T* __restrict__ feats_out, int64_t m_total, int64_t m_offset, int write_ones) {
   // outputs are windows [m_offset, m_offset + H*W) of a (N,4,m_total) / (N,m_total,C) memory
   const int b = blockIdx.y;
   const int64_t p = (int64_t)height * width;
@@ -75,7 +75,7 @@ unproject_equirect_kernel(const T* __restrict__ feats, const float* __restrict__
     X[i] = x;
     X[m_total + i] = y;
     X[2 * m_total + i] = z;
-    X[3 * m_total + i] = 1.0f;
+    if (write_ones) X[3 * m_total + i] = 1.0f;
     const T* fi = feats + ((int64_t)b * p + i) * channels;
     T* fo = feats_out + ((int64_t)b * m_total + m_offset + i) * channels;
     for (int k = 0; k < channels; ++k) fo[k] = valid ? fi[k] : vc;
@@ -96,7 +96,8 @@ unproject_equirect_vec4_kernel(const T* __restrict__ feats, const float* __restr
                                const float* __restrict__ sin_hd, const float* __restrict__ cos_hd,
                                const float* __restrict__ position, int height, int width,
                                float void_class, float depth_scale, float* __restrict__ xyz1,
-                               T* __restrict__ feats_out, int64_t m_total, int64_t m_offset) {
+                               T* __restrict__ feats_out, int64_t m_total, int64_t m_offset,
+                               int write_ones) {
   static_assert(sizeof(T) == 4 && (C == 1 || C == 3), "4-byte features, 1 or 3 channels");
   const int b = blockIdx.y;
   const uint32_t qw = (uint32_t)width >> 2;          // quads per row
@@ -149,7 +150,8 @@ unproject_equirect_vec4_kernel(const T* __restrict__ feats, const float* __restr
     *reinterpret_cast<float4*>(X + i) = make_float4(xo[0], xo[1], xo[2], xo[3]);
     *reinterpret_cast<float4*>(X + m_total + i) = make_float4(yo[0], yo[1], yo[2], yo[3]);
     *reinterpret_cast<float4*>(X + 2 * m_total + i) = make_float4(zo[0], zo[1], zo[2], zo[3]);
-    *reinterpret_cast<float4*>(X + 3 * m_total + i) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (write_ones)   // (SE3DS_XYZ1_ONES_PRESET: the memory's row 3 was filled when it was allocated)
+      *reinterpret_cast<float4*>(X + 3 * m_total + i) = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     T* fo = feats_out + ((int64_t)b * m_total + m_offset + i) * C;
 #pragma unroll
     for (int k = 0; k < C; ++k)
@@ -3641,6 +3643,9 @@ int se3ds_unproject_equirect_into(const void* feats, int feat_dtype, const float
                                   float* xyz1, void* feats_out, int64_t m_total, int64_t m_offset,
                                   void* stream) {
   if (n <= 0 || height <= 0 || width <= 0 || channels <= 0) return SE3DS_E_BADSHAPE;
+  // SE3DS_XYZ1_ONES_PRESET: row 3 of the window already holds 1.0 (a memory fills it at allocation)
+  const int write_ones = (feat_dtype & SE3DS_XYZ1_ONES_PRESET) ? 0 : 1;
+  feat_dtype &= ~SE3DS_XYZ1_ONES_PRESET;
   hipStream_t s = as_stream(stream);
   int64_t p = (int64_t)height * width;
   if (m_offset < 0 || m_offset + p > m_total) return SE3DS_E_BADSHAPE;
@@ -3657,7 +3662,7 @@ int se3ds_unproject_equirect_into(const void* feats, int feat_dtype, const float
 #define SE3DS_U4(T, CC)                                                                          \
     hipLaunchKernelGGL((unproject_equirect_vec4_kernel<T, CC>), g4, dim3(kBlock), 0, s,          \
                        (const T*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position, height, \
-                       width, void_class, depth_scale, xyz1, (T*)feats_out, m_total, m_offset)
+                       width, void_class, depth_scale, xyz1, (T*)feats_out, m_total, m_offset, write_ones)
     if (feat_dtype == SE3DS_F32) {
       if (channels == 3) SE3DS_U4(float, 3); else SE3DS_U4(float, 1);
     } else {
@@ -3671,20 +3676,20 @@ int se3ds_unproject_equirect_into(const void* feats, int feat_dtype, const float
       hipLaunchKernelGGL(unproject_equirect_kernel<float>, grid, dim3(kBlock), 0, s,
                          (const float*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position,
                          height, width, channels, void_class, depth_scale, xyz1, (float*)feats_out,
-                         m_total, m_offset);
+                         m_total, m_offset, write_ones);
       break;
     case SE3DS_I32:
       hipLaunchKernelGGL(unproject_equirect_kernel<int32_t>, grid, dim3(kBlock), 0, s,
                          (const int32_t*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position,
                          height, width, channels, void_class, depth_scale, xyz1,
-                         (int32_t*)feats_out, m_total, m_offset);
+                         (int32_t*)feats_out, m_total, m_offset, write_ones);
       break;
     case SE3DS_U8:
       if (void_class < 0.0f) return SE3DS_E_BADDTYPE;  // pano_utils.py:193-197
       hipLaunchKernelGGL(unproject_equirect_kernel<uint8_t>, grid, dim3(kBlock), 0, s,
                          (const uint8_t*)feats, depth, sin_el, cos_el, sin_hd, cos_hd, position,
                          height, width, channels, void_class, depth_scale, xyz1,
-                         (uint8_t*)feats_out, m_total, m_offset);
+                         (uint8_t*)feats_out, m_total, m_offset, write_ones);
       break;
     default:
       return SE3DS_E_BADDTYPE;
@@ -3750,7 +3755,8 @@ int se3ds_warp_views_to_target(const void* const* view_feats, int feat_dtype,
   if (views < 0 || n <= 0 || height <= 0 || width <= 0) return SE3DS_E_BADSHAPE;
   const int64_t p = (int64_t)height * width;
   if (m_offset < 0 || m_offset + (int64_t)views * p > capacity) return SE3DS_E_BADSHAPE;
-  const int dt = feat_dtype & ~SE3DS_FEAT_BYTE_RANGE;
+  const int dt = feat_dtype & ~SE3DS_FEAT_BYTE_RANGE;   // (keeps SE3DS_XYZ1_ONES_PRESET for the unprojects)
+  feat_dtype &= ~SE3DS_XYZ1_ONES_PRESET;
   for (int v = 0; v < views; ++v) {
     const int rc = se3ds_unproject_equirect_into(
         view_feats[v], dt, view_depth[v], sin_el, cos_el, sin_hd, cos_hd,

@@ -70,8 +70,8 @@ def equirectangular_to_pointcloud(feats: torch.Tensor, depth: torch.Tensor, void
                                   depth_scale: float, size_mult: float = 1.0,
                                   interpolation_method: str = 'nearest',
                                   position: Optional[torch.Tensor] = None,
-                                  out: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None
-                                  ) -> Tuple[torch.Tensor, torch.Tensor]:
+                                  out: Optional[Tuple[torch.Tensor, torch.Tensor, int]] = None,
+                                  ones_preset: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
   """Equirect image + depth -> point cloud (reference :164-242).
 
   feats (N,H,W) or (N,H,W,C) [uint8 / int32 / float32], depth (N,H,W) in [0,1].  Returns xyz1
@@ -120,8 +120,11 @@ def equirectangular_to_pointcloud(feats: torch.Tensor, depth: torch.Tensor, void
     m_total, off = h * w, 0
     xyz1 = torch.empty((n, 4, h * w), dtype=torch.float32, device=dev)
     res = torch.empty((n, h * w, c), dtype=feats.dtype, device=dev)
+  # ones_preset (with `out`): row 3 of the window already holds 1.0 -- PointCloudMemory fills it when it
+  # allocates -- and the kernel skips those 4 of its 44 bytes per pixel (SE3DS_XYZ1_ONES_PRESET)
+  flag = point_cloud_utils.XYZ1_ONES_PRESET if (ones_preset and out is not None) else 0
   rc = _lib.lib().se3ds_unproject_equirect_into(
-      _lib.ptr(feats), _lib.dtype_code(feats), _lib.ptr(depth), base, base + 4 * h,
+      _lib.ptr(feats), _lib.dtype_code(feats) | flag, _lib.ptr(depth), base, base + 4 * h,
       base + 8 * h, base + 8 * h + 4 * w, _lib.ptr(position), n, h, w, c, float(void_class),
       float(depth_scale), _lib.ptr(xyz1), _lib.ptr(res), m_total, off, _lib.stream())
   _lib.check(rc, 'se3ds_unproject_equirect')

@@ -75,6 +75,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 
 FEAT_BYTE_RANGE = 0x100   # include/se3ds_hip.h SE3DS_FEAT_BYTE_RANGE
+XYZ1_ONES_PRESET = 0x200  # include/se3ds_hip.h SE3DS_XYZ1_ONES_PRESET
 # A broken byte-range promise makes the packed splat pack f & 255: silently wrong features.  The
 # kernels raise a sticky flag in the workspace; it is read back ASYNCHRONOUSLY after the FIRST
 # promised splat of a process and after every _PROMISE_POLL_EVERY-th (a 1-thread kernel + a 4-byte
@@ -372,6 +373,9 @@ class PointCloudMemory:
     cap = max(capacity, 2 * self.capacity)
     x = torch.empty((self.n, 4, cap), dtype=torch.float32, device=self.device)
     f = torch.empty((self.n, cap, self.c), dtype=self.dtype, device=self.device)
+    # the homogeneous row is 1.0 for every point ever written (models.py:225-226 adds 0 to it): filled
+    # ONCE here, so that the unprojects write 40 instead of 44 bytes per pixel (SE3DS_XYZ1_ONES_PRESET)
+    x[:, 3, :].fill_(1.0)
     if self.m:
       x[:, :, :self.m].copy_(self._x[:, :, :self.m])
       f[:, :self.m].copy_(self._f[:, :self.m])
@@ -388,7 +392,8 @@ class PointCloudMemory:
     # (the unprojected features are the source's, or void: the promise carries over)
     self.byte_range = self.byte_range and byte_range(feats, void_class)
     pano_utils.equirectangular_to_pointcloud(feats, depth, void_class, depth_scale,
-                                             position=position, out=(self._x, self._f, self.m))
+                                             position=position, out=(self._x, self._f, self.m),
+                                             ones_preset=True)
     self.m += p
 
   def clear(self):
@@ -472,7 +477,8 @@ class PointCloudMemory:
       target = target.to(torch.float32).contiguous()
     hint = FEAT_BYTE_RANGE if (self.dtype == torch.int32 and c <= 3 and br_new) else 0
     rc = L.se3ds_warp_views_to_target(
-        arr(fl), _lib.dtype_code(self._f) | hint, arr(dl), arr(pl) if any_pos else None, nv, n, vh, vw,
+        arr(fl), _lib.dtype_code(self._f) | hint | XYZ1_ONES_PRESET, arr(dl), arr(pl) if any_pos else None,
+        nv, n, vh, vw,
         c, float(void_class), float(depth_scale), base, base + 4 * vh, base + 8 * vh,
         base + 8 * vh + 4 * vw, _lib.ptr(self._x), _lib.ptr(self._f), self.capacity, self.m,
         _lib.ptr(target), height, width, float(output_void_class), _lib.ptr(depth_o), _lib.ptr(out),

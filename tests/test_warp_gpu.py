@@ -100,6 +100,14 @@ def test_unproject_vec4_kernel_equals_scalar_kernel(dtype, c, monkeypatch):
       np.testing.assert_array_equal(mem_f[:, off:off + h * w].cpu().numpy(), f_o)
       assert float(mem_x[:, :, :off].min()) == 7.0 and float(mem_x[:, :, off + h * w:].min()) == 7.0
       assert int(mem_f[:, :off].min()) == 5 and int(mem_f[:, off + h * w:].min()) == 5
+      # SE3DS_XYZ1_ONES_PRESET (round 6): the homogeneous row of the window is the CALLER's -- a point-cloud
+      # memory fills it with 1.0 once -- and is not written; rows 0-2 and the features are as before
+      mem_x2 = torch.full((n, 4, m), 7.0, device=dev())
+      mem_f2 = torch.full((n, m, c), 5, dtype=t(feats).dtype, device=dev())
+      pano_utils.equirectangular_to_pointcloud(t(feats), t(depth), -1, DEPTH_SCALE, out=(mem_x2, mem_f2, off),
+                                               ones_preset=True)
+      assert torch.equal(mem_x2[:, :3], mem_x[:, :3]) and torch.equal(mem_f2, mem_f)
+      assert float(mem_x2[:, 3].min()) == 7.0 and float(mem_x2[:, 3].max()) == 7.0
     res[vec] = (x.cpu().numpy(), f.cpu().numpy())
   np.testing.assert_array_equal(res['0'][0], res['1'][0])
   np.testing.assert_array_equal(res['0'][1], res['1'][1])
