@@ -108,14 +108,15 @@ def _worker(rank, world, port, mode, out):
           return vals
         return run
       res = ctx.run_branches({1: branch(1), 2: branch(2)})
+      tri = world * (world - 1) // 2   # (sum of the ranks: every rank contributes value + rank)
       for tag in (1, 2):
         for k, v in enumerate(res[tag]):
-          assert torch.equal(v, torch.full((2, 4), float(2 * (100 * tag + 10 * k) + 1))), (tag, k)
+          assert torch.equal(v, torch.full((2, 4), float(world * (100 * tag + 10 * k) + tri))), (tag, k)
       assert ctx.collectives == 3, ctx.collectives          # 6 sums, 3 all-reduces
       ctx.backward()
       assert ctx.collectives == 6, ctx.collectives          # ... and 3 more for the 6 backward sums
       got = sorted((tag, k, float(g[0, 0])) for tag, k, g in seen['bwd'])
-      assert got == sorted((tag, k, float(2 * (1000 * tag + 10 * k) + 1)) for tag in (1, 2)
+      assert got == sorted((tag, k, float(world * (1000 * tag + 10 * k) + tri)) for tag in (1, 2)
                            for k in range(3)), got
       # per-branch order of the backward closures is kept: k = 2, 1, 0
       for tag in (1, 2):
@@ -146,12 +147,12 @@ def _worker(rank, world, port, mode, out):
     dist.destroy_process_group()
 
 
-def _run(mode):
+def _run(mode, world=2):
   ctx = mp.get_context('spawn')
   mgr = ctx.Manager()
   out = mgr.dict()
   port = _free_port()
-  procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, out)) for r in range(2)]
+  procs = [ctx.Process(target=_worker, args=(r, world, port, mode, out)) for r in range(world)]
   for p in procs:
     p.start()
   for p in procs:
@@ -178,12 +179,14 @@ def test_two_replica_step_semantics_gloo():
   assert np.isfinite(out[0]['sum']).all()
 
 
-def test_paired_syncbn_collectives_gloo():
+@pytest.mark.parametrize('world', [2, 4])
+def test_paired_syncbn_collectives_gloo(world):
   """the SyncBN sums of two lockstep branches go out as one all-reduce per pair,
   forward (two host threads meeting at a barrier) and backward (twin closures placed next to each
-  other): 12 reduced tensors, 6 collectives, every value the cross-replica sum."""
-  out = _run('paired_syncbn')
-  assert int(out[0][0]) == 6 and int(out[1][0]) == 6
+  other): 12 reduced tensors, 6 collectives, every value the cross-replica sum -- on 2 ranks and on 4
+  (cfg4 in miniature: the pairing is per rank, the sums are over all of them)."""
+  out = _run('paired_syncbn', world)
+  assert all(int(out[r][0]) == 6 for r in range(world))
 
 
 class _PacedSync(dist_utils.GradSync):
