@@ -2568,6 +2568,22 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
   }
   __syncthreads();
   SE3DS_STAMP(0, 3);   // exact pass done, all waves through the barrier
+  // ---- sink partials of the invalid points (as the packed path).  They are final here -- the exact
+  // pass was the last to feed them -- and their reduction rides on the scan's barriers below (round 6:
+  // as the kernel's tail it cost every workgroup a barrier and a serial loop behind its stores, ~0.7 us)
+  __shared__ uint32_t s_red[1 + C][kSThreads / 64];
+  sink = wave_min_u32(sink);
+  bad = wave_max_u32(bad);
+  if ((threadIdx.x & 63) == 0) s_red[0][threadIdx.x >> 6] = sink;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const uint32_t v = wave_max_u32(smax[k]);
+    if ((threadIdx.x & 63) == 0) s_red[1 + k][threadIdx.x >> 6] = v;
+  }
+  if ((threadIdx.x & 63) == 0 && bad != 0u) {
+    atomicExch(&sw.ctl[1], sw.epoch);
+    atomicOr(&ws.sink_z[kPromiseStickyWord], 1u);
+  }
   // ---- phase 3: exclusive scan of the supertile counts (<= 2048: four per thread), run descriptors
   uint32_t all;
   {
@@ -2579,6 +2595,20 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
       sum += c[q];
     }
     uint32_t ex = block_excl_scan_u32<kSThreads / 64>(sum, s_w, &all);
+    {   // (s_red is visible behind the scan's barriers)
+      const int part = blockIdx.y * gridDim.x + blockIdx.x;
+      if (threadIdx.x == 0) {
+        uint32_t v = s_red[0][0];
+        for (int i = 1; i < kSThreads / 64; ++i) v = s_red[0][i] < v ? s_red[0][i] : v;
+        ws.zpart[part] = v;
+      }
+      if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + C) {
+        const int k = threadIdx.x - 64;
+        uint32_t v = 0u;
+        for (int i = 0; i < kSThreads / 64; ++i) v = s_red[1 + k][i] > v ? s_red[1 + k][i] : v;
+        ws.fpart[(int64_t)part * C + k] = v;
+      }
+    }
     uint32_t* R = sw.runs + ((int64_t)b * nsuper) * sw.cstride + run_slot(blockIdx.x, sw.cstride);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -2613,34 +2643,7 @@ splat_sort_kernel(const float* __restrict__ coords, const float* __restrict__ of
       *reinterpret_cast<uint4*>(H + j) = *reinterpret_cast<const uint4*>(s_hi + j);
   }
   SE3DS_STAMP(0, 6);   // chunk stores issued
-  // ---- sink partials of the invalid points (as the packed path)
-  __shared__ uint32_t s_red[1 + C][kSThreads / 64];
-  sink = wave_min_u32(sink);
-  bad = wave_max_u32(bad);
-  if ((threadIdx.x & 63) == 0) s_red[0][threadIdx.x >> 6] = sink;
-#pragma unroll
-  for (int k = 0; k < C; ++k) {
-    const uint32_t v = wave_max_u32(smax[k]);
-    if ((threadIdx.x & 63) == 0) s_red[1 + k][threadIdx.x >> 6] = v;
-  }
-  if ((threadIdx.x & 63) == 0 && bad != 0u) {
-    atomicExch(&sw.ctl[1], sw.epoch);
-    atomicOr(&ws.sink_z[kPromiseStickyWord], 1u);
-  }
-  __syncthreads();
-  const int part = blockIdx.y * gridDim.x + blockIdx.x;
-  if (threadIdx.x == 0) {
-    uint32_t v = s_red[0][0];
-    for (int i = 1; i < kSThreads / 64; ++i) v = s_red[0][i] < v ? s_red[0][i] : v;
-    ws.zpart[part] = v;
-  }
-  if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + C) {
-    const int k = threadIdx.x - 64;
-    uint32_t v = 0u;
-    for (int i = 0; i < kSThreads / 64; ++i) v = s_red[1 + k][i] > v ? s_red[1 + k][i] : v;
-    ws.fpart[(int64_t)part * C + k] = v;
-  }
-  SE3DS_STAMP(0, 7);   // end
+  SE3DS_STAMP(0, 7);   // end (the sink partials left with the scan)
 }
 
 // byte-wise max of two words of three feature bytes
